@@ -1,0 +1,148 @@
+"""Architecture constants the native path needs.
+
+Mirrors the fields of the reference's ``AceStepConfig``
+(/root/reference/acestep/models/base/configuration_acestep_v15.py:148-263) and of
+``AutoencoderOobleck.config`` (acestep/models/mlx/vae_model.py:251-264, 322-336).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+
+@dataclass
+class DitConfig:
+    hidden_size: int = 2048
+    intermediate_size: int = 6144
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    sliding_window: int = 128
+    patch_size: int = 2
+    in_channels: int = 192
+    audio_acoustic_hidden_dim: int = 64
+    layer_types: Optional[List[str]] = None
+
+    def __post_init__(self):
+        if self.layer_types is None:
+            # configuration_acestep_v15.py:251-254
+            self.layer_types = [
+                "sliding_attention" if (i + 1) % 2 else "full_attention" for i in range(self.num_hidden_layers)
+            ]
+
+    @classmethod
+    def from_reference(cls, cfg) -> "DitConfig":
+        """Build from an ``AceStepConfig`` instance (``self.model.config`` on the handler)."""
+        return cls(
+            hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+            num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+            num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+            rms_norm_eps=cfg.rms_norm_eps, rope_theta=float(getattr(cfg, "rope_theta", 1e6)),
+            sliding_window=cfg.sliding_window or 0, patch_size=cfg.patch_size, in_channels=cfg.in_channels,
+            audio_acoustic_hidden_dim=cfg.audio_acoustic_hidden_dim, layer_types=list(cfg.layer_types),
+        )
+
+    def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Names/shapes of ``AceStepDiTModel.state_dict()`` (modeling_acestep_v15_base.py:1248-1299)."""
+        D, Fh, hd = self.hidden_size, self.intermediate_size, self.head_dim
+        q, kv = self.num_attention_heads * hd, self.num_key_value_heads * hd
+        s: Dict[str, Tuple[int, ...]] = {}
+        for li in range(self.num_hidden_layers):
+            p = f"layers.{li}."
+            s[p + "scale_shift_table"] = (1, 6, D)
+            for n in ("self_attn_norm", "cross_attn_norm", "mlp_norm"):
+                s[p + n + ".weight"] = (D,)
+            for a in ("self_attn", "cross_attn"):
+                s[p + a + ".q_proj.weight"] = (q, D)
+                s[p + a + ".k_proj.weight"] = (kv, D)
+                s[p + a + ".v_proj.weight"] = (kv, D)
+                s[p + a + ".o_proj.weight"] = (D, q)
+                s[p + a + ".q_norm.weight"] = (hd,)
+                s[p + a + ".k_norm.weight"] = (hd,)
+            s[p + "mlp.gate_proj.weight"] = (Fh, D)
+            s[p + "mlp.up_proj.weight"] = (Fh, D)
+            s[p + "mlp.down_proj.weight"] = (D, Fh)
+        s["proj_in.1.weight"] = (D, self.in_channels, self.patch_size)
+        s["proj_in.1.bias"] = (D,)
+        for e in ("time_embed", "time_embed_r"):
+            s[e + ".linear_1.weight"] = (D, 256)
+            s[e + ".linear_1.bias"] = (D,)
+            s[e + ".linear_2.weight"] = (D, D)
+            s[e + ".linear_2.bias"] = (D,)
+            s[e + ".time_proj.weight"] = (6 * D, D)
+            s[e + ".time_proj.bias"] = (6 * D,)
+        s["condition_embedder.weight"] = (D, D)
+        s["condition_embedder.bias"] = (D,)
+        s["norm_out.weight"] = (D,)
+        s["proj_out.1.weight"] = (D, self.audio_acoustic_hidden_dim, self.patch_size)
+        s["proj_out.1.bias"] = (self.audio_acoustic_hidden_dim,)
+        s["scale_shift_table"] = (1, 2, D)
+        return s
+
+
+@dataclass
+class VaeConfig:
+    """Decoder half of AutoencoderOobleck.  Strides are run-time data (checkpoints/vae/config.json);
+    the synthetic default has hop 1920 (handler/conditioning_target.py:47,53)."""
+
+    decoder_channels: int = 128
+    decoder_input_channels: int = 64
+    audio_channels: int = 2
+    channel_multiples: Tuple[int, ...] = (1, 2, 4, 8, 16)
+    downsampling_ratios: Tuple[int, ...] = (2, 4, 4, 6, 10)
+
+    @classmethod
+    def from_reference(cls, cfg) -> "VaeConfig":
+        return cls(decoder_channels=cfg.decoder_channels, decoder_input_channels=cfg.decoder_input_channels,
+                   audio_channels=cfg.audio_channels, channel_multiples=tuple(cfg.channel_multiples),
+                   downsampling_ratios=tuple(cfg.downsampling_ratios))
+
+    @property
+    def upsampling_ratios(self) -> Tuple[int, ...]:
+        return tuple(self.downsampling_ratios[::-1])
+
+    @property
+    def hop(self) -> int:
+        return int(math.prod(self.downsampling_ratios))
+
+    def block_dims(self) -> List[Tuple[int, int, int]]:
+        cm = [1] + list(self.channel_multiples)
+        s = self.upsampling_ratios
+        n = len(s)
+        return [(self.decoder_channels * cm[n - i], self.decoder_channels * cm[n - i - 1], s[i]) for i in range(n)]
+
+    def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """state_dict names/shapes of the decoder half (acestep/models/mlx/vae_convert.py:62-127)."""
+        sh: Dict[str, Tuple[int, ...]] = {}
+
+        def conv(name, cout, cin, k, bias=True):
+            sh[name + ".weight_g"] = (cout, 1, 1)
+            sh[name + ".weight_v"] = (cout, cin, k)
+            if bias:
+                sh[name + ".bias"] = (cout,)
+
+        def snk(name, c):
+            sh[name + ".alpha"] = (1, c, 1)
+            sh[name + ".beta"] = (1, c, 1)
+
+        dims = self.block_dims()
+        conv("decoder.conv1", dims[0][0], self.decoder_input_channels, 7)
+        for i, (cin, cout, s) in enumerate(dims):
+            p = f"decoder.block.{i}"
+            snk(p + ".snake1", cin)
+            sh[p + ".conv_t1.weight_g"] = (cin, 1, 1)
+            sh[p + ".conv_t1.weight_v"] = (cin, cout, 2 * s)
+            sh[p + ".conv_t1.bias"] = (cout,)
+            for j in (1, 2, 3):
+                r = f"{p}.res_unit{j}"
+                snk(r + ".snake1", cout)
+                conv(r + ".conv1", cout, cout, 7)
+                snk(r + ".snake2", cout)
+                conv(r + ".conv2", cout, cout, 1)
+        snk("decoder.snake1", self.decoder_channels)
+        conv("decoder.conv2", self.audio_channels, self.decoder_channels, 7, bias=False)
+        return sh

@@ -1,0 +1,200 @@
+/*
+ * ace355.h - C ABI of the MI355X-native (gfx950) ACE-Step 1.5 denoise + decode path.
+ *
+ * The reference (sdbds/ACE-Step-1.5-for-windows) has no FFI; its backend seam is a pair
+ * of Python mixin methods added for MLX.  This header is what a ctypes binding
+ * behind that seam talks to (INTEGRATION.md shows the stub).  Every entry point cites the
+ * reference interface it replaces (paths relative to /root/reference/acestep/):
+ *
+ *   base.py = models/base/modeling_acestep_v15_base.py      H/ = core/generation/handler/
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes; no torch / C++ types.
+ *   - "dev" pointers are HIP device pointers on the current device; "host" pointers are
+ *     ordinary host memory.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every function returns ACE355_OK (0) or an error code; ace355_last_error() returns a
+ *     thread-local message (HIP error string included).  Nothing aborts the process
+ *     (reference contract: backend failure = exception caught at the seam,
+ *     H/service_generate_execute.py:189-191, H/vae_decode.py:44-48).
+ *   - handles are not thread-safe; one generation in flight per handle (SURVEY.md section 5,
+ *     "Race detection": the reference serialises requests per handler).
+ */
+#ifndef ACE355_H
+#define ACE355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACE355_OK 0
+#define ACE355_ERR_INVALID 1 /* bad argument / shape / unknown tensor name */
+#define ACE355_ERR_HIP 2     /* a HIP runtime call failed */
+#define ACE355_ERR_STATE 3   /* call order violated (e.g. forward before finalize) */
+#define ACE355_ERR_UNSUPPORTED 4
+
+#define ACE355_DTYPE_F32 0
+#define ACE355_DTYPE_BF16 1
+
+#define ACE355_MAX_BLOCKS 8
+#define ACE355_MAX_SEQS 64
+
+const char* ace355_last_error(void);
+int ace355_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * DiT decoder (AceStepDiTModel, base.py:1240-1507) + sampler (generate_audio, base.py:1783-1989)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ace355_dit ace355_dit;
+
+/* Fields of AceStepConfig the path uses (models/base/configuration_acestep_v15.py:148-263). */
+typedef struct ace355_dit_config {
+    int32_t hidden_size;       /* 2048 */
+    int32_t intermediate_size; /* 6144 */
+    int32_t num_layers;        /* 24 */
+    int32_t num_heads;         /* 16 */
+    int32_t num_kv_heads;      /* 8 */
+    int32_t head_dim;          /* 128 (only 128 is supported) */
+    int32_t sliding_window;    /* 128: |i-j| <= window, inclusive (base.py:99-105) */
+    int32_t patch_size;        /* 2 (only 2 is supported) */
+    int32_t in_channels;       /* 192 = 128 context + 64 latent */
+    int32_t out_channels;      /* 64 */
+    float rms_norm_eps;        /* 1e-6 */
+    float rope_theta;          /* 1e6 */
+    uint64_t sliding_layer_mask; /* bit i set = layer i is "sliding_attention" (cfg.py:251-254) */
+} ace355_dit_config;
+
+/* Replaces H/mlx_dit_init.py:9-43 (_init_mlx_dit) + models/mlx/dit_convert.py:69-84. */
+int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out);
+void ace355_dit_destroy(ace355_dit* h);
+
+/* Upload one tensor of AceStepDiTModel.state_dict() by its reference name (e.g.
+ * "layers.3.self_attn.q_proj.weight", "proj_in.1.weight", "time_embed.linear_1.bias",
+ * "scale_shift_table").  `data` holds `numel` elements of `dtype`, on host or device.
+ * The library converts / packs into its own MFMA-friendly bf16 layout (fused QKV,
+ * interleaved gate|up, patchify as GEMM).  Unknown names or wrong numel -> ERR_INVALID. */
+int ace355_dit_load_tensor(ace355_dit* h, const char* name, const void* data, int dtype, int64_t numel, int is_device);
+/* Verifies that every tensor was loaded; must be called once before set_condition/forward. */
+int ace355_dit_finalize(ace355_dit* h);
+
+/* Encoder conditioning for one "slot" (cond, null, non-cover cond, ...).
+ * Runs condition_embedder (base.py:1359) and every layer's cross-attention
+ * K = k_norm(k_proj(.)), V = v_proj(.) ONCE (the reference's EncoderDecoderCache,
+ * base.py:312-329, 1875) and keeps them resident until the slot is overwritten.
+ * enc: dev f32 [rows, hidden]; rows == L, or rows == 1 to broadcast one row over L keys
+ * (null_condition_emb.expand_as, base.py:1907).  slot in [0, 8). */
+int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int rows, int L, void* stream);
+
+/* One decoder forward = AceStepDiTModel.forward (base.py:1303-1507) with use_cache=True and
+ * a filled cross cache.  x dev f32 [N,T,64]; ctx dev f32 [N,T,128]; t, t_r host [N];
+ * slots host [N] (which condition slot each sequence attends to); v_out dev f32 [N,T,64]. */
+int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, const float* t_host,
+                       const float* t_r_host, const int32_t* slots_host, int N, int T, float* v_out_dev, void* stream);
+
+/* Knobs of generate_audio (base.py:1796-1812) that survive past prepare_condition. */
+typedef struct ace355_sample_params {
+    int32_t num_steps;          /* len(t_sched) - 1 */
+    const float* t_sched_host;  /* [num_steps+1] fp32, base.py:1864-1867 (caller applies shift / custom timesteps) */
+    float guidance_scale;       /* diffusion_guidance_sale; > 1 enables CFG batch doubling (base.py:1905) */
+    float cfg_interval_start;   /* base.py:1945 */
+    float cfg_interval_end;
+    int32_t infer_method;       /* 0 = "ode" (base.py:1974-1979); 1 = "sde" -> ERR_UNSUPPORTED (unseeded RNG) */
+    int32_t use_adg;            /* 1 -> ERR_UNSUPPORTED this round (apg_guidance.py:107-180) */
+    int32_t cond_slot;          /* slot of the cover/main condition */
+    int32_t null_slot;          /* slot holding null_condition_emb (ignored when guidance <= 1) */
+    int32_t cover_switch_step;  /* = int(steps * audio_cover_strength); >= num_steps: never switch (base.py:1916-1927) */
+    int32_t non_cover_slot;     /* slot + context used from cover_switch_step on */
+    const float* ctx_non_cover_dev; /* dev f32 [B,T,128] or NULL */
+} ace355_sample_params;
+
+/* The sampling loop of generate_audio (base.py:1913-1981): CFG doubling, steps x {decoder forward,
+ * APG (apg_guidance.py:33-56, momentum -0.75, norm threshold 2.5, fp64 projection), Euler update}.
+ * xt0 dev f32 [B,T,64] is the initial state (noise, or the cover renoise of base.py:1887, prepared by
+ * the caller on the host with the CPU generator: SURVEY.md section 7.2 "Noise parity");
+ * ctx dev f32 [B,T,128]; latents_out dev f32 [B,T,64] ("target_latents").
+ * per_step_ms_host (optional, [num_steps]) receives HIP-event step times. */
+int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev, int B, int T,
+                      const ace355_sample_params* p, float* latents_out_dev, float* per_step_ms_host, void* stream);
+
+/* Work counters for roofline accounting: algorithmic FLOPs of the last forward (SURVEY.md section 8d formula)
+ * and GEMM-only HIP-event time when profiling was enabled with ace355_dit_set_profile(h, 1). */
+int ace355_dit_set_profile(ace355_dit* h, int enable);
+int ace355_dit_get_profile(ace355_dit* h, double* gemm_ms, double* gemm_flops, double* attn_ms, double* attn_flops,
+                           int64_t* gemm_launches);
+
+/* ------------------------------------------------------------------------------------------
+ * Oobleck VAE decoder (diffusers AutoencoderOobleck.decode; restated in models/mlx/vae_model.py:190-230)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ace355_vae ace355_vae;
+
+typedef struct ace355_vae_config {
+    int32_t decoder_channels;       /* 128 */
+    int32_t decoder_input_channels; /* 64 */
+    int32_t audio_channels;         /* 2 */
+    int32_t num_blocks;             /* 5 */
+    int32_t channel_multiples[ACE355_MAX_BLOCKS]; /* [1,2,4,8,16] */
+    int32_t upsampling_ratios[ACE355_MAX_BLOCKS]; /* decoder order, e.g. [10,6,4,4,2] (product = hop 1920) */
+} ace355_vae_config;
+
+/* Replaces H/mlx_vae_init.py:12-96 (_init_mlx_vae) + models/mlx/vae_convert.py. */
+int ace355_vae_create(const ace355_vae_config* cfg, ace355_vae** out);
+void ace355_vae_destroy(ace355_vae* h);
+/* Names are AutoencoderOobleck.state_dict() keys of the decoder half:
+ * "decoder.conv1.weight_g|weight_v|bias", "decoder.block.{i}.snake1.alpha|beta",
+ * "decoder.block.{i}.conv_t1.*", "decoder.block.{i}.res_unit{1,2,3}.{snake1,conv1,snake2,conv2}.*",
+ * "decoder.snake1.*", "decoder.conv2.weight_g|weight_v".  Weight-norm is fused at finalize
+ * (w = g*v/(||v||+1e-9), vae_convert.py:18-34).  A pre-fused "<conv>.weight" is accepted too. */
+int ace355_vae_load_tensor(ace355_vae* h, const char* name, const void* data, int dtype, int64_t numel, int is_device);
+int ace355_vae_finalize(ace355_vae* h);
+/* Replaces vae.decode(z).sample at H/vae_decode_chunks.py:42,95 / H/generate_music_decode.py:172-177 and
+ * _mlx_vae_decode (H/mlx_vae_decode_native.py:31-72).  z dev f32 [B,64,T] (the reference's
+ * [B,C,T] layout); wav_out dev f32 [B,2,hop*T].  Whole-sequence decode: equals the reference's
+ * overlap-discard tiling away from fp summation order. */
+int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream);
+int ace355_vae_hop(const ace355_vae* h);
+int ace355_vae_set_profile(ace355_vae* h, int enable);
+int ace355_vae_get_profile(ace355_vae* h, double* conv_ms, double* conv_flops, int64_t* conv_launches);
+
+/* Post-decode peak clip, H/generate_music_decode.py:191-195: per item, if any peak > 1 divide
+ * every item by clamp(peak, min=1).  wav dev f32 [B, per_item]. */
+int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream);
+/* NaN/Inf/all-zero latent guard, H/generate_music_decode.py:66-77: flags_host[0]=has_nan_or_inf, [1]=all_zero. */
+int ace355_latent_check(const float* lat_dev, int64_t numel, int32_t* flags_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Unit kernels (test hooks; each has an oracle twin in oracle/ used by tests/)
+ * ---------------------------------------------------------------------------------------- */
+/* C = A[M,K] * W[N,K]^T, bf16 in, fp32 accumulate (MFMA).  out_dtype: ACE355_DTYPE_*; bias f32 [N] or NULL. */
+int ace355_gemm_bf16(const void* A_dev, const void* W_dev, void* C_dev, int M, int N, int K, int out_dtype,
+                     const float* bias_dev, void* stream);
+/* Fused epilogues used by the DiT: mode 0: H[M,N] (f32) += gate * (A W^T), gate[n] = g1[n] + g2[(m / rows_per_seq)*g2_stride + n]
+ * (NULL g1 -> gate 1);  mode 1: out[M,N/2] (bf16) = silu(gate) * up with W rows interleaved [32 gate | 32 up]. */
+int ace355_gemm_bf16_fused(const void* A_dev, const void* W_dev, void* out_dev, int M, int N, int K, int mode,
+                           const float* g1_dev, const float* g2_dev, int g2_stride, int rows_per_seq, void* stream);
+/* y = bf16( rmsnorm(x; w, eps) * (1 + sc) + sh ), sc[n] = sc1[n] + sc2[(m / rows_per_seq)*stride + n] (NULL -> no modulation). */
+int ace355_rmsnorm_mod(const float* x_dev, const float* w_dev, void* y_bf16_dev, int M, int D, float eps,
+                       const float* sc1, const float* sc2, const float* sh1, const float* sh2, int stride,
+                       int rows_per_seq, void* stream);
+/* In-place head RMSNorm (+ RoPE when rope != 0) on `heads` heads of 128 starting at column col0 of a bf16 [M, ld] matrix. */
+int ace355_headnorm_rope(void* x_bf16_dev, int M, int ld, int col0, int heads, const float* w_dev, float eps,
+                         int rope, int S, float theta, void* stream);
+/* Flash attention: q bf16 [N,Sq,Hq*128] (ld = Hq*128), k bf16 [N,Skv,Hkv*128], v bf16 [N,Skv,Hkv*128];
+ * window < 0 = full, else |i-j| <= window.  out bf16 [N,Sq,Hq*128]. */
+int ace355_attention(const void* q_dev, const void* k_dev, const void* v_dev, void* out_dev, int N, int Sq, int Skv,
+                     int Hq, int Hkv, int window, float scale, void* stream);
+/* One guidance + Euler step (base.py:1946-1979): v dev f32 [2B,T,64] (cond | uncond), avg dev f32 [B,T,64]
+ * momentum state (updated), xt dev f32 [B,T,64] (updated in place). first != 0: momentum buffer is empty. */
+int ace355_apg_euler_step(const float* v_dev, float* avg_dev, float* xt_dev, int B, int T, float guidance, float dt,
+                          int apply_cfg, int first, void* stream);
+/* NLC conv (test hook for the VAE kernels): y[b,l,co] = bias[co] + sum_{tap,ci} f(x[b, l+(tap-center)*dil, ci]) * w[co,tap,ci]
+ * (+ res[b,l,co]); f = snake(alpha,beta) when alpha != NULL.  x,y,res bf16 NLC; w bf16 [Cout,taps,Cin]. */
+int ace355_conv1d_nlc(const void* x_dev, const void* w_dev, const float* bias_dev, const float* alpha_dev,
+                      const float* beta_dev, const void* res_dev, void* y_dev, int B, int L, int Cin, int Cout,
+                      int taps, int dilation, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACE355_H */

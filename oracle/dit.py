@@ -1,0 +1,308 @@
+"""fp32 CPU restatement of the ACE-Step 1.5 DiT decoder forward (test oracle).
+
+Reference: /root/reference/acestep/models/base/modeling_acestep_v15_base.py
+(``base.py`` below).  Every function cites the lines it restates.  Weight names
+are the keys of ``AceStepDiTModel.state_dict()`` so a reference checkpoint's
+``model.decoder`` weights drop in unchanged.
+
+Third-party arithmetic restated from its published definition because the
+reference delegates it to ``transformers`` (Qwen3RMSNorm, Qwen3MLP,
+Qwen3RotaryEmbedding, apply_rotary_pos_emb, eager_attention_forward):
+pinned by tests/golden/make_golden.py against the imported reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class DitConfig:
+    """Constants of AceStepConfig (configuration_acestep_v15.py:148-263) the path uses."""
+
+    hidden_size: int = 2048
+    intermediate_size: int = 6144
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    sliding_window: int = 128
+    patch_size: int = 2
+    in_channels: int = 192
+    audio_acoustic_hidden_dim: int = 64
+    layer_types: Optional[List[str]] = None
+
+    def __post_init__(self):
+        if self.layer_types is None:
+            # configuration_acestep_v15.py:251-254: even index = sliding, odd = full
+            self.layer_types = [
+                "sliding_attention" if (i + 1) % 2 else "full_attention"
+                for i in range(self.num_hidden_layers)
+            ]
+
+
+# --------------------------------------------------------------------------- primitives
+def rms_norm(x: Tensor, weight: Tensor, eps: float) -> Tensor:
+    """Qwen3RMSNorm.forward (transformers): w * (x_f32 * rsqrt(mean(x^2) + eps)).to(dtype)."""
+    dt = x.dtype
+    xf = x.to(torch.float32)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return weight * xf.to(dt)
+
+
+def sinusoid_embedding(t: Tensor, dim: int = 256, scale: float = 1000.0, max_period: float = 10000.0) -> Tensor:
+    """TimestepEmbedding.timestep_embedding, base.py:225-246: [cos | sin] of t*scale*freqs."""
+    t = t * scale
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def timestep_embed(t: Tensor, w: Dict[str, Tensor], prefix: str) -> Tuple[Tensor, Tensor]:
+    """TimestepEmbedding.forward, base.py:248-254 -> (temb [N,D], timestep_proj [N,6,D])."""
+    t_freq = sinusoid_embedding(t, 256).to(t.dtype)
+    temb = F.linear(t_freq, w[prefix + ".linear_1.weight"], w[prefix + ".linear_1.bias"])
+    temb = F.silu(temb)
+    temb = F.linear(temb, w[prefix + ".linear_2.weight"], w[prefix + ".linear_2.bias"])
+    proj = F.linear(F.silu(temb), w[prefix + ".time_proj.weight"], w[prefix + ".time_proj.bias"])
+    return temb, proj.unflatten(1, (6, -1))
+
+
+def rope_cos_sin(seq_len: int, head_dim: int, theta: float, dtype=torch.float32) -> Tuple[Tensor, Tensor]:
+    """Qwen3RotaryEmbedding.forward (default rope): inv_freq = theta^(-2k/d), emb = cat(freqs, freqs)."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    pos = torch.arange(seq_len, dtype=torch.float32)
+    freqs = pos[:, None] * inv_freq[None, :]
+    emb = torch.cat([freqs, freqs], dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def rotate_half(x: Tensor) -> Tensor:
+    x1 = x[..., : x.shape[-1] // 2]
+    x2 = x[..., x.shape[-1] // 2:]
+    return torch.cat([-x2, x1], dim=-1)
+
+
+def apply_rope(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor) -> Tuple[Tensor, Tensor]:
+    """transformers apply_rotary_pos_emb (half-split rotate_half form); q,k are [N,H,S,d]."""
+    cos = cos[None, None]
+    sin = sin[None, None]
+    return q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
+
+
+def band_valid(seq_len: int, window: Optional[int]) -> Tensor:
+    """create_4d_mask, base.py:56-135 with is_causal=False: valid iff |i-j| <= window (bool [S,S])."""
+    idx = torch.arange(seq_len)
+    diff = idx[:, None] - idx[None, :]
+    valid = torch.ones(seq_len, seq_len, dtype=torch.bool)
+    if window is not None:
+        valid = valid & (diff.abs() <= window)
+    return valid
+
+
+def additive_mask(valid: Tensor, dtype=torch.float32) -> Tensor:
+    m = torch.full(valid.shape, torch.finfo(dtype).min, dtype=dtype)
+    m.masked_fill_(valid, 0.0)
+    return m
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], scale: float) -> Tensor:
+    """eager_attention_forward (transformers): repeat_kv, matmul*scale + mask, softmax fp32, matmul.
+
+    q [N,Hq,Sq,d], k/v [N,Hkv,Sk,d]; returns [N,Sq,Hq*d].
+    """
+    groups = q.shape[1] // k.shape[1]
+    k = k.repeat_interleave(groups, dim=1)
+    v = v.repeat_interleave(groups, dim=1)
+    w = torch.matmul(q, k.transpose(2, 3)) * scale
+    if mask is not None:
+        w = w + mask
+    w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+    o = torch.matmul(w, v)
+    return o.transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+
+# --------------------------------------------------------------------------- layer
+def _heads(x: Tensor, head_dim: int) -> Tensor:
+    return x.view(x.shape[0], x.shape[1], -1, head_dim)
+
+
+def cross_kv(cfg: DitConfig, w: Dict[str, Tensor], li: int, enc: Tensor) -> Tuple[Tensor, Tensor]:
+    """Cross-attention K/V of layer li from the (already condition_embedder'ed) encoder states.
+
+    base.py:320-321: K = k_norm(k_proj(enc)) (no RoPE), V = v_proj(enc); both [N,Hkv,L,d].
+    """
+    p = f"layers.{li}.cross_attn."
+    k = rms_norm(_heads(F.linear(enc, w[p + "k_proj.weight"]), cfg.head_dim), w[p + "k_norm.weight"], cfg.rms_norm_eps)
+    v = _heads(F.linear(enc, w[p + "v_proj.weight"]), cfg.head_dim)
+    return k.transpose(1, 2), v.transpose(1, 2)
+
+
+def dit_layer(
+    cfg: DitConfig,
+    w: Dict[str, Tensor],
+    li: int,
+    h: Tensor,
+    tproj: Tensor,
+    cos: Tensor,
+    sin: Tensor,
+    self_mask: Optional[Tensor],
+    kv: Tuple[Tensor, Tensor],
+    taps: Optional[dict] = None,
+) -> Tensor:
+    """AceStepDiTLayer.forward, base.py:475-539."""
+    p = f"layers.{li}."
+    eps = cfg.rms_norm_eps
+    scale = cfg.head_dim ** -0.5
+    shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = (w[p + "scale_shift_table"] + tproj).chunk(6, dim=1)
+
+    # self attention (base.py:499-511, 304, 338-343)
+    xn = rms_norm(h, w[p + "self_attn_norm.weight"], eps) * (1 + scale_msa) + shift_msa
+    sp = p + "self_attn."
+    q = rms_norm(_heads(F.linear(xn, w[sp + "q_proj.weight"]), cfg.head_dim), w[sp + "q_norm.weight"], eps).transpose(1, 2)
+    k = rms_norm(_heads(F.linear(xn, w[sp + "k_proj.weight"]), cfg.head_dim), w[sp + "k_norm.weight"], eps).transpose(1, 2)
+    v = _heads(F.linear(xn, w[sp + "v_proj.weight"]), cfg.head_dim).transpose(1, 2)
+    q, k = apply_rope(q, k, cos, sin)
+    a = attention(q, k, v, self_mask, scale)
+    if taps is not None:
+        taps[f"l{li}.xn"] = xn
+        taps[f"l{li}.q"] = q
+        taps[f"l{li}.k"] = k
+        taps[f"l{li}.v"] = v
+        taps[f"l{li}.self_attn"] = a
+    h = h + F.linear(a, w[sp + "o_proj.weight"]) * gate_msa
+
+    # cross attention (base.py:515-526, 304, 310-333): plain residual, no RoPE, zero mask
+    xn = rms_norm(h, w[p + "cross_attn_norm.weight"], eps)
+    cp = p + "cross_attn."
+    q = rms_norm(_heads(F.linear(xn, w[cp + "q_proj.weight"]), cfg.head_dim), w[cp + "q_norm.weight"], eps).transpose(1, 2)
+    a = attention(q, kv[0], kv[1], None, scale)
+    if taps is not None:
+        taps[f"l{li}.cross_attn"] = a
+    h = h + F.linear(a, w[cp + "o_proj.weight"])
+
+    # SwiGLU MLP (base.py:530-533; transformers Qwen3MLP)
+    xn = rms_norm(h, w[p + "mlp_norm.weight"], eps) * (1 + c_scale) + c_shift
+    mp = p + "mlp."
+    ff = F.linear(F.silu(F.linear(xn, w[mp + "gate_proj.weight"])) * F.linear(xn, w[mp + "up_proj.weight"]), w[mp + "down_proj.weight"])
+    h = h + ff * c_gate
+    if taps is not None:
+        taps[f"l{li}.out"] = h
+    return h
+
+
+# --------------------------------------------------------------------------- model
+class CrossCache:
+    """Stand-in for EncoderDecoderCache's cross_attention_cache (base.py:312-329, 1875, 1927)."""
+
+    def __init__(self):
+        self.kv: Dict[int, Tuple[Tensor, Tensor]] = {}
+
+
+def dit_forward(
+    cfg: DitConfig,
+    w: Dict[str, Tensor],
+    x: Tensor,
+    t: Tensor,
+    t_r: Tensor,
+    enc_hs: Tensor,
+    ctx: Tensor,
+    cache: Optional[CrossCache] = None,
+    taps: Optional[dict] = None,
+) -> Tensor:
+    """AceStepDiTModel.forward, base.py:1303-1507.  x [N,T,64], ctx [N,T,128], enc_hs [N,L,D].
+
+    Both padding masks are discarded by the reference (base.py:1384-1385); only the
+    bidirectional sliding band on "sliding_attention" layers survives (base.py:1431-1440).
+    """
+    temb_t, proj_t = timestep_embed(t, w, "time_embed")
+    temb_r, proj_r = timestep_embed(t - t_r, w, "time_embed_r")
+    temb = temb_t + temb_r
+    tproj = proj_t + proj_r
+
+    h = torch.cat([ctx, x], dim=-1)
+    T0 = h.shape[1]
+    if T0 % cfg.patch_size:
+        h = F.pad(h, (0, 0, 0, cfg.patch_size - T0 % cfg.patch_size))
+    # proj_in: Conv1d(192 -> D, k=2, s=2) (base.py:1264-1274)
+    h = F.conv1d(h.transpose(1, 2), w["proj_in.1.weight"], w["proj_in.1.bias"], stride=cfg.patch_size).transpose(1, 2)
+    S = h.shape[1]
+
+    # condition_embedder runs every step in the reference (base.py:1359); its only
+    # consumer is the cross K/V which is cached after step 0, so we compute it only then.
+    kvs = {}
+    if cache is None or not cache.kv:
+        enc = F.linear(enc_hs, w["condition_embedder.weight"], w["condition_embedder.bias"])
+        for li in range(cfg.num_hidden_layers):
+            kvs[li] = cross_kv(cfg, w, li, enc)
+        if cache is not None:
+            cache.kv = kvs
+    else:
+        kvs = cache.kv
+
+    cos, sin = rope_cos_sin(S, cfg.head_dim, cfg.rope_theta, h.dtype)
+    slide = additive_mask(band_valid(S, cfg.sliding_window), h.dtype)[None, None]
+    if taps is not None:
+        taps["temb"] = temb
+        taps["tproj"] = tproj
+        taps["h0"] = h
+    for li in range(cfg.num_hidden_layers):
+        mask = slide if cfg.layer_types[li] == "sliding_attention" else None
+        h = dit_layer(cfg, w, li, h, tproj, cos, sin, mask, kvs[li], taps)
+
+    shift, scale = (w["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)
+    h = rms_norm(h, w["norm_out.weight"], cfg.rms_norm_eps) * (1 + scale) + shift
+    # proj_out: ConvTranspose1d(D -> 64, k=2, s=2) (base.py:1287-1297), then crop (:1501)
+    v = F.conv_transpose1d(h.transpose(1, 2), w["proj_out.1.weight"], w["proj_out.1.bias"], stride=cfg.patch_size).transpose(1, 2)
+    return v[:, :T0, :]
+
+
+def dit_weight_shapes(cfg: DitConfig) -> Dict[str, Tuple[int, ...]]:
+    """Names/shapes of AceStepDiTModel.state_dict() (base.py:1248-1299, 454-472, 279-285, 216-222)."""
+    D, Fh, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    q, kv = cfg.num_attention_heads * hd, cfg.num_key_value_heads * hd
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    for li in range(cfg.num_hidden_layers):
+        p = f"layers.{li}."
+        shapes[p + "scale_shift_table"] = (1, 6, D)
+        for n in ("self_attn_norm", "cross_attn_norm", "mlp_norm"):
+            shapes[p + n + ".weight"] = (D,)
+        for a in ("self_attn", "cross_attn"):
+            shapes[p + a + ".q_proj.weight"] = (q, D)
+            shapes[p + a + ".k_proj.weight"] = (kv, D)
+            shapes[p + a + ".v_proj.weight"] = (kv, D)
+            shapes[p + a + ".o_proj.weight"] = (D, q)
+            shapes[p + a + ".q_norm.weight"] = (hd,)
+            shapes[p + a + ".k_norm.weight"] = (hd,)
+        shapes[p + "mlp.gate_proj.weight"] = (Fh, D)
+        shapes[p + "mlp.up_proj.weight"] = (Fh, D)
+        shapes[p + "mlp.down_proj.weight"] = (D, Fh)
+    shapes["proj_in.1.weight"] = (D, cfg.in_channels, cfg.patch_size)
+    shapes["proj_in.1.bias"] = (D,)
+    for e in ("time_embed", "time_embed_r"):
+        shapes[e + ".linear_1.weight"] = (D, 256)
+        shapes[e + ".linear_1.bias"] = (D,)
+        shapes[e + ".linear_2.weight"] = (D, D)
+        shapes[e + ".linear_2.bias"] = (D,)
+        shapes[e + ".time_proj.weight"] = (6 * D, D)
+        shapes[e + ".time_proj.bias"] = (6 * D,)
+    shapes["condition_embedder.weight"] = (D, D)
+    shapes["condition_embedder.bias"] = (D,)
+    shapes["norm_out.weight"] = (D,)
+    shapes["proj_out.1.weight"] = (D, cfg.audio_acoustic_hidden_dim, cfg.patch_size)
+    shapes["proj_out.1.bias"] = (cfg.audio_acoustic_hidden_dim,)
+    shapes["scale_shift_table"] = (1, 2, D)
+    return shapes

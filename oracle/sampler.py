@@ -1,0 +1,137 @@
+"""fp32 CPU restatement of the base/sft flow-matching sampler (test oracle).
+
+Reference: AceStepConditionGenerationModel.generate_audio,
+/root/reference/acestep/models/base/modeling_acestep_v15_base.py:1783-1989 (``base.py``)
+and the sft twin's explicit ``timesteps=`` (sft/modeling_acestep_v15_base.py:1864-1875).
+
+The oracle starts where the drop-in boundary starts: conditions are
+already prepared (``encoder_hidden_states``, ``context_latents``), exactly what
+``_mlx_run_diffusion`` / ``_native_run_diffusion`` receive.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from . import apg as _apg
+from .dit import CrossCache, DitConfig, dit_forward
+
+Tensor = torch.Tensor
+
+
+def schedule(infer_steps: int, shift: float = 1.0, timesteps: Optional[Sequence[float]] = None, dtype=torch.float32) -> Tensor:
+    """base.py:1864-1867 (+ sft :1864-1875): linspace(1,0,steps+1), optional shift warp."""
+    if timesteps is not None:
+        return torch.as_tensor(timesteps, dtype=dtype)
+    t = torch.linspace(1.0, 0.0, infer_steps + 1, dtype=dtype)
+    if shift != 1.0:
+        t = shift * t / (1 + (shift - 1) * t)
+    return t
+
+
+def prepare_noise(shape, seed: Union[int, List[int], None], dtype=torch.float32) -> Tensor:
+    """base.py:1733-1770 on the CPU device: per-item torch.Generator when seed is a list."""
+    bsz, T, C = shape
+    if seed is None:
+        return torch.randn(shape, dtype=dtype)
+    if isinstance(seed, list):
+        out = []
+        for s in seed:
+            if s is None or s < 0:
+                out.append(torch.randn(1, T, C, dtype=dtype))
+            else:
+                g = torch.Generator(device="cpu").manual_seed(int(s))
+                out.append(torch.randn(1, T, C, generator=g, dtype=dtype))
+        return torch.cat(out, dim=0)
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    return torch.randn(shape, generator=g, dtype=dtype)
+
+
+def generate_audio(
+    cfg: DitConfig,
+    w: Dict[str, Tensor],
+    null_condition_emb: Tensor,
+    encoder_hidden_states: Tensor,
+    context_latents: Tensor,
+    seed: Union[int, List[int], None] = None,
+    infer_method: str = "ode",
+    infer_steps: int = 30,
+    diffusion_guidance_sale: float = 7.0,
+    cfg_interval_start: float = 0.0,
+    cfg_interval_end: float = 1.0,
+    use_adg: bool = False,
+    shift: float = 1.0,
+    timesteps: Optional[Sequence[float]] = None,
+    audio_cover_strength: float = 1.0,
+    cover_noise_strength: float = 0.0,
+    src_latents: Optional[Tensor] = None,
+    encoder_hidden_states_non_cover: Optional[Tensor] = None,
+    context_latents_non_cover: Optional[Tensor] = None,
+    noise: Optional[Tensor] = None,
+    trace: Optional[list] = None,
+) -> Tensor:
+    """The sampling loop of base.py:1861-1989 given prepared conditions; returns target_latents [B,T,64]."""
+    dtype = context_latents.dtype
+    bsz = context_latents.shape[0]
+    t = schedule(infer_steps, shift, timesteps, dtype)
+    if timesteps is not None:
+        infer_steps = len(t) - 1
+    cover_steps = int(infer_steps * audio_cover_strength)
+    if noise is None:
+        noise = prepare_noise((bsz, context_latents.shape[1], context_latents.shape[-1] // 2), seed, dtype)
+    cache = CrossCache()
+    momentum = _apg.MomentumBuffer()
+
+    if cover_noise_strength > 0.0:  # base.py:1879-1900
+        eff = 1.0 - cover_noise_strength
+        t_values = t[:-1].tolist()
+        nearest = min(t_values, key=lambda x: abs(x - eff))
+        start_idx = t_values.index(nearest)
+        xt = nearest * noise + (1 - nearest) * src_latents
+        t = t[start_idx:]
+        infer_steps = len(t) - 1
+        cover_steps = int(infer_steps * audio_cover_strength)
+    else:
+        xt = noise
+
+    do_cfg = diffusion_guidance_sale > 1.0
+    enc, ctx = encoder_hidden_states, context_latents
+    if do_cfg:  # base.py:1905-1911
+        enc = torch.cat([enc, null_condition_emb.expand_as(enc)], dim=0)
+        ctx = torch.cat([ctx, ctx], dim=0)
+
+    switched = False
+    for step_idx, (t_curr, t_prev) in enumerate(zip(t[:-1], t[1:])):
+        if step_idx >= cover_steps and not switched:  # base.py:1916-1927
+            switched = True
+            enc_nc, ctx_nc = encoder_hidden_states_non_cover, context_latents_non_cover
+            if do_cfg:
+                enc_nc = torch.cat([enc_nc, null_condition_emb.expand_as(enc_nc)], dim=0)
+                ctx_nc = torch.cat([ctx_nc, ctx_nc], dim=0)
+            enc, ctx = enc_nc, ctx_nc
+            cache = CrossCache()
+        x = torch.cat([xt, xt], dim=0) if do_cfg else xt
+        tt = t_curr * torch.ones((x.shape[0],), dtype=dtype)
+        vt = dit_forward(cfg, w, x, tt, tt, enc, ctx, cache)
+        apply_cfg = bool(t_curr >= cfg_interval_start and t_curr <= cfg_interval_end)
+        if do_cfg:  # base.py:1946-1966
+            pc, pu = vt.chunk(2)
+            if apply_cfg:
+                if not use_adg:
+                    vt = _apg.apg_forward(pc, pu, diffusion_guidance_sale, momentum, dims=[1])
+                else:
+                    vt = _apg.adg_forward(xt, pc, pu, t_curr, diffusion_guidance_sale)
+            else:
+                vt = pc
+        if infer_method == "sde":  # base.py:1968-1973 (unseeded renoise: not reproducible)
+            tb = t_curr * torch.ones((bsz,), dtype=dtype)
+            clean = xt - vt * tb[:, None, None]
+            nt = 1.0 - (float(step_idx + 1) / infer_steps)
+            xt = nt * torch.randn_like(clean) + (1 - nt) * clean
+        elif infer_method == "ode":  # base.py:1974-1979
+            dt = t_curr - t_prev
+            xt = xt - vt * (dt * torch.ones((bsz,), dtype=dtype))[:, None, None]
+        if trace is not None:
+            trace.append(xt.clone())
+    return xt

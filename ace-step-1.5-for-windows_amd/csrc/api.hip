@@ -1,0 +1,177 @@
+// api.hip - error plumbing, post-processing entry points and the unit-kernel test hooks of ace355.h.
+#include <math.h>
+#include <stdio.h>
+
+#include <algorithm>
+#include <string>
+
+#include "../../include/ace355.h"
+#include "common.h"
+
+namespace ace355 {
+
+static thread_local std::string g_err;
+
+void set_error(const std::string& msg) { g_err = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    char buf[1024];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    g_err = buf;
+    (void)hipGetLastError();  // clear the sticky error so the next call starts clean
+    return ACE355_ERR_HIP;
+}
+
+namespace {
+__global__ void snake_prep_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ ea,
+                                  float* __restrict__ ib, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    ea[i] = expf(alpha[i]);
+    ib[i] = 1.0f / (expf(beta[i]) + 1e-9f);
+}
+}  // namespace
+
+}  // namespace ace355
+
+using namespace ace355;
+
+extern "C" {
+
+const char* ace355_last_error(void) { return g_err.c_str(); }
+int ace355_version(void) { return 100; }
+
+int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream) {
+    ACE_CHECK(wav_dev && B > 0 && B <= 256 && per_item > 0, "peak_normalize: bad argument");
+    float* scratch = nullptr;
+    ACE_HIP(hipMalloc((void**)&scratch, sizeof(float) * 256));
+    int rc = launch_peak_normalize(wav_dev, B, (long)per_item, scratch, (hipStream_t)stream);
+    ACE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    hipFree(scratch);
+    return rc;
+}
+
+int ace355_latent_check(const float* lat_dev, int64_t numel, int32_t* flags_host, void* stream) {
+    ACE_CHECK(lat_dev && flags_host && numel >= 0, "latent_check: bad argument");
+    flags_host[0] = 0;
+    flags_host[1] = numel == 0 ? 0 : 1;
+    if (numel == 0) return ACE355_OK;
+    int* f = nullptr;
+    ACE_HIP(hipMalloc((void**)&f, 2 * sizeof(int)));
+    int rc = launch_latent_check(lat_dev, (long)numel, f, (hipStream_t)stream);
+    int host[2] = {0, 0};
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(host, f, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { hipFree(f); return hip_fail(e, "latent_check copy", __FILE__, __LINE__); }
+    }
+    hipFree(f);
+    flags_host[0] = host[0];           // NaN / Inf present
+    flags_host[1] = host[1] ? 0 : 1;   // all zero
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------ unit hooks
+int ace355_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int out_dtype, const float* bias, void* stream) {
+    ACE_CHECK(A && W && C, "gemm_bf16: null pointer");
+    GemmEpilogue ep{out_dtype == ACE355_DTYPE_F32 ? 1 : 0, bias, nullptr, nullptr, 0, 0};
+    return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, C, N, M, N, K, ep, (hipStream_t)stream);
+}
+
+int ace355_gemm_bf16_fused(const void* A, const void* W, void* out, int M, int N, int K, int mode, const float* g1, const float* g2,
+                           int g2_stride, int rows_per_seq, void* stream) {
+    ACE_CHECK(A && W && out, "gemm_bf16_fused: null pointer");
+    ACE_CHECK(mode == 0 || mode == 1, "gemm_bf16_fused: mode");
+    if (mode == 0) {
+        GemmEpilogue ep{2, nullptr, g1, g2, g2_stride, rows_per_seq};
+        return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, out, N, M, N, K, ep, (hipStream_t)stream);
+    }
+    GemmEpilogue ep{3, nullptr, nullptr, nullptr, 0, 0};
+    return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, out, N / 2, M, N, K, ep, (hipStream_t)stream);
+}
+
+int ace355_rmsnorm_mod(const float* x, const float* w, void* y, int M, int D, float eps, const float* sc1, const float* sc2,
+                       const float* sh1, const float* sh2, int stride, int rows_per_seq, void* stream) {
+    ACE_CHECK(x && w && y, "rmsnorm_mod: null pointer");
+    return launch_rmsnorm_mod(x, w, (bf16_t*)y, M, D, eps, sc1, sc2, sh1, sh2, stride, rows_per_seq, (hipStream_t)stream);
+}
+
+int ace355_headnorm_rope(void* x, int M, int ld, int col0, int heads, const float* w, float eps, int rope, int S, float theta,
+                         void* stream) {
+    ACE_CHECK(x && w, "headnorm_rope: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float *c = nullptr, *sn = nullptr;
+    if (rope) {
+        ACE_CHECK(S > 0, "headnorm_rope: S");
+        ACE_HIP(hipMalloc((void**)&c, (size_t)S * 64 * 4));
+        ACE_HIP(hipMalloc((void**)&sn, (size_t)S * 64 * 4));
+        int rc = launch_rope_table(c, sn, S, theta, s);
+        if (rc) return rc;
+    }
+    int rc = launch_headnorm_rope((bf16_t*)x, M, ld, col0, heads, w, eps, c, sn, S, s);
+    ACE_HIP(hipStreamSynchronize(s));
+    if (c) hipFree(c);
+    if (sn) hipFree(sn);
+    return rc;
+}
+
+int ace355_attention(const void* q, const void* k, const void* v, void* out, int N, int Sq, int Skv, int Hq, int Hkv, int window,
+                     float scale, void* stream) {
+    ACE_CHECK(q && k && v && out, "attention: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int Sp = ((Skv + 63) / 64) * 64;
+    bf16_t* vt = nullptr;
+    ACE_HIP(hipMalloc((void**)&vt, (size_t)N * Hkv * 128 * Sp * 2));
+    int rc = launch_transpose_v((const bf16_t*)v, Hkv * 128, 0, N, Skv, Hkv, vt, Sp, s);
+    if (!rc) {
+        AttnArgs a{};
+        a.q = (const bf16_t*)q; a.q_seq_stride = (long)Sq * Hq * 128; a.q_row_stride = Hq * 128;
+        a.k = (const bf16_t*)k; a.k_seq_stride = (long)Skv * Hkv * 128; a.k_head_stride = 128; a.k_row_stride = Hkv * 128;
+        a.vt = vt; a.vt_seq_stride = (long)Hkv * 128 * Sp; a.vt_head_stride = 128L * Sp; a.vt_ld = Sp;
+        a.use_tab = 0;
+        a.out = (bf16_t*)out; a.o_seq_stride = (long)Sq * Hq * 128; a.o_row_stride = Hq * 128;
+        a.N = N; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv; a.window = window; a.scale = scale;
+        rc = launch_attention(a, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    hipFree(vt);
+    if (e != hipSuccess) return hip_fail(e, "attention sync", __FILE__, __LINE__);
+    return rc;
+}
+
+int ace355_apg_euler_step(const float* v, float* avg, float* xt, int B, int T, float guidance, float dt, int apply_cfg, int first,
+                          void* stream) {
+    ACE_CHECK(v && avg && xt && B > 0 && T > 0, "apg_euler_step: bad argument");
+    const int do_cfg = guidance > 1.0f ? 1 : 0;
+    return launch_apg_euler(v, (long)B * T * 64, avg, xt, nullptr, 0, B, T, T, guidance, dt, apply_cfg, do_cfg, first,
+                            (hipStream_t)stream);
+}
+
+int ace355_conv1d_nlc(const void* x, const void* w, const float* bias, const float* alpha, const float* beta, const void* res,
+                      void* y, int B, int L, int Cin, int Cout, int taps, int dilation, void* stream) {
+    ACE_CHECK(x && w && y, "conv1d_nlc: null pointer");
+    ACE_CHECK(taps % 2 == 1, "conv1d_nlc: odd taps only");
+    hipStream_t s = (hipStream_t)stream;
+    float *ea = nullptr, *ib = nullptr;
+    if (alpha) {
+        ACE_CHECK(beta != nullptr, "conv1d_nlc: beta");
+        ACE_HIP(hipMalloc((void**)&ea, (size_t)Cin * 4));
+        ACE_HIP(hipMalloc((void**)&ib, (size_t)Cin * 4));
+        hipLaunchKernelGGL(snake_prep_kernel, dim3((Cin + 255) / 256), dim3(256), 0, s, alpha, beta, ea, ib, Cin);
+    }
+    ConvArgs a{};
+    a.x = (const bf16_t*)x; a.x_batch_stride = (long)L * Cin; a.L_in = L; a.Cin = Cin;
+    a.w = (const bf16_t*)w; a.bias = bias; a.alpha = ea; a.beta = ib;
+    a.res = (const bf16_t*)res; a.res_batch_stride = (long)L * Cout;
+    a.y = y; a.y_batch_stride = (long)L * Cout;
+    a.B = B; a.M = L; a.N = Cout; a.taps = taps; a.dil = dilation; a.center = taps / 2;
+    a.y_shift = 0; a.y_valid = (long)L * Cout; a.out_mode = 0;
+    int rc = launch_conv(a, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (ea) hipFree(ea);
+    if (ib) hipFree(ib);
+    if (e != hipSuccess) return hip_fail(e, "conv1d_nlc sync", __FILE__, __LINE__);
+    return rc;
+}
+
+}  // extern "C"

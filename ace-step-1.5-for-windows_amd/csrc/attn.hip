@@ -1,0 +1,191 @@
+// attn.hip - bidirectional flash attention for the DiT (full / sliding-band self-attention, cross-attention).
+//
+// Replaces ALL_ATTENTION_FUNCTIONS[impl] / eager_attention_forward as called from AceStepAttention.forward
+// (base.py:351-367) including the dense additive band mask of create_4d_mask (base.py:56-135): the band predicate
+// |i-j| <= window is evaluated in-kernel and K/V tiles wholly outside the band are skipped.
+//
+// gfx950 design (head_dim 128, GQA): one workgroup = 128 query rows of one (sequence, q-head); 4 waves x 32 rows.
+// K tiles [64 keys][128 d] and V^T tiles [128 d][64 keys] are staged in LDS (XOR-swizzled, conflict-free
+// ds_read_b128 / ds_read_b64).  QK^T is computed "swapped" (S^T = K Q^T, MFMA 32x32x16) so a lane owns one query
+// column: the online-softmax row max/sum are in-register (+1 cross-half shuffle), and the C-layout of P is
+// already the B-operand layout needed by O^T += V^T P^T - no LDS round trip, no lane permutes for P.
+// V is consumed pre-transposed ([d][key], produced by transpose_v_kernel / the cross-KV cache builder).
+#include "common.h"
+
+namespace ace355 {
+
+namespace {
+
+constexpr int QB = 128;  // query rows per workgroup
+constexpr int KB = 64;   // keys per tile
+
+__device__ __forceinline__ int k_off(int key, int slot) { return key * 256 + ((slot ^ (key & 15)) << 4); }
+// V^T tile: row d = 128 B (64 keys); 8-byte chunk c8 (4 keys) stored at c8 ^ ((d>>1)&15)
+__device__ __forceinline__ int vt_off8(int d, int c8) { return d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3); }
+
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_log2) {
+    __shared__ __attribute__((aligned(16))) char smem[32768];  // K tile 16 KB | V^T tile 16 KB
+    char* Ks = smem;
+    char* Vs = smem + 16384;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const int hkv = h / (a.Hq / a.Hkv);
+    const int q0 = qb * QB;
+    const int lq = lane & 31, half = lane >> 5;
+    const int qrow = q0 + wave * 32 + lq;  // this lane's query row
+    const int qrow_c = min(qrow, a.Sq - 1);
+
+    // Q fragments (B operand of S^T = K Q^T): lane holds q = lq, d = ks*16 + half*8 .. +8
+    bf16x8 qf[8];
+    {
+        const bf16_t* qp = a.q + (long)n * a.q_seq_stride + (long)qrow_c * a.q_row_stride + h * 128 + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(qp + ks * 16));
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // key tile range for this query block
+    int kt_lo = 0, kt_hi = (a.Skv + KB - 1) / KB;
+    if (a.window >= 0) {
+        kt_lo = max(0, q0 - a.window) / KB;
+        kt_hi = min(kt_hi, (min(a.Skv - 1, q0 + QB - 1 + a.window)) / KB + 1);
+    }
+
+    const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
+    const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
+
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int key0 = kt * KB;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K tile: 64 keys x 16 slots of 16 B
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256, key = c >> 4, slot = c & 15;
+            const int kr = min(key0 + key, a.Skv - 1);
+            const uint4 v = *reinterpret_cast<const uint4*>(kbase + (long)kr * a.k_row_stride + slot * 8);
+            *reinterpret_cast<uint4*>(Ks + k_off(key, slot)) = v;
+        }
+        // ---- stage V^T tile: 128 d x 8 chunks of 16 B (8 keys)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + i * 256, d = c >> 3, j = c & 7;
+            uint4 v = *reinterpret_cast<const uint4*>(vbase + (long)d * a.vt_ld + key0 + j * 8);
+            const int x = (d >> 1) & 15;
+            if (x & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // the two 8-B halves swap places under the XOR
+            *reinterpret_cast<uint4*>(Vs + d * 128 + ((j ^ (x >> 1)) << 4)) = v;
+        }
+        __syncthreads();
+
+        // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16x8 kf = as_bf16x8(*reinterpret_cast<const uint4*>(Ks + k_off(t2 * 32 + lq, ks * 2 + half)));
+                s[t2] = mfma32(kf, qf[ks], s[t2]);
+            }
+        }
+
+        // ---- mask + online softmax (lane owns query qrow; its 32 scores are keys key0 + t2*32 + mfma_row(r))
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                bool ok = key < a.Skv;
+                if (a.window >= 0) {
+                    const int dlt = qrow - key;
+                    ok = ok && dlt <= a.window && dlt >= -a.window;
+                }
+                const float v = ok ? s[t2][r] * scale_log2 : -INFINITY;
+                s[t2][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[t2][r] - m_use);
+                s[t2][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+        // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]
+        // k-slot e of MFMA step (t2, t) on lane-half `half` <-> key t2*32 + 16t + 4*half + (e&3) + 8*(e>>2):
+        // exactly registers r = 8t .. 8t+7 of s[t2] (C layout), so P needs no data movement.
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 pb;
+                pb.x = pack_bf2(s[t2][8 * t + 0], s[t2][8 * t + 1]);
+                pb.y = pack_bf2(s[t2][8 * t + 2], s[t2][8 * t + 3]);
+                pb.z = pack_bf2(s[t2][8 * t + 4], s[t2][8 * t + 5]);
+                pb.w = pack_bf2(s[t2][8 * t + 6], s[t2][8 * t + 7]);
+                const bf16x8 pf = as_bf16x8(pb);
+                const int c8 = t2 * 8 + t * 4 + half;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int d = dt * 32 + lq;
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(Vs + vt_off8(d, c8));
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(Vs + vt_off8(d, c8 + 2));
+                    const bf16x8 vf = as_bf16x8(make_uint4(v0.x, v0.y, v1.x, v1.y));
+                    o[dt] = mfma32(vf, pf, o[dt]);
+                }
+            }
+    }
+
+    // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = dt*32 + 8g + 4*half + {0..3} for g = 0..3
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < a.Sq) {
+        bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 4 * half;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint2 pk = make_uint2(pack_bf2(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv),
+                                            pack_bf2(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv));
+                *reinterpret_cast<uint2*>(op + dt * 32 + 8 * g) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention(const AttnArgs& a, hipStream_t s) {
+    ACE_CHECK(a.N > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
+    ACE_CHECK(!a.use_tab || a.N <= 64, "attention: at most 64 sequences with pointer tables");
+    ACE_CHECK(a.Hq % a.Hkv == 0, "attention: Hq % Hkv");
+    ACE_CHECK(a.vt_ld % 64 == 0 && a.vt_ld >= ((a.Skv + 63) / 64) * 64, "attention: V^T row stride must be a padded multiple of 64");
+    ACE_CHECK(a.q_row_stride % 8 == 0 && a.k_row_stride % 8 == 0 && a.o_row_stride % 4 == 0, "attention: strides");
+    dim3 grid((a.Sq + QB - 1) / QB, a.Hq, a.N), block(256);
+    const float scale_log2 = a.scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_kernel, grid, block, 0, s, a, scale_log2);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ace355

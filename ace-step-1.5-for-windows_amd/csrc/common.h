@@ -1,0 +1,140 @@
+// common.h - shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace ace355 {
+
+// ------------------------------------------------------------------ error plumbing (host)
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define ACE_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) return ::ace355::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define ACE_CHECK(cond, msg)                                  \
+    do {                                                      \
+        if (!(cond)) {                                        \
+            ::ace355::set_error(std::string("invalid argument: ") + (msg)); \
+            return 1;                                         \
+        }                                                     \
+    } while (0)
+
+#define ACE_LAUNCH_CHECK() ACE_HIP(hipGetLastError())
+
+// ------------------------------------------------------------------ device types
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite on this path)
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// MFMA 32x32x16 bf16: D[i][j] += sum_k A[i][k] B[k][j].
+//   A operand: lane l holds A[i = l&31][k = (l>>5)*8 + e], e = 0..7
+//   B operand: lane l holds B[k = (l>>5)*8 + e][j = l&31]
+//   C/D:       lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------ host-side kernel launch API (internal)
+struct GemmEpilogue {
+    int mode;  // 0 store bf16 (+bias), 1 store f32 (+bias), 2 residual-gate into f32 H, 3 swiglu -> bf16 [M,N/2]
+    const float* bias;
+    const float* g1;
+    const float* g2;
+    int g2_stride;
+    int rows_per_seq;
+};
+int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
+                const GemmEpilogue& ep, hipStream_t s);
+
+struct AttnArgs {
+    const bf16_t* q; long q_seq_stride; int q_row_stride;           // q[n][s][h*128 + d]
+    const bf16_t* k; long k_seq_stride; long k_head_stride; int k_row_stride;  // k[n][hkv][s][d] general strides
+    const bf16_t* vt; long vt_seq_stride; long vt_head_stride; int vt_ld;      // vt[n][hkv][d][s_pad]
+    int use_tab;          // 1: per-sequence absolute base addresses below (cross-attention condition slots)
+    unsigned long long k_tab[64];
+    unsigned long long vt_tab[64];
+    bf16_t* out; long o_seq_stride; int o_row_stride;
+    int N, Sq, Skv, Hq, Hkv, window;
+    float scale;
+};
+int launch_attention(const AttnArgs& a, hipStream_t s);
+
+int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, float eps, const float* sc1,
+                       const float* sc2, const float* sh1, const float* sh2, int stride, int rows_per_seq, hipStream_t s);
+int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const float* w, float eps,
+                         const float* cos_tab, const float* sin_tab, int S, hipStream_t s);
+// vt[n][h][d][s] (ld = s_pad) <- x[(n*S + s)*ld + col0 + h*128 + d]
+int launch_transpose_v(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vt, int s_pad, hipStream_t s);
+int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s);
+
+struct TVals { float t[64]; };
+int launch_sinusoid(const TVals& tv, int n, float* out /*[n,256]*/, hipStream_t s);
+// out[m][n] (+)= sum_k act(in[m][k]) W[n][k] + b[n];  in f32 [Mr,K], W bf16 [N,K], out f32 [Mr,N]
+int launch_small_linear(const float* in, const bf16_t* W, const float* b, float* out, int Mr, int N, int K,
+                        int silu_in, int silu_out, int accumulate, hipStream_t s);
+int launch_small_linear_ex(const float* in, const bf16_t* W, const float* b, float* out, float* out_silu, int Mr, int N,
+                           int K, int silu_out, int accumulate, hipStream_t s);
+int launch_pack_xin(const float* x, const float* ctx, bf16_t* xin, int N, int T, int Tpad, hipStream_t s);
+int launch_set_xin_latent(const float* xt, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s);
+int launch_set_xin_ctx(const float* ctx, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s);
+int launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
+int launch_bcast_rows(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s);
+int launch_copy_v(const float* vpad, float* v, int N, int T, int Tpad, hipStream_t s);
+int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, bf16_t* xin, int copies, int B, int T,
+                     int Tpad, float guidance, float dt, int apply_cfg, int do_cfg, int first, hipStream_t s);
+int launch_peak_normalize(float* wav, int B, long per_item, float* scratch, hipStream_t s);
+int launch_latent_check(const float* x, long n, int* flags_dev, hipStream_t s);
+
+// generic pack: dst bf16 / f32 from src (f32 or bf16) with an index mapping
+enum PackMode { PACK_ROWS = 0, PACK_ROWS_IL32 = 1, PACK_CONV_IN = 2, PACK_CONVT_OUT = 3 };
+int launch_pack(const void* src, int src_dtype, void* dst, int dst_is_bf16, int mode, long rows, long cols, long dst_ld,
+                long dst_row0, int p0, int p1, hipStream_t s);
+
+struct ConvArgs {
+    const bf16_t* x; long x_batch_stride; int L_in; int Cin;   // x[b][l][ci] NLC bf16
+    const bf16_t* w;                                             // w[n][tap][ci]
+    const float* bias;                                           // [N] or null
+    const float* alpha; const float* beta;                       // snake params [Cin] (log scale) or null
+    const bf16_t* res; long res_batch_stride;                    // residual, same layout as y, or null
+    void* y; long y_batch_stride;                                // out[b][flat]: flat = m*N + n + y_shift (bf16) or NCL f32
+    int B, M, N, taps, dil, center;                              // rows m in [0,M): x row = m + (tap-center)*dil
+    long y_shift; long y_valid;                                  // flat index valid iff 0 <= flat < y_valid (transposed conv crop)
+    int out_mode;                                                // 0: bf16 NLC flat; 1: f32 NCL [b][n][m] (n < n_real)
+    int n_real;
+};
+int launch_conv(const ConvArgs& a, hipStream_t s);
+int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s);
+
+}  // namespace ace355

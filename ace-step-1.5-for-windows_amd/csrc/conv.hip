@@ -1,0 +1,196 @@
+// conv.hip - Oobleck decoder convolutions as one MFMA implicit-GEMM kernel (channels-last, bf16, fp32 accumulate).
+//
+// Replaces, per call site of AutoencoderOobleck.decode (restated at acestep/models/mlx/vae_model.py):
+//   * Snake1d -> Conv1d(k=7, dilated) and Snake1d -> Conv1d(k=1) + residual   (OobleckResidualUnit, :62-87)
+//   * Snake1d -> ConvTranspose1d(k=2s, stride s, pad ceil(s/2))               (OobleckDecoderBlock, :119-142)
+//   * the k=7 input conv and the Snake -> k=7 bias-free output conv           (OobleckDecoder, :190-230)
+//
+// One formulation covers all of them:  y[b, m, n] = bias[n] + sum_{tap, ci} f(x[b, m + (tap-center)*dil, ci]) * w[n][tap][ci]
+// with f = Snake (x + 1/(e^beta+1e-9) * sin^2(e^alpha x)) or identity, zero rows outside [0, L_in).
+// A stride-s transposed conv is the 2-tap case with N = s*Cout (all s polyphase filters side by side): row i0 of the
+// GEMM is the contiguous NLC output span [(i0*s - pad)*Cout, ...+s*Cout), i.e. a flat shift of -pad*Cout (y_shift).
+//
+// gfx950 design: workgroup tile = 128 positions x BN outputs, K loop over 64-channel chunks; per chunk the input
+// window (128 + (taps-1)*dil rows) is loaded ONCE, Snake applied in registers (fp32), and parked in LDS (swizzled);
+// every tap then reads its shifted rows from LDS, so Snake costs (1 + halo) instead of `taps` evaluations and x is
+// read from HBM/L2 once per chunk.  Weight tiles stream through a 2-stage LDS ring, one barrier per tap.
+#include "common.h"
+
+namespace ace355 {
+
+namespace {
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+constexpr int WIN_MAX = 192;  // 128 + 6*9 = 182 rows needed at most
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
+    constexpr int MT = (BN == 128) ? 2 : 1;
+    constexpr int NT = (BN == 128) ? 2 : 1;
+    constexpr int WCH = BN * 8 / 256;  // 16-B weight chunks per thread per tile
+    __shared__ __attribute__((aligned(16))) char smem[WIN_MAX * 128 + 2 * BN * 128];
+    char* As = smem;
+    char* Wbase = smem + WIN_MAX * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, half = lane >> 5;
+    const int wm = (BN == 128) ? (wave >> 1) : wave;
+    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN, b = blockIdx.z;
+    const int Cin = a.Cin, taps = a.taps, dil = a.dil;
+    const int win_rows = 128 + (taps - 1) * dil;
+    const int x_row0 = m0 - a.center * dil;
+    const bf16_t* xb = a.x + (long)b * a.x_batch_stride;
+    const long wrow = (long)taps * Cin;  // elements per output channel in w
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sslot = tid & 7;
+    // weight staging addresses: chunk c = tid + i*256 -> row = c>>3 (i-th: + 32*i), slot = tid&7
+    const bf16_t* wsrc[WCH];
+    int wst[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        wsrc[i] = a.w + (long)min(n0 + row, a.N - 1) * wrow + sslot * 8;
+        wst[i] = lds_off(row, sslot);
+    }
+    uint4 rw[WCH];
+
+    for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
+        __syncthreads();  // previous chunk fully consumed
+        // ---- stage the input window once (Snake in fp32 registers)
+        float sa[8], sib[8];
+        const bool snake = a.alpha != nullptr;
+        if (snake) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sa[e] = a.alpha[ci0 + sslot * 8 + e];   // already exp(alpha)
+                sib[e] = a.beta[ci0 + sslot * 8 + e];   // already 1/(exp(beta)+1e-9)
+            }
+        }
+        for (int c = tid; c < win_rows * 8; c += 256) {
+            const int wr = c >> 3;
+            const int xr = x_row0 + wr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (xr >= 0 && xr < a.L_in) {
+                v = *reinterpret_cast<const uint4*>(xb + (long)xr * Cin + ci0 + sslot * 8);
+                if (snake) {
+                    uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        const float x0 = bf_lo(pv[e2]), x1 = bf_hi(pv[e2]);
+                        const float s0 = __sinf(sa[2 * e2] * x0), s1 = __sinf(sa[2 * e2 + 1] * x1);
+                        pv[e2] = pack_bf2(x0 + sib[2 * e2] * s0 * s0, x1 + sib[2 * e2 + 1] * s1 * s1);
+                    }
+                }
+            }
+            *reinterpret_cast<uint4*>(As + lds_off(wr, sslot)) = v;
+        }
+        // ---- weight tile for tap 0 of this chunk
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const uint4*>(wsrc[i] + ci0);
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(Wbase + wst[i]) = rw[i];
+        __syncthreads();
+
+        for (int tap = 0; tap < taps; ++tap) {
+            const bool more = (tap + 1) < taps;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const uint4*>(wsrc[i] + (long)(tap + 1) * Cin + ci0);
+            }
+            const char* Ws = Wbase + (tap & 1) * (BN * 128);
+            const int arow = wm * (MT * 32) + tap * dil + lq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 fa[MT], fw[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(arow + i * 32, kk * 2 + half)));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
+            }
+            if (more) {
+                char* Wd = Wbase + ((tap + 1) & 1) * (BN * 128);
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(Wd + wst[i]) = rw[i];
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * (NT * 32) + j * 32 + lq;
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (MT * 32) + i * 32 + mfma_row(r, lane);
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (a.out_mode == 0) {
+                    const long flat = (long)m * a.N + n + a.y_shift;
+                    if (flat < 0 || flat >= a.y_valid) continue;
+                    if (a.res) v += bf2f(a.res[(long)b * a.res_batch_stride + flat]);
+                    reinterpret_cast<bf16_t*>(a.y)[(long)b * a.y_batch_stride + flat] = f2bf(v);
+                } else {  // f32 NCL [b][n][m]
+                    if (n < a.n_real) reinterpret_cast<float*>(a.y)[(long)b * a.y_batch_stride + (long)n * a.M + m] = v;
+                }
+            }
+        }
+    }
+}
+
+// z f32 [B][C][T] (NCL) -> bf16 [B][T][C] (NLC)
+__global__ void ncl_to_nlc_kernel(const float* __restrict__ z, bf16_t* __restrict__ out, int C, int T, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long bt = i / C;
+    const int t = (int)(bt % T);
+    const long b = bt / T;
+    out[i] = f2bf(z[(b * C + c) * T + t]);
+}
+
+}  // namespace
+
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    ACE_CHECK(a.Cin % 64 == 0, "conv: Cin must be a multiple of 64");
+    ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil + 128 <= WIN_MAX && a.dil >= 1, "conv: window too large");
+    ACE_CHECK(a.B > 0 && a.M > 0 && a.N > 0, "conv: empty problem");
+    if (a.N >= 128 || a.N % 128 == 0) {
+        dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.B);
+        hipLaunchKernelGGL(conv_kernel<128>, grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((a.M + 127) / 128, (a.N + 31) / 32, a.B);
+        hipLaunchKernelGGL(conv_kernel<32>, grid, dim3(256), 0, s, a);
+    }
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s) {
+    const long total = (long)B * C * T;
+    hipLaunchKernelGGL(ncl_to_nlc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, out, C, T, total);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ace355

@@ -1,0 +1,660 @@
+// dit.hip - the DiT handle behind ace355.h: weight ingestion/packing, condition slots (cross K/V cache),
+// the decoder forward (AceStepDiTModel.forward, base.py:1303-1507) and the sampling loop
+// (generate_audio, base.py:1913-1981).  Host-side orchestration only; kernels live in gemm/attn/elementwise.hip.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ace355.h"
+#include "common.h"
+
+using namespace ace355;
+
+namespace {
+
+struct LayerW {
+    bf16_t *wqkv, *wo, *wq_c, *wkv_c, *wo_c, *wgu, *wdown;
+    float *n_sa, *n_ca, *n_mlp, *qn_s, *kn_s, *qn_c, *kn_c, *sst;
+};
+struct TimeEmbedW {
+    bf16_t *l1, *l2, *tp;
+    float *b1, *b2, *bp;
+};
+struct CondSlot {
+    int L = 0, Lpad = 0;
+    long cap = 0;          // allocated L capacity
+    bf16_t* kv = nullptr;  // [layers][L][2*KVD]   (K | V rows as produced by the GEMM; K head-normed in place)
+    bf16_t* vt = nullptr;  // [layers][KVH][128][Lpad]
+    bool valid = false;
+};
+
+}  // namespace
+
+struct ace355_dit {
+    ace355_dit_config cfg;
+    int D, F, QD, KVD, NL, KVH, HQ, OUTC;
+    std::vector<LayerW> layers;
+    bf16_t *w_in = nullptr, *w_out = nullptr, *w_cond = nullptr;
+    float *b_in = nullptr, *b_out = nullptr, *b_cond = nullptr, *norm_out = nullptr, *sst_out = nullptr;
+    TimeEmbedW te[2];
+    std::set<std::string> loaded;
+    size_t expected_tensors = 0;
+    bool finalized = false;
+    std::vector<void*> allocs;
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+
+    // workspace
+    int ws_N = 0, ws_T = 0;
+    std::vector<void*> ws_allocs;
+    bf16_t *xin = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr;
+    float *h = nullptr, *vpad = nullptr, *tfreq = nullptr, *ta1 = nullptr, *temb = nullptr, *tsilu = nullptr, *tproj = nullptr;
+    float *xt = nullptr, *avg = nullptr;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_S = 0;
+    // condition staging
+    bf16_t *enc_bf = nullptr, *enc_emb = nullptr;
+    long enc_cap = 0;
+    CondSlot slots[8];
+    int* flags_dev = nullptr;
+
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev, attn_ev;
+    double gemm_flops = 0, attn_flops = 0;
+    long gemm_launches = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(std::vector<void*>& bag, T** p, size_t n) {
+    void* q = nullptr;
+    ACE_HIP(hipMalloc(&q, n * sizeof(T) + 256));
+    bag.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+#define ALLOC(bag, ptr, n)                         \
+    do {                                           \
+        int _rc = dev_alloc(bag, &(ptr), (n));     \
+        if (_rc) return _rc;                       \
+    } while (0)
+
+struct Dest {
+    void* dst;
+    int is_bf16;
+    int mode;
+    long rows, cols, dst_ld, dst_row0;
+    int p0, p1;
+};
+
+// Map a reference state_dict key to its packed destination.
+bool resolve(ace355_dit* h, const std::string& name, Dest* d) {
+    const long D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+    auto rows = [&](void* dst, int bf, long r, long c, long ld, long row0) {
+        *d = Dest{dst, bf, PACK_ROWS, r, c, ld, row0, 0, 0};
+        return true;
+    };
+    if (name.rfind("layers.", 0) == 0) {
+        const size_t dot = name.find('.', 7);
+        if (dot == std::string::npos) return false;
+        const int li = atoi(name.substr(7, dot - 7).c_str());
+        if (li < 0 || li >= h->NL) return false;
+        LayerW& L = h->layers[li];
+        const std::string r = name.substr(dot + 1);
+        if (r == "scale_shift_table") return rows(L.sst, 0, 6, D, D, 0);
+        if (r == "self_attn_norm.weight") return rows(L.n_sa, 0, 1, D, D, 0);
+        if (r == "cross_attn_norm.weight") return rows(L.n_ca, 0, 1, D, D, 0);
+        if (r == "mlp_norm.weight") return rows(L.n_mlp, 0, 1, D, D, 0);
+        if (r == "self_attn.q_proj.weight") return rows(L.wqkv, 1, QD, D, D, 0);
+        if (r == "self_attn.k_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD);
+        if (r == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
+        if (r == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
+        if (r == "self_attn.q_norm.weight") return rows(L.qn_s, 0, 1, 128, 128, 0);
+        if (r == "self_attn.k_norm.weight") return rows(L.kn_s, 0, 1, 128, 128, 0);
+        if (r == "cross_attn.q_proj.weight") return rows(L.wq_c, 1, QD, D, D, 0);
+        if (r == "cross_attn.k_proj.weight") return rows(L.wkv_c, 1, KVD, D, D, 0);
+        if (r == "cross_attn.v_proj.weight") return rows(L.wkv_c, 1, KVD, D, D, KVD);
+        if (r == "cross_attn.o_proj.weight") return rows(L.wo_c, 1, D, QD, QD, 0);
+        if (r == "cross_attn.q_norm.weight") return rows(L.qn_c, 0, 1, 128, 128, 0);
+        if (r == "cross_attn.k_norm.weight") return rows(L.kn_c, 0, 1, 128, 128, 0);
+        if (r == "mlp.gate_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 0, 0}; return true; }
+        if (r == "mlp.up_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 1, 0}; return true; }
+        if (r == "mlp.down_proj.weight") return rows(L.wdown, 1, D, F, F, 0);
+        return false;
+    }
+    const int C = h->cfg.in_channels, P = h->cfg.patch_size, OC = h->OUTC;
+    if (name == "proj_in.1.weight") { *d = Dest{h->w_in, 1, PACK_CONV_IN, D, (long)C * P, (long)C * P, 0, C, P}; return true; }
+    if (name == "proj_in.1.bias") return rows(h->b_in, 0, 1, D, D, 0);
+    if (name == "proj_out.1.weight") { *d = Dest{h->w_out, 1, PACK_CONVT_OUT, D, (long)OC * P, D, 0, OC, P}; return true; }
+    if (name == "proj_out.1.bias") return rows(h->b_out, 0, 1, OC, OC, 0);  // duplicated per patch position at finalize
+    for (int e = 0; e < 2; ++e) {
+        const std::string p = e == 0 ? "time_embed." : "time_embed_r.";
+        if (name.rfind(p, 0) != 0) continue;
+        const std::string r = name.substr(p.size());
+        TimeEmbedW& T = h->te[e];
+        if (r == "linear_1.weight") return rows(T.l1, 1, D, 256, 256, 0);
+        if (r == "linear_1.bias") return rows(T.b1, 0, 1, D, D, 0);
+        if (r == "linear_2.weight") return rows(T.l2, 1, D, D, D, 0);
+        if (r == "linear_2.bias") return rows(T.b2, 0, 1, D, D, 0);
+        if (r == "time_proj.weight") return rows(T.tp, 1, 6 * D, D, D, 0);
+        if (r == "time_proj.bias") return rows(T.bp, 0, 1, 6 * D, 6 * D, 0);
+        return false;
+    }
+    if (name == "condition_embedder.weight") return rows(h->w_cond, 1, D, D, D, 0);
+    if (name == "condition_embedder.bias") return rows(h->b_cond, 0, 1, D, D, 0);
+    if (name == "norm_out.weight") return rows(h->norm_out, 0, 1, D, D, 0);
+    if (name == "scale_shift_table") return rows(h->sst_out, 0, 2, D, D, 0);
+    return false;
+}
+
+struct EvScope {
+    ace355_dit* h;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* bag;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EvScope(ace355_dit* h_, std::vector<std::pair<hipEvent_t, hipEvent_t>>* b, hipStream_t s_) : h(h_), bag(b), s(s_) {
+        if (h->profile) {
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, s);
+        }
+    }
+    ~EvScope() {
+        if (h->profile) {
+            hipEventRecord(e1, s);
+            bag->push_back({e0, e1});
+        }
+    }
+};
+
+int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
+         const GemmEpilogue& ep, hipStream_t s) {
+    EvScope ev(h, &h->gemm_ev, s);
+    if (h->profile) {
+        h->gemm_flops += 2.0 * M * N * K;
+        h->gemm_launches++;
+    }
+    return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
+}
+
+int ensure_rope(ace355_dit* h, int S, hipStream_t s) {
+    if (S <= h->rope_S) return 0;
+    int cap = 512;
+    while (cap < S) cap *= 2;
+    ALLOC(h->allocs, h->rope_cos, (size_t)cap * 64);
+    ALLOC(h->allocs, h->rope_sin, (size_t)cap * 64);
+    int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->cfg.rope_theta, s);
+    if (rc) return rc;
+    h->rope_S = cap;
+    return 0;
+}
+
+int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
+    const int S = (T + 1) / 2;
+    int rc = ensure_rope(h, S, s);
+    if (rc) return rc;
+    if (N <= h->ws_N && T <= h->ws_T) return 0;
+    ACE_HIP(hipStreamSynchronize(s));
+    for (void* p : h->ws_allocs) hipFree(p);
+    h->ws_allocs.clear();
+    const int capN = N > h->ws_N ? N : h->ws_N, capT = T > h->ws_T ? T : h->ws_T;
+    const long cS = (capT + 1) / 2, cTp = 2 * cS, M = (long)capN * cS, Sp = ((cS + 63) / 64) * 64;
+    const long D = h->D, QKV = h->QD + 2 * h->KVD;
+    ALLOC(h->ws_allocs, h->xin, (size_t)capN * cTp * 192);
+    ALLOC(h->ws_allocs, h->h, (size_t)M * D);
+    ALLOC(h->ws_allocs, h->xn, (size_t)M * D);
+    ALLOC(h->ws_allocs, h->qkv, (size_t)M * QKV);
+    ALLOC(h->ws_allocs, h->ao, (size_t)M * h->QD);
+    ALLOC(h->ws_allocs, h->act, (size_t)M * h->F);
+    ALLOC(h->ws_allocs, h->vt, (size_t)capN * h->KVH * 128 * Sp);
+    ALLOC(h->ws_allocs, h->vpad, (size_t)M * 2 * h->OUTC);
+    ALLOC(h->ws_allocs, h->tfreq, (size_t)2 * capN * 256);
+    ALLOC(h->ws_allocs, h->ta1, (size_t)capN * D);
+    ALLOC(h->ws_allocs, h->temb, (size_t)capN * D);
+    ALLOC(h->ws_allocs, h->tsilu, (size_t)capN * D);
+    ALLOC(h->ws_allocs, h->tproj, (size_t)capN * 6 * D);
+    ALLOC(h->ws_allocs, h->xt, (size_t)capN * capT * h->OUTC);
+    ALLOC(h->ws_allocs, h->avg, (size_t)capN * capT * h->OUTC);
+    h->ws_N = capN;
+    h->ws_T = capT;
+    return 0;
+}
+
+// TimestepEmbedding x2 (base.py:1340-1344): temb[rows][D], tproj[rows][6D] for `rows` distinct (t, t - t_r) pairs.
+int time_embed(ace355_dit* h, const float* t, const float* tr, int rows, hipStream_t s) {
+    TVals tv;
+    const int D = h->D;
+    for (int e = 0; e < 2; ++e) {
+        for (int i = 0; i < rows; ++i) tv.t[i] = e == 0 ? t[i] : (t[i] - tr[i]);
+        float* tf = h->tfreq + (size_t)e * rows * 256;
+        int rc = launch_sinusoid(tv, rows, tf, s);
+        if (rc) return rc;
+        const TimeEmbedW& T = h->te[e];
+        rc = launch_small_linear_ex(tf, T.l1, T.b1, h->ta1, nullptr, rows, D, 256, /*silu_out*/ 1, 0, s);
+        if (rc) return rc;
+        rc = launch_small_linear_ex(h->ta1, T.l2, T.b2, h->temb, h->tsilu, rows, D, D, 0, /*accumulate*/ e, s);
+        if (rc) return rc;
+        rc = launch_small_linear_ex(h->tsilu, T.tp, T.bp, h->tproj, nullptr, rows, 6 * D, D, 0, e, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Decoder body on a packed patch input xin[N][Tpad][192]; writes vpad[N][Tpad][64].
+// temb_rows == 1: every sequence shares one timestep (the sampler); else one row per sequence.
+int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, hipStream_t s) {
+    const int S = (T + 1) / 2, M = N * S;
+    const int D = h->D, F = h->F, QD = h->QD, KVD = h->KVD, QKV = QD + 2 * KVD;
+    const int Sp = ((S + 63) / 64) * 64;
+    const float eps = h->cfg.rms_norm_eps;
+    const float scale = 1.0f / sqrtf((float)h->cfg.head_dim);
+    const int tstride = temb_rows == 1 ? 0 : 6 * D;
+    int rc;
+    GemmEpilogue ep{};
+
+    int L = -1;
+    for (int i = 0; i < N; ++i) {
+        ACE_CHECK(slots[i] >= 0 && slots[i] < 8 && h->slots[slots[i]].valid, "forward: condition slot not set");
+        if (L < 0) L = h->slots[slots[i]].L;
+        ACE_CHECK(h->slots[slots[i]].L == L, "forward: all condition slots of one call must share L");
+    }
+    const int Lpad = ((L + 63) / 64) * 64;
+
+    // patchify: Conv1d(192 -> D, k=2, s=2) == GEMM over [M, 384] (base.py:1358)
+    ep = GemmEpilogue{1, h->b_in, nullptr, nullptr, 0, 0};
+    rc = gemm(h, h->xin, 2 * h->cfg.in_channels, h->w_in, 2 * h->cfg.in_channels, h->h, D, M, D, 2 * h->cfg.in_channels, ep, s);
+    if (rc) return rc;
+
+    for (int li = 0; li < h->NL; ++li) {
+        const LayerW& W = h->layers[li];
+        const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
+        // ---- self attention (base.py:499-511)
+        rc = launch_rmsnorm_mod(h->h, W.n_sa, h->xn, M, D, eps, W.sst + 1 * D, h->tproj + 1 * D, W.sst + 0 * D, h->tproj + 0 * D,
+                                tstride, S, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
+        if (rc) return rc;
+        rc = launch_headnorm_rope(h->qkv, M, QKV, 0, h->HQ, W.qn_s, eps, h->rope_cos, h->rope_sin, S, s);
+        if (rc) return rc;
+        rc = launch_headnorm_rope(h->qkv, M, QKV, QD, h->KVH, W.kn_s, eps, h->rope_cos, h->rope_sin, S, s);
+        if (rc) return rc;
+        rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
+        if (rc) return rc;
+        {
+            AttnArgs a{};
+            a.q = h->qkv; a.q_seq_stride = (long)S * QKV; a.q_row_stride = QKV;
+            a.k = h->qkv + QD; a.k_seq_stride = (long)S * QKV; a.k_head_stride = 128; a.k_row_stride = QKV;
+            a.vt = h->vt; a.vt_seq_stride = (long)h->KVH * 128 * Sp; a.vt_head_stride = 128L * Sp; a.vt_ld = Sp;
+            a.use_tab = 0;
+            a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
+            a.N = N; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
+            a.window = sliding ? h->cfg.sliding_window : -1;
+            a.scale = scale;
+            EvScope ev(h, &h->attn_ev, s);
+            if (h->profile) {
+                double keys = (double)S;
+                if (sliding) {
+                    double tot = 0;
+                    for (int i = 0; i < S; ++i) tot += (double)(std::min(S - 1, i + a.window) - std::max(0, i - a.window) + 1);
+                    keys = tot / S;
+                }
+                h->attn_flops += 4.0 * N * h->HQ * (double)S * keys * 128.0;
+            }
+            rc = launch_attention(a, s);
+            if (rc) return rc;
+        }
+        ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S};
+        rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
+        if (rc) return rc;
+
+        // ---- cross attention (base.py:515-526): un-modulated norm, plain residual, cached K/V, no RoPE
+        rc = launch_rmsnorm_mod(h->h, W.n_ca, h->xn, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        rc = gemm(h, h->xn, D, W.wq_c, D, h->qkv, QD, M, QD, D, ep, s);
+        if (rc) return rc;
+        rc = launch_headnorm_rope(h->qkv, M, QD, 0, h->HQ, W.qn_c, eps, nullptr, nullptr, S, s);
+        if (rc) return rc;
+        {
+            AttnArgs a{};
+            a.q = h->qkv; a.q_seq_stride = (long)S * QD; a.q_row_stride = QD;
+            a.use_tab = 1;
+            for (int i = 0; i < N; ++i) {
+                const CondSlot& cs = h->slots[slots[i]];
+                a.k_tab[i] = (unsigned long long)(cs.kv + (size_t)li * cs.L * 2 * KVD);
+                a.vt_tab[i] = (unsigned long long)(cs.vt + (size_t)li * h->KVH * 128 * cs.Lpad);
+            }
+            a.k_head_stride = 128; a.k_row_stride = 2 * KVD;
+            a.vt_head_stride = 128L * Lpad; a.vt_ld = Lpad;
+            a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
+            a.N = N; a.Sq = S; a.Skv = L; a.Hq = h->HQ; a.Hkv = h->KVH; a.window = -1; a.scale = scale;
+            EvScope ev(h, &h->attn_ev, s);
+            if (h->profile) h->attn_flops += 4.0 * N * h->HQ * (double)S * L * 128.0;
+            rc = launch_attention(a, s);
+            if (rc) return rc;
+        }
+        ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};
+        rc = gemm(h, h->ao, QD, W.wo_c, QD, h->h, D, M, D, QD, ep, s);
+        if (rc) return rc;
+
+        // ---- SwiGLU MLP (base.py:530-533)
+        rc = launch_rmsnorm_mod(h->h, W.n_mlp, h->xn, M, D, eps, W.sst + 4 * D, h->tproj + 4 * D, W.sst + 3 * D, h->tproj + 3 * D,
+                                tstride, S, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{3, nullptr, nullptr, nullptr, 0, 0};
+        rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, h->tproj + 5 * D, tstride, S};
+        rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
+        if (rc) return rc;
+    }
+
+    // output norm + modulation with temb (base.py:1491-1496): shift = sst[0] + temb, scale = sst[1] + temb
+    rc = launch_rmsnorm_mod(h->h, h->norm_out, h->xn, M, D, eps, h->sst_out + D, h->temb, h->sst_out, h->temb,
+                            temb_rows == 1 ? 0 : D, S, s);
+    if (rc) return rc;
+    // proj_out: ConvTranspose1d(D -> 64, k=2, s=2) == GEMM to [M, 128] == [N, 2S, 64] (base.py:1498)
+    ep = GemmEpilogue{1, h->b_out, nullptr, nullptr, 0, 0};
+    rc = gemm(h, h->xn, D, h->w_out, D, h->vpad, 2 * h->OUTC, M, 2 * h->OUTC, D, ep, s);
+    return rc;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
+    ACE_CHECK(cfg && out, "dit_create: null argument");
+    ACE_CHECK(cfg->head_dim == 128, "dit_create: head_dim must be 128");
+    ACE_CHECK(cfg->patch_size == 2, "dit_create: patch_size must be 2");
+    ACE_CHECK(cfg->hidden_size % 256 == 0 || cfg->hidden_size % 64 == 0, "dit_create: hidden_size % 64");
+    ACE_CHECK(cfg->hidden_size % 64 == 0 && cfg->intermediate_size % 64 == 0, "dit_create: sizes must be multiples of 64");
+    ACE_CHECK((2 * cfg->in_channels) % 64 == 0, "dit_create: 2*in_channels must be a multiple of 64");
+    ACE_CHECK(cfg->num_heads % cfg->num_kv_heads == 0 && cfg->num_layers > 0 && cfg->num_layers <= 64, "dit_create: heads/layers");
+    ACE_CHECK(cfg->out_channels % 4 == 0 && cfg->out_channels == 64, "dit_create: out_channels must be 64");
+    ace355_dit* h = new ace355_dit();
+    h->cfg = *cfg;
+    h->D = cfg->hidden_size; h->F = cfg->intermediate_size; h->NL = cfg->num_layers;
+    h->HQ = cfg->num_heads; h->KVH = cfg->num_kv_heads; h->QD = cfg->num_heads * 128; h->KVD = cfg->num_kv_heads * 128;
+    h->OUTC = cfg->out_channels;
+    const size_t D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+    h->layers.resize(h->NL);
+    for (LayerW& L : h->layers) {
+        ALLOC(h->allocs, L.wqkv, (QD + 2 * KVD) * D);
+        ALLOC(h->allocs, L.wo, D * QD);
+        ALLOC(h->allocs, L.wq_c, QD * D);
+        ALLOC(h->allocs, L.wkv_c, 2 * KVD * D);
+        ALLOC(h->allocs, L.wo_c, D * QD);
+        ALLOC(h->allocs, L.wgu, 2 * F * D);
+        ALLOC(h->allocs, L.wdown, D * F);
+        ALLOC(h->allocs, L.n_sa, D); ALLOC(h->allocs, L.n_ca, D); ALLOC(h->allocs, L.n_mlp, D);
+        ALLOC(h->allocs, L.qn_s, 128); ALLOC(h->allocs, L.kn_s, 128); ALLOC(h->allocs, L.qn_c, 128); ALLOC(h->allocs, L.kn_c, 128);
+        ALLOC(h->allocs, L.sst, 6 * D);
+    }
+    const size_t CP = (size_t)cfg->in_channels * cfg->patch_size;
+    ALLOC(h->allocs, h->w_in, D * CP);
+    ALLOC(h->allocs, h->b_in, D);
+    ALLOC(h->allocs, h->w_out, (size_t)2 * h->OUTC * D);
+    ALLOC(h->allocs, h->b_out, (size_t)2 * h->OUTC);
+    for (int e = 0; e < 2; ++e) {
+        ALLOC(h->allocs, h->te[e].l1, D * 256); ALLOC(h->allocs, h->te[e].b1, D);
+        ALLOC(h->allocs, h->te[e].l2, D * D); ALLOC(h->allocs, h->te[e].b2, D);
+        ALLOC(h->allocs, h->te[e].tp, 6 * D * D); ALLOC(h->allocs, h->te[e].bp, 6 * D);
+    }
+    ALLOC(h->allocs, h->w_cond, D * D);
+    ALLOC(h->allocs, h->b_cond, D);
+    ALLOC(h->allocs, h->norm_out, D);
+    ALLOC(h->allocs, h->sst_out, 2 * D);
+    ALLOC(h->allocs, h->flags_dev, 4);
+    h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
+    *out = h;
+    return ACE355_OK;
+}
+
+void ace355_dit_destroy(ace355_dit* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    for (void* p : h->ws_allocs) hipFree(p);
+    for (CondSlot& c : h->slots) {
+        if (c.kv) hipFree(c.kv);
+        if (c.vt) hipFree(c.vt);
+    }
+    if (h->stage) hipFree(h->stage);
+    if (h->enc_bf) hipFree(h->enc_bf);
+    if (h->enc_emb) hipFree(h->enc_emb);
+    for (auto& e : h->gemm_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : h->attn_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete h;
+}
+
+int ace355_dit_load_tensor(ace355_dit* h, const char* name, const void* data, int dtype, int64_t numel, int is_device) {
+    ACE_CHECK(h && name && data, "dit_load_tensor: null argument");
+    ACE_CHECK(dtype == ACE355_DTYPE_F32 || dtype == ACE355_DTYPE_BF16, "dit_load_tensor: dtype");
+    Dest d;
+    if (!resolve(h, name, &d)) {
+        set_error(std::string("dit_load_tensor: unknown tensor name '") + name + "'");
+        return ACE355_ERR_INVALID;
+    }
+    if (numel != d.rows * d.cols) {
+        set_error(std::string("dit_load_tensor: wrong element count for '") + name + "': got " + std::to_string(numel) +
+                  ", expected " + std::to_string(d.rows * d.cols));
+        return ACE355_ERR_INVALID;
+    }
+    const size_t esz = dtype == ACE355_DTYPE_F32 ? 4 : 2;
+    const void* src = data;
+    if (!is_device) {
+        const size_t bytes = (size_t)numel * esz;
+        if (bytes > h->stage_bytes) {
+            if (h->stage) ACE_HIP(hipFree(h->stage));
+            h->stage = nullptr;
+            ACE_HIP(hipMalloc(&h->stage, bytes));
+            h->stage_bytes = bytes;
+        }
+        ACE_HIP(hipMemcpy(h->stage, data, bytes, hipMemcpyHostToDevice));
+        src = h->stage;
+    }
+    int rc = launch_pack(src, dtype, d.dst, d.is_bf16, d.mode, d.rows, d.cols, d.dst_ld, d.dst_row0, d.p0, d.p1, nullptr);
+    if (rc) return rc;
+    if (std::string(name) == "proj_out.1.bias") {  // bias[p*64 + c] = b[c]
+        rc = launch_pack(src, dtype, h->b_out, 0, PACK_ROWS, 1, h->OUTC, h->OUTC, 0, 0, 0, nullptr);
+        if (rc) return rc;
+        rc = launch_pack(src, dtype, h->b_out + h->OUTC, 0, PACK_ROWS, 1, h->OUTC, h->OUTC, 0, 0, 0, nullptr);
+        if (rc) return rc;
+    }
+    ACE_HIP(hipDeviceSynchronize());
+    h->loaded.insert(name);
+    h->finalized = false;
+    return ACE355_OK;
+}
+
+int ace355_dit_finalize(ace355_dit* h) {
+    ACE_CHECK(h, "dit_finalize: null handle");
+    if (h->loaded.size() != h->expected_tensors) {
+        set_error("dit_finalize: " + std::to_string(h->loaded.size()) + " of " + std::to_string(h->expected_tensors) +
+                  " tensors loaded");
+        return ACE355_ERR_STATE;
+    }
+    if (h->stage) { hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+    h->finalized = true;
+    return ACE355_OK;
+}
+
+int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int rows, int L, void* stream) {
+    ACE_CHECK(h && enc_dev, "set_condition: null argument");
+    if (!h->finalized) { set_error("set_condition: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(slot >= 0 && slot < 8, "set_condition: slot out of range");
+    ACE_CHECK(L > 0 && (rows == L || rows == 1), "set_condition: rows must be L or 1");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->D, KVD = h->KVD;
+    const int Lpad = ((L + 63) / 64) * 64;
+    if (L > h->enc_cap) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->enc_bf) hipFree(h->enc_bf);
+        if (h->enc_emb) hipFree(h->enc_emb);
+        ACE_HIP(hipMalloc((void**)&h->enc_bf, (size_t)L * D * 2 + 256));
+        ACE_HIP(hipMalloc((void**)&h->enc_emb, (size_t)2 * L * D * 2 + 256));
+        h->enc_cap = L;
+    }
+    CondSlot& cs = h->slots[slot];
+    if (L > cs.cap) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (cs.kv) hipFree(cs.kv);
+        if (cs.vt) hipFree(cs.vt);
+        ACE_HIP(hipMalloc((void**)&cs.kv, (size_t)h->NL * L * 2 * KVD * 2 + 256));
+        ACE_HIP(hipMalloc((void**)&cs.vt, (size_t)h->NL * h->KVH * 128 * Lpad * 2 + 256));
+        cs.cap = L;
+    }
+    cs.valid = false;
+    int rc = launch_f32_to_bf16(enc_dev, h->enc_bf, (long)rows * D, s);
+    if (rc) return rc;
+    // condition_embedder (base.py:1359)
+    GemmEpilogue ep{0, h->b_cond, nullptr, nullptr, 0, 0};
+    bf16_t* emb = h->enc_emb;
+    rc = gemm(h, h->enc_bf, D, h->w_cond, D, emb, D, rows, D, D, ep, s);
+    if (rc) return rc;
+    if (rows == 1 && L > 1) {  // null_condition_emb.expand_as(enc) (base.py:1907)
+        bf16_t* wide = h->enc_emb + (size_t)L * D;
+        rc = launch_bcast_rows(emb, wide, L, D, s);
+        if (rc) return rc;
+        emb = wide;
+    }
+    for (int li = 0; li < h->NL; ++li) {
+        const LayerW& W = h->layers[li];
+        bf16_t* kv = cs.kv + (size_t)li * L * 2 * KVD;
+        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        rc = gemm(h, emb, D, W.wkv_c, D, kv, 2 * KVD, L, 2 * KVD, D, ep, s);  // K | V (base.py:320-321)
+        if (rc) return rc;
+        rc = launch_headnorm_rope(kv, L, 2 * KVD, 0, h->KVH, W.kn_c, h->cfg.rms_norm_eps, nullptr, nullptr, L, s);
+        if (rc) return rc;
+        rc = launch_transpose_v(kv, 2 * KVD, KVD, 1, L, h->KVH, cs.vt + (size_t)li * h->KVH * 128 * Lpad, Lpad, s);
+        if (rc) return rc;
+    }
+    cs.L = L;
+    cs.Lpad = Lpad;
+    cs.valid = true;
+    return ACE355_OK;
+}
+
+int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, const float* t_host, const float* t_r_host,
+                       const int32_t* slots_host, int N, int T, float* v_out_dev, void* stream) {
+    ACE_CHECK(h && x_dev && ctx_dev && t_host && t_r_host && slots_host && v_out_dev, "dit_forward: null argument");
+    if (!h->finalized) { set_error("dit_forward: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(N > 0 && N <= ACE355_MAX_SEQS && T > 0, "dit_forward: N in [1,64], T > 0");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_workspace(h, N, T, s);
+    if (rc) return rc;
+    const int Tpad = 2 * ((T + 1) / 2);
+    rc = launch_pack_xin(x_dev, ctx_dev, h->xin, N, T, Tpad, s);
+    if (rc) return rc;
+    rc = time_embed(h, t_host, t_r_host, N, s);
+    if (rc) return rc;
+    rc = forward_core(h, N, T, slots_host, N, s);
+    if (rc) return rc;
+    return launch_copy_v(h->vpad, v_out_dev, N, T, Tpad, s);
+}
+
+int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev, int B, int T, const ace355_sample_params* p,
+                      float* latents_out_dev, float* per_step_ms_host, void* stream) {
+    ACE_CHECK(h && xt0_dev && ctx_dev && p && latents_out_dev && p->t_sched_host, "dit_sample: null argument");
+    if (!h->finalized) { set_error("dit_sample: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && T > 0 && p->num_steps > 0, "dit_sample: empty problem");
+    if (p->infer_method != 0) { set_error("dit_sample: only infer_method 'ode' is supported (sde uses an unseeded RNG)"); return ACE355_ERR_UNSUPPORTED; }
+    if (p->use_adg) { set_error("dit_sample: use_adg is not supported by the native path this round"); return ACE355_ERR_UNSUPPORTED; }
+    const bool do_cfg = p->guidance_scale > 1.0f;
+    const int copies = do_cfg ? 2 : 1, N = B * copies;
+    ACE_CHECK(N <= ACE355_MAX_SEQS, "dit_sample: at most 64 sequences per call");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_workspace(h, N, T, s);
+    if (rc) return rc;
+    const int Tpad = 2 * ((T + 1) / 2);
+    const size_t lat_bytes = (size_t)B * T * h->OUTC * sizeof(float);
+    ACE_HIP(hipMemcpyAsync(h->xt, xt0_dev, lat_bytes, hipMemcpyDeviceToDevice, s));
+    rc = launch_set_xin_ctx(ctx_dev, h->xin, B, copies, T, Tpad, s);
+    if (rc) return rc;
+    rc = launch_set_xin_latent(h->xt, h->xin, B, copies, T, Tpad, s);
+    if (rc) return rc;
+
+    int slots[ACE355_MAX_SEQS];
+    int cond = p->cond_slot;
+    bool switched = false;
+    int apg_calls = 0;
+    std::vector<hipEvent_t> evs;
+    if (per_step_ms_host) {
+        evs.resize(p->num_steps + 1);
+        for (auto& e : evs) hipEventCreate(&e);
+        hipEventRecord(evs[0], s);
+    }
+    for (int i = 0; i < p->num_steps; ++i) {
+        if (i >= p->cover_switch_step && !switched) {  // base.py:1916-1927
+            switched = true;
+            ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
+            cond = p->non_cover_slot;
+            rc = launch_set_xin_ctx(p->ctx_non_cover_dev, h->xin, B, copies, T, Tpad, s);
+            if (rc) return rc;
+        }
+        for (int b = 0; b < B; ++b) {
+            slots[b] = cond;
+            if (do_cfg) slots[B + b] = p->null_slot;
+        }
+        const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
+        rc = time_embed(h, &t_curr, &t_curr, 1, s);
+        if (rc) return rc;
+        rc = forward_core(h, N, T, slots, 1, s);
+        if (rc) return rc;
+        const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
+        const float dt = t_curr - t_prev;
+        rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
+                              apply, do_cfg ? 1 : 0, apg_calls == 0 ? 1 : 0, s);
+        if (rc) return rc;
+        if (do_cfg && apply) ++apg_calls;
+        if (per_step_ms_host) hipEventRecord(evs[i + 1], s);
+    }
+    ACE_HIP(hipMemcpyAsync(latents_out_dev, h->xt, lat_bytes, hipMemcpyDeviceToDevice, s));
+    if (per_step_ms_host) {
+        ACE_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < p->num_steps; ++i) hipEventElapsedTime(&per_step_ms_host[i], evs[i], evs[i + 1]);
+        for (auto& e : evs) hipEventDestroy(e);
+    }
+    return ACE355_OK;
+}
+
+int ace355_dit_set_profile(ace355_dit* h, int enable) {
+    ACE_CHECK(h, "set_profile: null handle");
+    hipDeviceSynchronize();
+    for (auto& e : h->gemm_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : h->attn_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    h->gemm_ev.clear();
+    h->attn_ev.clear();
+    h->gemm_flops = h->attn_flops = 0;
+    h->gemm_launches = 0;
+    h->profile = enable != 0;
+    return ACE355_OK;
+}
+
+int ace355_dit_get_profile(ace355_dit* h, double* gemm_ms, double* gemm_flops, double* attn_ms, double* attn_flops,
+                           int64_t* gemm_launches) {
+    ACE_CHECK(h, "get_profile: null handle");
+    ACE_HIP(hipDeviceSynchronize());
+    double g = 0, a = 0;
+    float ms;
+    for (auto& e : h->gemm_ev) { if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) g += ms; }
+    for (auto& e : h->attn_ev) { if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) a += ms; }
+    if (gemm_ms) *gemm_ms = g;
+    if (gemm_flops) *gemm_flops = h->gemm_flops;
+    if (attn_ms) *attn_ms = a;
+    if (attn_flops) *attn_flops = h->attn_flops;
+    if (gemm_launches) *gemm_launches = h->gemm_launches;
+    return ACE355_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,528 @@
+// elementwise.hip - HBM-bound kernels of the DiT path: RMSNorm+modulation, head-RMSNorm+RoPE, V transpose,
+// timestep-embedding GEMVs, patchify input packing, the APG + Euler sampler step, weight packing, post-processing.
+// All are wave64 kernels with 8/16-byte vector accesses and shuffle reductions (no LDS unless transposing).
+#include "common.h"
+
+#include <math.h>
+
+#include <vector>
+
+namespace ace355 {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// y = bf16( w * (x * rsqrt(mean(x^2) + eps)) * (1 + sc) + sh )     (Qwen3RMSNorm + base.py:499,530,1496)
+// one wave per row; x f32 [M, D]
+__global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          bf16_t* __restrict__ y, int M, int D, float eps,
+                                                          const float* __restrict__ sc1, const float* __restrict__ sc2,
+                                                          const float* __restrict__ sh1, const float* __restrict__ sh2,
+                                                          int stride, int rows_per_seq) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (long)row * D;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    const long so = sc1 ? (long)(row / rows_per_seq) * stride : 0;
+    bf16_t* yr = y + (long)row * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        float o0 = ww.x * (v.x * rstd), o1 = ww.y * (v.y * rstd), o2 = ww.z * (v.z * rstd), o3 = ww.w * (v.w * rstd);
+        if (sc1) {
+            const float4 a = *reinterpret_cast<const float4*>(sc1 + c);
+            const float4 b = *reinterpret_cast<const float4*>(sc2 + so + c);
+            const float4 e = *reinterpret_cast<const float4*>(sh1 + c);
+            const float4 f = *reinterpret_cast<const float4*>(sh2 + so + c);
+            o0 = o0 * (1.f + (a.x + b.x)) + (e.x + f.x);
+            o1 = o1 * (1.f + (a.y + b.y)) + (e.y + f.y);
+            o2 = o2 * (1.f + (a.z + b.z)) + (e.z + f.z);
+            o3 = o3 * (1.f + (a.w + b.w)) + (e.w + f.w);
+        }
+        uint2 p;
+        p.x = pack_bf2(o0, o1);
+        p.y = pack_bf2(o2, o3);
+        *reinterpret_cast<uint2*>(yr + c) = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-place per-head RMSNorm(128) (+ RoPE, rotate-half form) on bf16 x[M, ld], heads at col0 + h*128.
+// 16 lanes per head: lane j holds d = 4j..4j+3 and 64+4j..64+4j+3 (the rotate_half partners).
+__global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, int M, int ld, int col0, int heads,
+                                                            const float* __restrict__ w, float eps,
+                                                            const float* __restrict__ cos_tab,
+                                                            const float* __restrict__ sin_tab, int S) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long unit = gid >> 4;  // (row, head)
+    const int j = threadIdx.x & 15;
+    const long total = (long)M * heads;
+    const bool ok = unit < total;
+    const int row = ok ? (int)(unit / heads) : 0;
+    const int head = ok ? (int)(unit - (long)row * heads) : 0;
+    bf16_t* p = x + (long)row * ld + col0 + head * 128 + j * 4;
+    uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
+    if (ok) {
+        lo = *reinterpret_cast<const uint2*>(p);
+        hi = *reinterpret_cast<const uint2*>(p + 64);
+    }
+    float a[4] = {bf_lo(lo.x), bf_hi(lo.x), bf_lo(lo.y), bf_hi(lo.y)};
+    float b[4] = {bf_lo(hi.x), bf_hi(hi.x), bf_lo(hi.y), bf_hi(hi.y)};
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ss += a[e] * a[e] + b[e] * b[e];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss * (1.f / 128.f) + eps);
+    const float4 wl = *reinterpret_cast<const float4*>(w + j * 4);
+    const float4 wh = *reinterpret_cast<const float4*>(w + 64 + j * 4);
+    a[0] = wl.x * (a[0] * rstd); a[1] = wl.y * (a[1] * rstd); a[2] = wl.z * (a[2] * rstd); a[3] = wl.w * (a[3] * rstd);
+    b[0] = wh.x * (b[0] * rstd); b[1] = wh.y * (b[1] * rstd); b[2] = wh.z * (b[2] * rstd); b[3] = wh.w * (b[3] * rstd);
+    if (cos_tab) {
+        const int pos = row % S;
+        const float4 c = *reinterpret_cast<const float4*>(cos_tab + (long)pos * 64 + j * 4);
+        const float4 s = *reinterpret_cast<const float4*>(sin_tab + (long)pos * 64 + j * 4);
+        const float cc[4] = {c.x, c.y, c.z, c.w}, sn[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo_ = a[e] * cc[e] - b[e] * sn[e];
+            const float hi_ = b[e] * cc[e] + a[e] * sn[e];
+            a[e] = lo_;
+            b[e] = hi_;
+        }
+    }
+    if (ok) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
+        *reinterpret_cast<uint2*>(p + 64) = make_uint2(pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// vt[n][h][d][s] = x[(n*S + s)*ld + col0 + h*128 + d]; pad keys s in [S, s_pad) are written as zero.
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ x, int ld, int col0, int S, int heads,
+                                                          bf16_t* __restrict__ vt, int s_pad) {
+    __shared__ bf16_t tile[64][136];  // +8 pad: 272-B rows
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256, key = c >> 4, ch = c & 15;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (s0 + key < S) v = *reinterpret_cast<const uint4*>(x + ((long)n * S + s0 + key) * ld + col0 + h * 128 + ch * 8);
+        *reinterpret_cast<uint4*>(&tile[key][ch * 8]) = v;
+    }
+    __syncthreads();
+    bf16_t* base = vt + ((long)n * heads + h) * 128 * s_pad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + i * 256, d = c >> 3, kc = c & 7;
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)tile[kc * 8 + 2 * e][d] | ((uint32_t)tile[kc * 8 + 2 * e + 1][d] << 16);
+        if (s0 + kc * 8 < s_pad) *reinterpret_cast<uint4*>(base + (long)d * s_pad + s0 + kc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TimestepEmbedding.timestep_embedding (base.py:225-246): out[m][0:128] = cos(t*1000*f_k), [128:256] = sin(..)
+__global__ void sinusoid_kernel(TVals tv, int n, float* __restrict__ out) {
+    const int m = blockIdx.x, k = threadIdx.x;  // 128 threads
+    if (m >= n) return;
+    const float f = expf(-logf(10000.f) * (float)k / 128.f);
+    const float a = (tv.t[m] * 1000.f) * f;
+    out[m * 256 + k] = cosf(a);
+    out[m * 256 + 128 + k] = sinf(a);
+}
+
+// out[m][n] (+)= sum_k in[m][k] * W[n][k] + b[n]; optional second output silu(value) (own value, not accumulated)
+// one wave per output column n, all Mr <= 16 rows at once (weights streamed exactly once).
+template <int MT>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ in, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ b, float* __restrict__ out,
+                                                           float* __restrict__ out_silu, int Mr, int N, int K,
+                                                           int silu_out, int accumulate) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+    const bf16_t* wr = W + (long)n * K;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        const uint4 wv = *reinterpret_cast<const uint4*>(wr + k0);
+        const float wf[8] = {bf_lo(wv.x), bf_hi(wv.x), bf_lo(wv.y), bf_hi(wv.y), bf_lo(wv.z), bf_hi(wv.z), bf_lo(wv.w), bf_hi(wv.w)};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < Mr) {
+                const float4 x0 = *reinterpret_cast<const float4*>(in + (long)m * K + k0);
+                const float4 x1 = *reinterpret_cast<const float4*>(in + (long)m * K + k0 + 4);
+                acc[m] += wf[0] * x0.x + wf[1] * x0.y + wf[2] * x0.z + wf[3] * x0.w + wf[4] * x1.x + wf[5] * x1.y + wf[6] * x1.z + wf[7] * x1.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = wave_sum(acc[m]);
+    if (lane == 0) {
+        const float bias = b ? b[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            if (m < Mr) {
+                float v = acc[m] + bias;
+                if (out_silu) out_silu[(long)m * N + n] = silu_f(v);
+                if (silu_out) v = silu_f(v);
+                float* o = out + (long)m * N + n;
+                *o = accumulate ? (*o + v) : v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// xin[n][t][0:128] = bf16(ctx[n][t][:]), xin[n][t][128:192] = bf16(x[n][t][:]); rows t in [T, Tpad) are zero.
+__global__ void pack_xin_kernel(const float* __restrict__ x, const float* __restrict__ ctx, bf16_t* __restrict__ xin,
+                                int T, int Tpad, long total /* N*Tpad*48 */) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread = 4 channels
+    if (i >= total) return;
+    const int q = (int)(i % 48);
+    const long row = i / 48;
+    const int t = (int)(row % Tpad);
+    const long n = row / Tpad;
+    const bool is_ctx = q < 32;
+    const float* src = is_ctx ? ctx : x;
+    if (!src) return;  // this part of the row is owned by another call
+    float4 v = make_float4(0, 0, 0, 0);
+    if (t < T) v = is_ctx ? *reinterpret_cast<const float4*>(ctx + (n * T + t) * 128 + q * 4)
+                          : *reinterpret_cast<const float4*>(x + (n * T + t) * 64 + (q - 32) * 4);
+    *reinterpret_cast<uint2*>(xin + row * 192 + q * 4) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(in + i);
+        *reinterpret_cast<uint2*>(out + i) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    } else {
+        for (long j = i; j < n; ++j) out[j] = f2bf(in[j]);
+    }
+}
+
+__global__ void bcast_rows_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    out[i] = in[i % cols];
+}
+
+__global__ void copy_v_kernel(const float* __restrict__ vpad, float* __restrict__ v, int T, int Tpad, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units: N*T*16
+    if (i >= total) return;
+    const int q = (int)(i & 15);
+    const long row = i >> 4;
+    const int t = (int)(row % T);
+    const long n = row / T;
+    *reinterpret_cast<float4*>(v + row * 64 + q * 4) = *reinterpret_cast<const float4*>(vpad + (n * Tpad + t) * 64 + q * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One sampler step after the decoder forward (base.py:1946-1979 + apg_guidance.py:33-56):
+//   diff = cond - uncond; avg = diff + (-0.75) * avg_prev; d = avg * min(1, 2.5/||avg||_T)
+//   (fp64) u = cond/||cond||_T; orth = d - (d.u) u;  v = cond + (g-1) orth;  xt -= v * dt
+// reductions are over the T axis per (item, channel).  grid (B, 4), block 256 = 16 channels x 16 t-slices.
+__global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict__ v, long uncond_off, float* __restrict__ avg,
+                                                        float* __restrict__ xt, bf16_t* __restrict__ xin, int copies, int B,
+                                                        int T, int Tpad, float guidance, float dt, int apply_cfg, int do_cfg,
+                                                        int first) {
+    __shared__ double red[3][16][16];
+    __shared__ double tot[3][16];
+    const int b = blockIdx.x, cl = threadIdx.x & 15, ts = threadIdx.x >> 4;
+    const int c = blockIdx.y * 16 + cl;
+    const float* vc = v + (long)b * Tpad * 64 + c;
+    const float* vu = vc + uncond_off;
+    float* av = avg + (long)b * T * 64 + c;
+    float* x = xt + (long)b * T * 64 + c;
+    const bool guided = do_cfg && apply_cfg;
+    double saa = 0, scc = 0, sac = 0;
+    if (guided) {
+        for (int t = ts; t < T; t += 16) {
+            const float pc = vc[(long)t * 64], pu = vu[(long)t * 64];
+            float a = pc - pu;
+            if (!first) a = a + (-0.75f) * av[(long)t * 64];
+            av[(long)t * 64] = a;
+            saa += (double)a * a;
+            scc += (double)pc * pc;
+            sac += (double)a * pc;
+        }
+        red[0][ts][cl] = saa;
+        red[1][ts][cl] = scc;
+        red[2][ts][cl] = sac;
+        __syncthreads();
+        if (ts < 3) {
+            double s = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += red[ts][i][cl];
+            tot[ts][cl] = s;
+        }
+        __syncthreads();
+    }
+    float scale = 1.f;
+    double inv_nc = 0, dotf = 0;
+    if (guided) {
+        const float norm_a = (float)sqrt(tot[0][cl]);
+        scale = fminf(1.f, 2.5f / norm_a);
+        const double nc = fmax(sqrt(tot[1][cl]), 1e-12);
+        inv_nc = 1.0 / nc;
+        dotf = 0;  // recomputed below from the float-rounded d to follow the reference's cast order
+    }
+    if (guided) {
+        // dot = sum_t (double)(float)(a*scale) * (cond/nc): needs a second reduction because d is rounded to fp32 first
+        double sd = 0;
+        for (int t = ts; t < T; t += 16) {
+            const float d = av[(long)t * 64] * scale;
+            sd += (double)d * ((double)vc[(long)t * 64] * inv_nc);
+        }
+        __syncthreads();
+        red[0][ts][cl] = sd;
+        __syncthreads();
+        if (ts == 0) {
+            double s = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += red[0][i][cl];
+            tot[0][cl] = s;
+        }
+        __syncthreads();
+        dotf = tot[0][cl];
+    }
+    for (int t = ts; t < T; t += 16) {
+        const float pc = vc[(long)t * 64];
+        float vv = pc;
+        if (guided) {
+            const float d = av[(long)t * 64] * scale;
+            const double u = (double)pc * inv_nc;
+            const float orth = (float)((double)d - dotf * u);
+            vv = pc + (guidance - 1.f) * orth;
+        }
+        const float xn = x[(long)t * 64] - vv * dt;
+        x[(long)t * 64] = xn;
+        if (xin) {
+            const bf16_t xb = f2bf(xn);
+            for (int cp = 0; cp < copies; ++cp) xin[((long)(cp * B + b) * Tpad + t) * 192 + 128 + c] = xb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void absmax_kernel(const float* __restrict__ wav, long per_item, float* __restrict__ peaks) {
+    const int b = blockIdx.y;
+    const float* p = wav + (long)b * per_item;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_item; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(peaks + b), __float_as_uint(m));  // m >= 0
+}
+__global__ void peak_scale_kernel(float* __restrict__ wav, long per_item, int B, const float* __restrict__ peaks) {
+    bool any = false;
+    for (int i = 0; i < B; ++i) any |= peaks[i] > 1.f;
+    if (!any) return;
+    const int b = blockIdx.y;
+    const float inv = 1.f / fmaxf(peaks[b], 1.f);
+    float* p = wav + (long)b * per_item;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_item; i += (long)gridDim.x * blockDim.x) p[i] *= inv;
+}
+__global__ void latent_check_kernel(const float* __restrict__ x, long n, int* __restrict__ flags) {
+    bool bad = false, nz = false;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        bad |= !(fabsf(v) <= 3.0e38f);
+        nz |= (v != 0.f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(flags + 1, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename SRC>
+__device__ __forceinline__ float ldsrc(const SRC* p, long i);
+template <>
+__device__ __forceinline__ float ldsrc<float>(const float* p, long i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ldsrc<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
+
+template <typename SRC>
+__global__ void pack_kernel(const SRC* __restrict__ src, void* __restrict__ dst, int dst_is_bf16, int mode, long rows, long cols,
+                            long dst_ld, long dst_row0, int p0, int p1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols, c = i - r * cols;
+    long di;
+    if (mode == PACK_ROWS) {
+        di = (dst_row0 + r) * dst_ld + c;
+    } else if (mode == PACK_ROWS_IL32) {
+        di = (dst_row0 + (r >> 5) * 64 + p0 * 32 + (r & 31)) * dst_ld + c;
+    } else if (mode == PACK_CONV_IN) {  // src [O][C][P] -> dst[o][p*C + c]
+        const long cc = c / p1, pp = c - cc * p1;
+        di = (dst_row0 + r) * dst_ld + pp * p0 + cc;
+    } else {  // PACK_CONVT_OUT: src [I][C][P] -> dst[p*C + c][i]
+        const long cc = c / p1, pp = c - cc * p1;
+        di = (dst_row0 + pp * p0 + cc) * dst_ld + r;
+    }
+    const float v = ldsrc<SRC>(src, i);
+    if (dst_is_bf16) reinterpret_cast<bf16_t*>(dst)[di] = f2bf(v);
+    else reinterpret_cast<float*>(dst)[di] = v;
+}
+
+inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, float eps, const float* sc1,
+                       const float* sc2, const float* sh1, const float* sh2, int stride, int rows_per_seq, hipStream_t s) {
+    ACE_CHECK(D % 4 == 0, "rmsnorm: D % 4");
+    ACE_CHECK(!sc1 || (sc2 && sh1 && sh2 && rows_per_seq > 0), "rmsnorm: modulation needs all four vectors");
+    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride,
+                       rows_per_seq > 0 ? rows_per_seq : 1);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const float* w, float eps, const float* cos_tab,
+                         const float* sin_tab, int S, hipStream_t s) {
+    const long threads = (long)M * heads * 16;
+    hipLaunchKernelGGL(headnorm_rope_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, x, M, ld, col0, heads, w, eps,
+                       cos_tab, sin_tab, S > 0 ? S : 1);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_transpose_v(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vt, int s_pad, hipStream_t s) {
+    ACE_CHECK(s_pad % 64 == 0 && s_pad >= S, "transpose_v: s_pad");
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(s_pad / 64, heads, N), dim3(256), 0, s, x, ld, col0, S, heads, vt, s_pad);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Qwen3RotaryEmbedding (default rope): inv_freq = theta^(-2k/128) in fp32, angle = pos * inv_freq in fp32.
+int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s) {
+    std::vector<float> c((size_t)S * 64), sn((size_t)S * 64);
+    float inv[64];
+    for (int k = 0; k < 64; ++k) inv[k] = 1.0f / powf(theta, (float)(2 * k) / 128.0f);
+    for (int p = 0; p < S; ++p)
+        for (int k = 0; k < 64; ++k) {
+            const float a = (float)p * inv[k];
+            c[(size_t)p * 64 + k] = (float)cos((double)a);
+            sn[(size_t)p * 64 + k] = (float)sin((double)a);
+        }
+    ACE_HIP(hipMemcpyAsync(cos_tab, c.data(), c.size() * 4, hipMemcpyHostToDevice, s));
+    ACE_HIP(hipMemcpyAsync(sin_tab, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, s));
+    ACE_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int launch_sinusoid(const TVals& tv, int n, float* out, hipStream_t s) {
+    ACE_CHECK(n <= 64, "sinusoid: n <= 64");
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(n), dim3(128), 0, s, tv, n, out);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_small_linear_ex(const float* in, const bf16_t* W, const float* b, float* out, float* out_silu, int Mr, int N, int K,
+                           int silu_out, int accumulate, hipStream_t s) {
+    ACE_CHECK(K % 8 == 0, "small_linear: K % 8");
+    for (int m0 = 0; m0 < Mr; m0 += 16) {
+        const int mr = Mr - m0 < 16 ? Mr - m0 : 16;
+        hipLaunchKernelGGL(small_linear_kernel<16>, dim3((N + 3) / 4), dim3(256), 0, s, in + (long)m0 * K, W, b, out + (long)m0 * N,
+                           out_silu ? out_silu + (long)m0 * N : nullptr, mr, N, K, silu_out, accumulate);
+    }
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_small_linear(const float* in, const bf16_t* W, const float* b, float* out, int Mr, int N, int K, int silu_in,
+                        int silu_out, int accumulate, hipStream_t s) {
+    ACE_CHECK(!silu_in, "small_linear: silu_in is provided by the producer's second output");
+    return launch_small_linear_ex(in, W, b, out, nullptr, Mr, N, K, silu_out, accumulate, s);
+}
+
+int launch_pack_xin(const float* x, const float* ctx, bf16_t* xin, int N, int T, int Tpad, hipStream_t s) {
+    const long total = (long)N * Tpad * 48;
+    hipLaunchKernelGGL(pack_xin_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, ctx, xin, T, Tpad, total);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+// latent part only, replicated `copies` times along the sequence axis (CFG doubling, base.py:1929)
+int launch_set_xin_latent(const float* xt, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s) {
+    for (int cp = 0; cp < copies; ++cp) {
+        int rc = launch_pack_xin(xt, nullptr, xin + (long)cp * B * Tpad * 192, B, T, Tpad, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+int launch_set_xin_ctx(const float* ctx, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s) {
+    for (int cp = 0; cp < copies; ++cp) {
+        int rc = launch_pack_xin(nullptr, ctx, xin + (long)cp * B * Tpad * 192, B, T, Tpad, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, s, in, out, n);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_bcast_rows(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(blocks_for((long)rows * cols, 256)), dim3(256), 0, s, in, out, rows, cols);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_copy_v(const float* vpad, float* v, int N, int T, int Tpad, hipStream_t s) {
+    const long total = (long)N * T * 16;
+    hipLaunchKernelGGL(copy_v_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, vpad, v, T, Tpad, total);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, bf16_t* xin, int copies, int B, int T, int Tpad,
+                     float guidance, float dt, int apply_cfg, int do_cfg, int first, hipStream_t s) {
+    hipLaunchKernelGGL(apg_euler_kernel, dim3(B, 4), dim3(256), 0, s, v, uncond_offset, avg, xt, xin, copies, B, T, Tpad, guidance,
+                       dt, apply_cfg, do_cfg, first);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_peak_normalize(float* wav, int B, long per_item, float* scratch, hipStream_t s) {
+    ACE_HIP(hipMemsetAsync(scratch, 0, sizeof(float) * B, s));
+    const int gx = (int)((per_item + 256L * 16 - 1) / (256L * 16));
+    const int g = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(absmax_kernel, dim3(g, B), dim3(256), 0, s, wav, per_item, scratch);
+    hipLaunchKernelGGL(peak_scale_kernel, dim3(g, B), dim3(256), 0, s, wav, per_item, B, scratch);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_latent_check(const float* x, long n, int* flags_dev, hipStream_t s) {
+    ACE_HIP(hipMemsetAsync(flags_dev, 0, 2 * sizeof(int), s));
+    const int g = (int)((n + 255) / 256) > 1024 ? 1024 : (int)((n + 255) / 256);
+    hipLaunchKernelGGL(latent_check_kernel, dim3(g < 1 ? 1 : g), dim3(256), 0, s, x, n, flags_dev);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pack(const void* src, int src_dtype, void* dst, int dst_is_bf16, int mode, long rows, long cols, long dst_ld,
+                long dst_row0, int p0, int p1, hipStream_t s) {
+    const long n = rows * cols;
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const float*)src, dst, dst_is_bf16, mode,
+                           rows, cols, dst_ld, dst_row0, p0, p1);
+    else
+        hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks_for(n, 256)), dim3(256), 0, s, (const bf16_t*)src, dst, dst_is_bf16, mode,
+                           rows, cols, dst_ld, dst_row0, p0, p1);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ace355

@@ -1,0 +1,192 @@
+// gemm.hip - bf16 MFMA GEMM  C[M,N] = A[M,K] * W[N,K]^T  (fp32 accumulate) with the DiT's fused epilogues.
+//
+// Replaces the nn.Linear contractions of AceStepDiTLayer (q/k/v/o_proj, base.py:279-282; Qwen3MLP gate/up/down,
+// base.py:469), proj_in/proj_out as GEMMs (base.py:1264-1274, 1287-1297) and condition_embedder (base.py:1282).
+//
+// gfx950 design: 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32x16 bf16
+// accumulators (64 acc VGPRs).  A and W tiles are K-contiguous, staged global -> registers -> LDS (16-B
+// vectors), double-buffered in LDS with one barrier per K-step; the LDS image is XOR-swizzled at 16-B
+// granularity (slot ^= (row>>1)&7) so every ds_read_b128 fragment read is bank-conflict free.
+// Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
+#include "common.h"
+
+namespace ace355 {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                       int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                       GemmEpilogue ep, int tiles_n, int nwg) {
+    __shared__ __attribute__((aligned(16))) char smem[65536];  // 2 stages x (A 16 KB | W 16 KB)
+
+    // XCD-aware bijective remap: block b runs on XCD b % 8; give XCD x a contiguous tile range.
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // global -> register staging assignment: 4 x 16-B chunks of A and of W per thread per K-step.
+    // chunk c = tid + i*256 -> row = (tid>>3) + 32*i, slot = tid&7; the swizzle term (row>>1)&7 is i-invariant.
+    const int srow = tid >> 3, sslot = tid & 7;
+    const int st_off0 = lds_off(srow, sslot);
+    const bf16_t* a_src0 = A + (long)min(m0 + srow, M - 1) * lda + sslot * 8;
+    const bf16_t* a_src1 = A + (long)min(m0 + srow + 32, M - 1) * lda + sslot * 8;
+    const bf16_t* a_src2 = A + (long)min(m0 + srow + 64, M - 1) * lda + sslot * 8;
+    const bf16_t* a_src3 = A + (long)min(m0 + srow + 96, M - 1) * lda + sslot * 8;
+    const bf16_t* w_src0 = W + (long)min(n0 + srow, N - 1) * ldw + sslot * 8;
+    const bf16_t* w_src1 = W + (long)min(n0 + srow + 32, N - 1) * ldw + sslot * 8;
+    const bf16_t* w_src2 = W + (long)min(n0 + srow + 64, N - 1) * ldw + sslot * 8;
+    const bf16_t* w_src3 = W + (long)min(n0 + srow + 96, N - 1) * ldw + sslot * 8;
+#define LOAD_TILE(koff)                                            \
+    ra0 = *reinterpret_cast<const uint4*>(a_src0 + (koff));        \
+    ra1 = *reinterpret_cast<const uint4*>(a_src1 + (koff));        \
+    ra2 = *reinterpret_cast<const uint4*>(a_src2 + (koff));        \
+    ra3 = *reinterpret_cast<const uint4*>(a_src3 + (koff));        \
+    rw0 = *reinterpret_cast<const uint4*>(w_src0 + (koff));        \
+    rw1 = *reinterpret_cast<const uint4*>(w_src1 + (koff));        \
+    rw2 = *reinterpret_cast<const uint4*>(w_src2 + (koff));        \
+    rw3 = *reinterpret_cast<const uint4*>(w_src3 + (koff));
+#define STORE_TILE(base)                                                    \
+    *reinterpret_cast<uint4*>((base) + st_off0) = ra0;                      \
+    *reinterpret_cast<uint4*>((base) + st_off0 + 4096) = ra1;               \
+    *reinterpret_cast<uint4*>((base) + st_off0 + 8192) = ra2;               \
+    *reinterpret_cast<uint4*>((base) + st_off0 + 12288) = ra3;              \
+    *reinterpret_cast<uint4*>((base) + 16384 + st_off0) = rw0;              \
+    *reinterpret_cast<uint4*>((base) + 16384 + st_off0 + 4096) = rw1;       \
+    *reinterpret_cast<uint4*>((base) + 16384 + st_off0 + 8192) = rw2;       \
+    *reinterpret_cast<uint4*>((base) + 16384 + st_off0 + 12288) = rw3;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    LOAD_TILE(0)
+    STORE_TILE(smem)
+    __syncthreads();
+
+    const int nk = K / BK;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1) < nk;
+        if (more) { LOAD_TILE((kt + 1) * BK) }
+        const char* As = smem + (kt & 1) * 32768;
+        const char* Ws = As + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(wm * 64 + i * 32 + frow, kk * 2 + fhalf)));
+                fw[i] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * 64 + i * 32 + frow, kk * 2 + fhalf)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
+        }
+        if (more) {
+            char* Ad = smem + ((kt + 1) & 1) * 32768;
+            STORE_TILE(Ad)
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // lane holds column n = .. + (lane&31) and 16 rows m = .. + mfma_row(r, lane) of each 32x32 tile
+    if (MODE == 3) {
+        // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up of the same column
+        bf16_t* out = reinterpret_cast<bf16_t*>(Cv);
+        const int col = ((n0 + wn * 64) >> 1) + frow;
+        const bool nok = (n0 + wn * 64 + 32 + frow) < N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + mfma_row(r, lane);
+                if (m < M && nok) {
+                    const float g = acc[i][0][r], u = acc[i][1][r];
+                    out[(long)m * ldc + col] = f2bf(silu_f(g) * u);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + frow;
+        if (n >= N) continue;
+        float bias = 0.f, g1 = 1.f;
+        if (MODE <= 1 && ep.bias) bias = ep.bias[n];
+        if (MODE == 2 && ep.g1) g1 = ep.g1[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm * 64 + i * 32 + 4 * fhalf;
+            int seq0 = 0, rem0 = 0;
+            if (MODE == 2 && ep.g1) {
+                seq0 = mb / ep.rows_per_seq;
+                rem0 = mb - seq0 * ep.rows_per_seq;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                const int m = mb + off;
+                if (m >= M) continue;
+                const float v = acc[i][j][r];
+                if (MODE == 0) {
+                    reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + bias);
+                } else if (MODE == 1) {
+                    reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + bias;
+                } else {
+                    float gate = 1.f;
+                    if (ep.g1) {
+                        int seq = seq0, rem = rem0 + off;
+                        while (rem >= ep.rows_per_seq) { rem -= ep.rows_per_seq; ++seq; }
+                        gate = g1 + ep.g2[(long)seq * ep.g2_stride + n];
+                    }
+                    float* h = reinterpret_cast<float*>(Cv) + (long)m * ldc + n;
+                    *h = *h + gate * v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
+                const GemmEpilogue& ep, hipStream_t s) {
+    ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
+    ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");
+    ACE_CHECK((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-B rows)");
+    ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
+    ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int nwg = tiles_m * tiles_n;
+    dim3 grid(nwg), block(256);
+    switch (ep.mode) {
+        case 0: hipLaunchKernelGGL(gemm_kernel<0>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 1: hipLaunchKernelGGL(gemm_kernel<1>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 2: hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 3: hipLaunchKernelGGL(gemm_kernel<3>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        default: ACE_CHECK(false, "gemm: bad epilogue mode");
+    }
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace ace355

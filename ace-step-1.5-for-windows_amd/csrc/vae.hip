@@ -1,0 +1,443 @@
+// vae.hip - the Oobleck decoder handle behind ace355.h: weight-norm fusion + packing at load time, whole-sequence
+// decode as a chain of conv_kernel launches (conv.hip).  Architecture per acestep/models/mlx/vae_model.py:190-230.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ace355.h"
+#include "common.h"
+
+using namespace ace355;
+
+namespace {
+
+struct ConvW {
+    bf16_t* w = nullptr;   // [N][taps][Cin]
+    float* bias = nullptr; // [N] or null
+    int N = 0, taps = 0, Cin = 0;
+};
+struct SnakeP {
+    float* ea = nullptr;  // exp(alpha)
+    float* ib = nullptr;  // 1 / (exp(beta) + 1e-9)
+};
+struct ResUnitW {
+    SnakeP s1, s2;
+    ConvW c1, c2;
+    int dil = 1;
+};
+struct BlockW {
+    SnakeP s1;
+    ConvW ct;
+    int stride = 1, pad = 0, cin = 0, cout = 0;
+    ResUnitW ru[3];
+};
+struct RawT {
+    float* p = nullptr;
+    long n = 0;
+};
+
+// ||v_row||_2 per row (one wave per row)
+__global__ void rownorm_kernel(const float* __restrict__ v, long cols, float* __restrict__ out, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    double s = 0;
+    for (long c = lane; c < cols; c += 64) {
+        const double x = v[(long)row * cols + c];
+        s += x * x;
+    }
+    s = wave_sum_d(s);
+    if (lane == 0) out[row] = (float)sqrt(s);
+}
+// Conv1d weight_v [Cout][Cin][K] (+g, norm) -> w[co][k][ci] bf16
+__global__ void pack_conv_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ nrm,
+                                 bf16_t* __restrict__ w, int Cout, int Cin, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Cout * Cin * K) return;
+    const int k = (int)(i % K);
+    const long t = i / K;
+    const int ci = (int)(t % Cin), co = (int)(t / Cin);
+    float x = v[i];
+    if (g) x = g[co] * x / (nrm[co] + 1e-9f);
+    w[((long)co * K + k) * Cin + ci] = f2bf(x);
+}
+// ConvTranspose1d weight_v [Cin][Cout][2s] (+g over dim 0) -> w[r*Cout + co][tap][ci]; tap0 <-> k = r + s (x[i0-1]), tap1 <-> k = r (x[i0])
+__global__ void pack_convt_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ nrm,
+                                  bf16_t* __restrict__ w, int Cin, int Cout, int s) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = 2 * s;
+    if (i >= (long)Cin * Cout * K) return;
+    const int k = (int)(i % K);
+    const long t = i / K;
+    const int co = (int)(t % Cout), ci = (int)(t / Cout);
+    float x = v[i];
+    if (g) x = g[ci] * x / (nrm[ci] + 1e-9f);
+    const int r = k % s, tap = k >= s ? 0 : 1;
+    w[(((long)r * Cout + co) * 2 + tap) * Cin + ci] = f2bf(x);
+}
+__global__ void snake_prep_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ ea,
+                                  float* __restrict__ ib, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    ea[i] = expf(alpha[i]);
+    ib[i] = 1.0f / (expf(beta[i]) + 1e-9f);
+}
+__global__ void tile_bias_kernel(const float* __restrict__ b, float* __restrict__ out, int C, int reps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * reps) return;
+    out[i] = b[i % C];
+}
+__global__ void cvt_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bf2f(in[i]);
+}
+
+}  // namespace
+
+struct ace355_vae {
+    ace355_vae_config cfg;
+    int hop = 1;
+    std::map<std::string, RawT> raw;
+    std::vector<void*> allocs;
+    ConvW conv1, conv2;
+    SnakeP s_out;
+    std::vector<BlockW> blocks;
+    bool finalized = false;
+    // activations
+    bf16_t* buf[3] = {nullptr, nullptr, nullptr};
+    size_t buf_elems = 0;
+    bf16_t* zin = nullptr;
+    size_t zin_elems = 0;
+    float* scratch = nullptr;
+    // profile
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double flops = 0;
+    long launches = 0;
+};
+
+namespace {
+
+template <typename T>
+int valloc(ace355_vae* h, T** p, size_t n) {
+    void* q = nullptr;
+    ACE_HIP(hipMalloc(&q, n * sizeof(T) + 256));
+    h->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+
+const RawT* find(ace355_vae* h, const std::string& k) {
+    auto it = h->raw.find(k);
+    return it == h->raw.end() ? nullptr : &it->second;
+}
+
+int need(ace355_vae* h, const std::string& k, long n, const RawT** out) {
+    const RawT* r = find(h, k);
+    if (!r) { set_error("vae_finalize: missing tensor '" + k + "'"); return ACE355_ERR_STATE; }
+    if (r->n != n) { set_error("vae_finalize: wrong size for '" + k + "': got " + std::to_string(r->n) + ", expected " + std::to_string(n)); return ACE355_ERR_INVALID; }
+    *out = r;
+    return 0;
+}
+
+// Conv1d: base.weight_g [Cout,1,1], base.weight_v [Cout,Cin,K] (or fused base.weight), base.bias [Cout]
+int build_conv(ace355_vae* h, const std::string& base, int Cout, int Cin, int K, bool has_bias, ConvW* c) {
+    const RawT *v = nullptr, *g = nullptr, *b = nullptr;
+    int rc;
+    const bool fused = find(h, base + ".weight") != nullptr;
+    if (fused) {
+        if ((rc = need(h, base + ".weight", (long)Cout * Cin * K, &v))) return rc;
+    } else {
+        if ((rc = need(h, base + ".weight_v", (long)Cout * Cin * K, &v))) return rc;
+        if ((rc = need(h, base + ".weight_g", Cout, &g))) return rc;
+    }
+    if (has_bias && (rc = need(h, base + ".bias", Cout, &b))) return rc;
+    c->N = Cout; c->taps = K; c->Cin = Cin;
+    if ((rc = valloc(h, &c->w, (size_t)Cout * Cin * K))) return rc;
+    float* nrm = nullptr;
+    if (g) {
+        if ((rc = valloc(h, &nrm, (size_t)Cout))) return rc;
+        hipLaunchKernelGGL(rownorm_kernel, dim3((Cout + 3) / 4), dim3(256), 0, 0, v->p, (long)Cin * K, nrm, Cout);
+    }
+    const long n = (long)Cout * Cin * K;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v->p, g ? g->p : nullptr, nrm, c->w, Cout, Cin, K);
+    c->bias = has_bias ? b->p : nullptr;
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int build_convt(ace355_vae* h, const std::string& base, int Cin, int Cout, int s, ConvW* c) {
+    const RawT *v = nullptr, *g = nullptr, *b = nullptr;
+    int rc;
+    const int K = 2 * s;
+    const bool fused = find(h, base + ".weight") != nullptr;
+    if (fused) {
+        if ((rc = need(h, base + ".weight", (long)Cin * Cout * K, &v))) return rc;
+    } else {
+        if ((rc = need(h, base + ".weight_v", (long)Cin * Cout * K, &v))) return rc;
+        if ((rc = need(h, base + ".weight_g", Cin, &g))) return rc;
+    }
+    if ((rc = need(h, base + ".bias", Cout, &b))) return rc;
+    c->N = s * Cout; c->taps = 2; c->Cin = Cin;
+    if ((rc = valloc(h, &c->w, (size_t)Cin * Cout * K))) return rc;
+    float* nrm = nullptr;
+    if (g) {
+        if ((rc = valloc(h, &nrm, (size_t)Cin))) return rc;
+        hipLaunchKernelGGL(rownorm_kernel, dim3((Cin + 3) / 4), dim3(256), 0, 0, v->p, (long)Cout * K, nrm, Cin);
+    }
+    const long n = (long)Cin * Cout * K;
+    hipLaunchKernelGGL(pack_convt_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v->p, g ? g->p : nullptr, nrm, c->w, Cin, Cout, s);
+    if ((rc = valloc(h, &c->bias, (size_t)s * Cout))) return rc;
+    hipLaunchKernelGGL(tile_bias_kernel, dim3((s * Cout + 255) / 256), dim3(256), 0, 0, b->p, c->bias, Cout, s);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int build_snake(ace355_vae* h, const std::string& base, int C, SnakeP* sp) {
+    const RawT *a = nullptr, *b = nullptr;
+    int rc;
+    if ((rc = need(h, base + ".alpha", C, &a))) return rc;
+    if ((rc = need(h, base + ".beta", C, &b))) return rc;
+    if ((rc = valloc(h, &sp->ea, (size_t)C))) return rc;
+    if ((rc = valloc(h, &sp->ib, (size_t)C))) return rc;
+    hipLaunchKernelGGL(snake_prep_kernel, dim3((C + 255) / 256), dim3(256), 0, 0, a->p, b->p, sp->ea, sp->ib, C);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int run_conv(ace355_vae* h, const ConvArgs& a, hipStream_t s) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profile) {
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, s);
+        h->flops += 2.0 * a.B * (double)a.M * (a.out_mode == 1 ? a.n_real : a.N) * a.taps * a.Cin;
+        h->launches++;
+    }
+    int rc = launch_conv(a, s);
+    if (h->profile) {
+        hipEventRecord(e1, s);
+        h->ev.push_back({e0, e1});
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ace355_vae_create(const ace355_vae_config* cfg, ace355_vae** out) {
+    ACE_CHECK(cfg && out, "vae_create: null argument");
+    ACE_CHECK(cfg->num_blocks > 0 && cfg->num_blocks <= ACE355_MAX_BLOCKS, "vae_create: num_blocks");
+    ACE_CHECK(cfg->decoder_input_channels % 64 == 0 && cfg->decoder_channels % 64 == 0, "vae_create: channels must be multiples of 64");
+    ACE_CHECK(cfg->audio_channels >= 1 && cfg->audio_channels <= 32, "vae_create: audio_channels");
+    ace355_vae* h = new ace355_vae();
+    h->cfg = *cfg;
+    h->hop = 1;
+    for (int i = 0; i < cfg->num_blocks; ++i) {
+        ACE_CHECK(cfg->upsampling_ratios[i] >= 1 && cfg->channel_multiples[i] >= 1, "vae_create: ratios/multiples");
+        h->hop *= cfg->upsampling_ratios[i];
+    }
+    *out = h;
+    return ACE355_OK;
+}
+
+void ace355_vae_destroy(ace355_vae* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    for (auto& kv : h->raw) if (kv.second.p) hipFree(kv.second.p);
+    for (void* p : h->allocs) hipFree(p);
+    for (int i = 0; i < 3; ++i) if (h->buf[i]) hipFree(h->buf[i]);
+    if (h->zin) hipFree(h->zin);
+    if (h->scratch) hipFree(h->scratch);
+    for (auto& e : h->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete h;
+}
+
+int ace355_vae_load_tensor(ace355_vae* h, const char* name, const void* data, int dtype, int64_t numel, int is_device) {
+    ACE_CHECK(h && name && data && numel > 0, "vae_load_tensor: null/empty argument");
+    ACE_CHECK(dtype == ACE355_DTYPE_F32 || dtype == ACE355_DTYPE_BF16, "vae_load_tensor: dtype");
+    const std::string key(name);
+    if (key.rfind("decoder.", 0) != 0) { set_error("vae_load_tensor: unknown tensor name '" + key + "' (decoder.* expected)"); return ACE355_ERR_INVALID; }
+    RawT& r = h->raw[key];
+    if (r.p) { hipFree(r.p); r.p = nullptr; }
+    ACE_HIP(hipMalloc((void**)&r.p, (size_t)numel * 4 + 256));
+    r.n = numel;
+    if (dtype == ACE355_DTYPE_F32) {
+        ACE_HIP(hipMemcpy(r.p, data, (size_t)numel * 4, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    } else {
+        bf16_t* tmp = nullptr;
+        ACE_HIP(hipMalloc((void**)&tmp, (size_t)numel * 2 + 256));
+        ACE_HIP(hipMemcpy(tmp, data, (size_t)numel * 2, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cvt_bf16_f32_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, 0, tmp, r.p, (long)numel);
+        ACE_HIP(hipDeviceSynchronize());
+        hipFree(tmp);
+    }
+    h->finalized = false;
+    return ACE355_OK;
+}
+
+int ace355_vae_finalize(ace355_vae* h) {
+    ACE_CHECK(h, "vae_finalize: null handle");
+    const ace355_vae_config& c = h->cfg;
+    const int nb = c.num_blocks;
+    int cm[ACE355_MAX_BLOCKS + 1];
+    cm[0] = 1;
+    for (int i = 0; i < nb; ++i) cm[i + 1] = c.channel_multiples[i];
+    int rc;
+    const int C0 = c.decoder_channels * cm[nb];
+    if ((rc = build_conv(h, "decoder.conv1", C0, c.decoder_input_channels, 7, true, &h->conv1))) return rc;
+    h->blocks.assign(nb, BlockW());
+    for (int i = 0; i < nb; ++i) {
+        BlockW& B = h->blocks[i];
+        B.cin = c.decoder_channels * cm[nb - i];
+        B.cout = c.decoder_channels * cm[nb - i - 1];
+        B.stride = c.upsampling_ratios[i];
+        B.pad = (B.stride + 1) / 2;
+        ACE_CHECK(B.cin % 64 == 0 && B.cout % 64 == 0, "vae_finalize: block channels must be multiples of 64");
+        const std::string p = "decoder.block." + std::to_string(i);
+        if ((rc = build_snake(h, p + ".snake1", B.cin, &B.s1))) return rc;
+        if ((rc = build_convt(h, p + ".conv_t1", B.cin, B.cout, B.stride, &B.ct))) return rc;
+        const int dils[3] = {1, 3, 9};
+        for (int j = 0; j < 3; ++j) {
+            ResUnitW& R = B.ru[j];
+            R.dil = dils[j];
+            const std::string r = p + ".res_unit" + std::to_string(j + 1);
+            if ((rc = build_snake(h, r + ".snake1", B.cout, &R.s1))) return rc;
+            if ((rc = build_conv(h, r + ".conv1", B.cout, B.cout, 7, true, &R.c1))) return rc;
+            if ((rc = build_snake(h, r + ".snake2", B.cout, &R.s2))) return rc;
+            if ((rc = build_conv(h, r + ".conv2", B.cout, B.cout, 1, true, &R.c2))) return rc;
+        }
+    }
+    if ((rc = build_snake(h, "decoder.snake1", c.decoder_channels, &h->s_out))) return rc;
+    if ((rc = build_conv(h, "decoder.conv2", c.audio_channels, c.decoder_channels, 7, false, &h->conv2))) return rc;
+    ACE_HIP(hipDeviceSynchronize());
+    // raw weight_v / weight_g copies are no longer needed (biases are still referenced)
+    for (auto& kv : h->raw) {
+        const std::string& k = kv.first;
+        const bool keep = k.size() > 5 && k.compare(k.size() - 5, 5, ".bias") == 0;
+        if (!keep && kv.second.p) { hipFree(kv.second.p); kv.second.p = nullptr; }
+    }
+    if (!h->scratch) ACE_HIP(hipMalloc((void**)&h->scratch, 1024));
+    h->finalized = true;
+    return ACE355_OK;
+}
+
+int ace355_vae_hop(const ace355_vae* h) { return h ? h->hop : 0; }
+
+int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream) {
+    ACE_CHECK(h && z_dev && wav_out_dev, "vae_decode: null argument");
+    if (!h->finalized) { set_error("vae_decode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && T > 0, "vae_decode: empty problem");
+    hipStream_t s = (hipStream_t)stream;
+    const ace355_vae_config& c = h->cfg;
+    // largest activation: max over stages of L*C
+    size_t need_elems = (size_t)T * h->conv1.N;
+    {
+        long L = T;
+        for (const BlockW& Bk : h->blocks) {
+            L = (L - 1) * Bk.stride - 2 * Bk.pad + 2 * Bk.stride;
+            need_elems = std::max(need_elems, (size_t)L * Bk.cout);
+        }
+    }
+    need_elems *= (size_t)B;
+    if (need_elems > h->buf_elems) {
+        ACE_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < 3; ++i) {
+            if (h->buf[i]) hipFree(h->buf[i]);
+            h->buf[i] = nullptr;
+            ACE_HIP(hipMalloc((void**)&h->buf[i], need_elems * 2 + 256));
+        }
+        h->buf_elems = need_elems;
+    }
+    const size_t zel = (size_t)B * T * c.decoder_input_channels;
+    if (zel > h->zin_elems) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->zin) hipFree(h->zin);
+        ACE_HIP(hipMalloc((void**)&h->zin, zel * 2 + 256));
+        h->zin_elems = zel;
+    }
+    int rc = launch_ncl_to_nlc(z_dev, h->zin, B, c.decoder_input_channels, T, s);
+    if (rc) return rc;
+
+    bf16_t *cur = h->buf[0], *nxt = h->buf[1], *tmp = h->buf[2];
+    long L = T;
+    ConvArgs a{};
+    // conv1: k7, no snake (vae_model.py:224)
+    a = ConvArgs{};
+    a.x = h->zin; a.x_batch_stride = (long)T * c.decoder_input_channels; a.L_in = T; a.Cin = c.decoder_input_channels;
+    a.w = h->conv1.w; a.bias = h->conv1.bias;
+    a.y = cur; a.y_batch_stride = (long)T * h->conv1.N;
+    a.B = B; a.M = T; a.N = h->conv1.N; a.taps = 7; a.dil = 1; a.center = 3;
+    a.y_shift = 0; a.y_valid = (long)T * h->conv1.N; a.out_mode = 0;
+    if ((rc = run_conv(h, a, s))) return rc;
+
+    for (const BlockW& Bk : h->blocks) {
+        const long Lout = (L - 1) * Bk.stride - 2 * Bk.pad + 2 * Bk.stride;
+        // snake -> ConvTranspose1d as the 2-tap polyphase GEMM (vae_model.py:136-137)
+        a = ConvArgs{};
+        a.x = cur; a.x_batch_stride = L * Bk.cin; a.L_in = (int)L; a.Cin = Bk.cin;
+        a.w = Bk.ct.w; a.bias = Bk.ct.bias; a.alpha = Bk.s1.ea; a.beta = Bk.s1.ib;
+        a.y = nxt; a.y_batch_stride = Lout * Bk.cout;
+        a.B = B; a.M = (int)L + 1; a.N = Bk.ct.N; a.taps = 2; a.dil = 1; a.center = 1;
+        a.y_shift = -(long)Bk.pad * Bk.cout; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
+        if ((rc = run_conv(h, a, s))) return rc;
+        for (int j = 0; j < 3; ++j) {
+            const ResUnitW& R = Bk.ru[j];
+            // snake1 -> conv k7 dilated (vae_model.py:79)
+            a = ConvArgs{};
+            a.x = nxt; a.x_batch_stride = Lout * Bk.cout; a.L_in = (int)Lout; a.Cin = Bk.cout;
+            a.w = R.c1.w; a.bias = R.c1.bias; a.alpha = R.s1.ea; a.beta = R.s1.ib;
+            a.y = tmp; a.y_batch_stride = Lout * Bk.cout;
+            a.B = B; a.M = (int)Lout; a.N = Bk.cout; a.taps = 7; a.dil = R.dil; a.center = 3;
+            a.y_shift = 0; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
+            if ((rc = run_conv(h, a, s))) return rc;
+            // snake2 -> conv k1, + residual, in place on the block state (vae_model.py:80-87)
+            a = ConvArgs{};
+            a.x = tmp; a.x_batch_stride = Lout * Bk.cout; a.L_in = (int)Lout; a.Cin = Bk.cout;
+            a.w = R.c2.w; a.bias = R.c2.bias; a.alpha = R.s2.ea; a.beta = R.s2.ib;
+            a.res = nxt; a.res_batch_stride = Lout * Bk.cout;
+            a.y = nxt; a.y_batch_stride = Lout * Bk.cout;
+            a.B = B; a.M = (int)Lout; a.N = Bk.cout; a.taps = 1; a.dil = 1; a.center = 0;
+            a.y_shift = 0; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
+            if ((rc = run_conv(h, a, s))) return rc;
+        }
+        std::swap(cur, nxt);
+        L = Lout;
+    }
+    // snake -> conv k7 -> [B, audio, L] fp32 (vae_model.py:228-229)
+    a = ConvArgs{};
+    a.x = cur; a.x_batch_stride = L * c.decoder_channels; a.L_in = (int)L; a.Cin = c.decoder_channels;
+    a.w = h->conv2.w; a.bias = nullptr; a.alpha = h->s_out.ea; a.beta = h->s_out.ib;
+    a.y = wav_out_dev; a.y_batch_stride = L * c.audio_channels;
+    a.B = B; a.M = (int)L; a.N = c.audio_channels; a.taps = 7; a.dil = 1; a.center = 3;
+    a.out_mode = 1; a.n_real = c.audio_channels;
+    return run_conv(h, a, s);
+}
+
+int ace355_vae_set_profile(ace355_vae* h, int enable) {
+    ACE_CHECK(h, "vae_set_profile: null handle");
+    hipDeviceSynchronize();
+    for (auto& e : h->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    h->ev.clear();
+    h->flops = 0;
+    h->launches = 0;
+    h->profile = enable != 0;
+    return ACE355_OK;
+}
+
+int ace355_vae_get_profile(ace355_vae* h, double* conv_ms, double* conv_flops, int64_t* conv_launches) {
+    ACE_CHECK(h, "vae_get_profile: null handle");
+    ACE_HIP(hipDeviceSynchronize());
+    double g = 0;
+    float ms;
+    for (auto& e : h->ev) if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) g += ms;
+    if (conv_ms) *conv_ms = g;
+    if (conv_flops) *conv_flops = h->flops;
+    if (conv_launches) *conv_launches = h->launches;
+    return ACE355_OK;
+}
+
+}  // extern "C"

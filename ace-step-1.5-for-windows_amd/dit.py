@@ -1,0 +1,217 @@
+"""NativeDit: Python owner of an ``ace355_dit`` handle (weights, condition slots, forward, sampler).
+
+Host-side mirror of what the reference's MLX path does around ``mlx_generate_diffusion``
+(acestep/core/generation/handler/diffusion.py:18-140, mlx_dit_init.py:9-43): convert weights from the
+already-loaded PyTorch module's ``state_dict()``, prepare noise on the host with the CPU generator
+(modeling_acestep_v15_base.py:1733-1770), build the timestep schedule (:1864-1867), call the native loop.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+
+from . import native
+from .config import DitConfig
+
+SLOT_COND, SLOT_NULL, SLOT_NON_COVER = 0, 1, 2
+
+
+def schedule(infer_steps: int, shift: float = 1.0, timesteps: Optional[Sequence[float]] = None) -> torch.Tensor:
+    """fp32 schedule of modeling_acestep_v15_base.py:1864-1867 (+ sft ``timesteps=`` :1864-1875)."""
+    if timesteps is not None:
+        return torch.as_tensor(timesteps, dtype=torch.float32).cpu()
+    t = torch.linspace(1.0, 0.0, infer_steps + 1, dtype=torch.float32)
+    if shift != 1.0:
+        t = shift * t / (1 + (shift - 1) * t)
+    return t
+
+
+def prepare_noise(shape, seed: Union[int, List[int], None]) -> torch.Tensor:
+    """prepare_noise (modeling_acestep_v15_base.py:1733-1770) with the CPU generator in fp32: the reference CPU
+    path's stream, so seeds reproduce across the CPU reference and this backend (SURVEY.md 7.2 "Noise parity")."""
+    bsz, T, Cc = shape
+    if seed is None:
+        return torch.randn(shape, dtype=torch.float32)
+    if isinstance(seed, (list, tuple)):
+        out = []
+        for s in seed:
+            if s is None or s < 0:
+                out.append(torch.randn(1, T, Cc, dtype=torch.float32))
+            else:
+                g = torch.Generator(device="cpu").manual_seed(int(s))
+                out.append(torch.randn(1, T, Cc, generator=g, dtype=torch.float32))
+        return torch.cat(out, dim=0)
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+class NativeDit:
+    def __init__(self, cfg: DitConfig, device: Union[str, torch.device] = "cuda:0"):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._lib = native.lib()
+        mask = 0
+        for i, t in enumerate(cfg.layer_types):
+            if t == "sliding_attention":
+                mask |= 1 << i
+        c = native.DitConfigC(cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_attention_heads,
+                              cfg.num_key_value_heads, cfg.head_dim, int(cfg.sliding_window or 0), cfg.patch_size,
+                              cfg.in_channels, cfg.audio_acoustic_hidden_dim, cfg.rms_norm_eps, cfg.rope_theta, mask)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_create(C.byref(c), C.byref(h)), "dit_create")
+        self._h = h
+        self._finalized = False
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            with torch.cuda.device(self.device):
+                self._lib.ace355_dit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Ingest ``AceStepDiTModel.state_dict()`` (fp32 or bf16, CPU or this device). Extra keys raise."""
+        with torch.cuda.device(self.device):
+            for name, t in sd.items():
+                if "rotary_emb" in name:
+                    continue
+                t = t.detach()
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                t = t.contiguous()
+                is_dev = 1 if t.is_cuda else 0
+                dt = native.DTYPE_F32 if t.dtype == torch.float32 else native.DTYPE_BF16
+                native.check(self._lib.ace355_dit_load_tensor(self._h, name.encode(), native.ptr(t), dt, t.numel(), is_dev),
+                             f"dit_load_tensor({name})")
+            native.check(self._lib.ace355_dit_finalize(self._h), "dit_finalize")
+        self._finalized = True
+
+    # ------------------------------------------------------------------ conditioning
+    def set_condition(self, slot: int, enc: torch.Tensor, L: Optional[int] = None) -> None:
+        """enc: [L, D] (or [1, D] broadcast over L keys, e.g. null_condition_emb)."""
+        enc = enc.detach().to(self.device, torch.float32).reshape(-1, self.cfg.hidden_size).contiguous()
+        rows = enc.shape[0]
+        L = rows if L is None else L
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_set_condition(self._h, slot, native.ptr(enc), rows, L, native.current_stream_ptr()),
+                         "dit_set_condition")
+            torch.cuda.current_stream().synchronize()  # enc may be freed by the caller after return
+
+    # ------------------------------------------------------------------ compute
+    def forward(self, x: torch.Tensor, ctx: torch.Tensor, t: Sequence[float], t_r: Sequence[float], slots: Sequence[int]) -> torch.Tensor:
+        N, T, _ = x.shape
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        ctx = ctx.detach().to(self.device, torch.float32).contiguous()
+        out = torch.empty(N, T, self.cfg.audio_acoustic_hidden_dim, device=self.device, dtype=torch.float32)
+        ta = (C.c_float * N)(*[float(v) for v in t])
+        tr = (C.c_float * N)(*[float(v) for v in t_r])
+        sl = (C.c_int32 * N)(*[int(v) for v in slots])
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_forward(self._h, native.ptr(x), native.ptr(ctx), ta, tr, sl, N, T, native.ptr(out),
+                                                      native.current_stream_ptr()), "dit_forward")
+        return out
+
+    def sample(self, xt0: torch.Tensor, ctx: torch.Tensor, t_sched: torch.Tensor, guidance_scale: float = 7.0,
+               cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0, infer_method: str = "ode", use_adg: bool = False,
+               cond_slot: int = SLOT_COND, null_slot: int = SLOT_NULL, cover_switch_step: Optional[int] = None,
+               non_cover_slot: int = SLOT_NON_COVER, ctx_non_cover: Optional[torch.Tensor] = None,
+               return_step_ms: bool = False):
+        if infer_method not in {"ode", "sde"}:
+            raise ValueError(f"Unsupported infer_method '{infer_method}'. Expected 'ode' or 'sde'.")
+        B, T, _ = xt0.shape
+        xt0 = xt0.detach().to(self.device, torch.float32).contiguous()
+        ctx = ctx.detach().to(self.device, torch.float32).contiguous()
+        ts = t_sched.detach().to("cpu", torch.float32).contiguous()
+        steps = ts.numel() - 1
+        sched = (C.c_float * (steps + 1))(*ts.tolist())
+        if ctx_non_cover is not None:
+            ctx_non_cover = ctx_non_cover.detach().to(self.device, torch.float32).contiguous()
+        p = native.SampleParamsC(steps, C.cast(sched, C.POINTER(C.c_float)), float(guidance_scale), float(cfg_interval_start),
+                                 float(cfg_interval_end), 0 if infer_method == "ode" else 1, 1 if use_adg else 0, cond_slot,
+                                 null_slot, steps if cover_switch_step is None else int(cover_switch_step), non_cover_slot,
+                                 native.ptr(ctx_non_cover))
+        out = torch.empty_like(xt0)
+        ms = (C.c_float * steps)() if return_step_ms else None
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_sample(self._h, native.ptr(xt0), native.ptr(ctx), B, T, C.byref(p), native.ptr(out),
+                                                     ms, native.current_stream_ptr()), "dit_sample")
+        if return_step_ms:
+            return out, list(ms)
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def set_profile(self, enable: bool) -> None:
+        native.check(self._lib.ace355_dit_set_profile(self._h, 1 if enable else 0), "dit_set_profile")
+
+    def get_profile(self) -> Dict[str, float]:
+        g, gf, a, af, n = C.c_double(), C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        native.check(self._lib.ace355_dit_get_profile(self._h, C.byref(g), C.byref(gf), C.byref(a), C.byref(af), C.byref(n)),
+                     "dit_get_profile")
+        return {"gemm_ms": g.value, "gemm_flops": gf.value, "attn_ms": a.value, "attn_flops": af.value, "gemm_launches": n.value}
+
+
+def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                     context_latents: torch.Tensor, seed=None, infer_method: str = "ode", infer_steps: int = 30,
+                     diffusion_guidance_sale: float = 7.0, cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0,
+                     use_adg: bool = False, shift: float = 1.0, timesteps=None, audio_cover_strength: float = 1.0,
+                     cover_noise_strength: float = 0.0, src_latents: Optional[torch.Tensor] = None,
+                     encoder_hidden_states_non_cover: Optional[torch.Tensor] = None,
+                     context_latents_non_cover: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> Dict:
+    """The part of ``generate_audio`` (modeling_acestep_v15_base.py:1861-1989) after ``prepare_condition``.
+
+    The reference replicates ONE caption across the batch (handler/batch_prep.py:93-96), so the cross-attention
+    K/V of identical rows of ``encoder_hidden_states`` are computed once per distinct row.  Batches whose items
+    carry different conditions are not a product path of the reference handler and raise here.
+    """
+    t0 = time.time()
+    B, T, _ = context_latents.shape
+    enc = encoder_hidden_states
+    if enc.shape[0] > 1 and not bool((enc == enc[:1]).all()):
+        raise NotImplementedError("ace355: per-item encoder_hidden_states in one call are not supported; "
+                                  "the handler replicates one caption across the batch")
+    ts = schedule(infer_steps, shift, timesteps)
+    steps = ts.numel() - 1
+    cover_steps = int(steps * audio_cover_strength)
+    if noise is None:
+        noise = prepare_noise((B, T, context_latents.shape[-1] // 2), seed)
+    xt0 = noise
+    if cover_noise_strength > 0.0:  # modeling_acestep_v15_base.py:1879-1900
+        eff = 1.0 - cover_noise_strength
+        tv = ts[:-1].tolist()
+        nearest = min(tv, key=lambda x: abs(x - eff))
+        start = tv.index(nearest)
+        xt0 = nearest * noise + (1 - nearest) * src_latents.detach().float().cpu()
+        ts = ts[start:]
+        steps = ts.numel() - 1
+        cover_steps = int(steps * audio_cover_strength)
+    dit.set_condition(SLOT_COND, enc[0])
+    do_cfg = diffusion_guidance_sale > 1.0
+    if do_cfg:
+        dit.set_condition(SLOT_NULL, null_condition_emb.reshape(1, -1), L=enc.shape[1])
+    ctx_nc = None
+    if cover_steps < steps:
+        enc_nc = encoder_hidden_states_non_cover
+        if enc_nc is None or context_latents_non_cover is None:
+            raise ValueError("audio_cover_strength < 1 needs the non-cover conditions")
+        if enc_nc.shape[1] != enc.shape[1]:
+            raise NotImplementedError("ace355: cover / non-cover conditions must share the encoder length")
+        dit.set_condition(SLOT_NON_COVER, enc_nc[0])
+        ctx_nc = context_latents_non_cover
+    t1 = time.time()
+    out = dit.sample(xt0, context_latents, ts, diffusion_guidance_sale, cfg_interval_start, cfg_interval_end, infer_method,
+                     use_adg, cover_switch_step=cover_steps, ctx_non_cover=ctx_nc)
+    torch.cuda.synchronize(dit.device)
+    t2 = time.time()
+    return {"target_latents": out,
+            "time_costs": {"encoder_time_cost": t1 - t0, "diffusion_time_cost": t2 - t1,
+                           "diffusion_per_step_time_cost": (t2 - t1) / max(steps, 1), "total_time_cost": t2 - t0}}

@@ -53,7 +53,7 @@ def make_vae_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, mode: st
     """Weights for the Oobleck decoder state dict (weight_g / weight_v / bias / alpha / beta).
 
     ``weight_v`` ~ N(0, 1/fan_in) so activations stay O(1) through ~40 conv layers;
-    ``weight_g`` = ||v|| (identity weight-norm) in "init" mode, randomly rescaled in "test".
+    ``weight_g`` = gain * ||v|| (see ``_vae_gain``) in "init" mode, additionally jittered in "test".
     """
     out = {}
     for name, shape in shapes.items():
@@ -68,7 +68,7 @@ def make_vae_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, mode: st
     for name, shape in shapes.items():
         if name.endswith("weight_g"):
             v = out[name[:-1] + "v"]
-            g = v.reshape(v.shape[0], -1).norm(dim=1).reshape(shape)
+            g = v.reshape(v.shape[0], -1).norm(dim=1).reshape(shape) * _vae_gain(name)
             if mode != "init":
                 g = g * (1.0 + 0.1 * _randn(name, shape, seed))
             out[name] = g
@@ -77,6 +77,21 @@ def make_vae_weights(shapes: Dict[str, Tuple[int, ...]], seed: int = 0, mode: st
         elif name.endswith(".alpha") or name.endswith(".beta"):
             out[name] = torch.zeros(shape) if mode == "init" else 0.3 * _randn(name, shape, seed)
     return out
+
+
+def _vae_gain(name: str) -> float:
+    """Per-layer gains that keep the random decoder's activations O(1) through ~40 layers (rms 0.4-0.9, waveform
+    rms ~0.1): an un-scaled random residual stack grows to rms ~250, where sin(alpha*x) is chaotic and bf16 drift is
+    meaningless.  Tuned once on the fp32 oracle ("Synthetic VAE weights")."""
+    if ".res_unit" in name and ".conv2." in name:
+        return 0.3
+    if ".res_unit" in name and ".conv1." in name:
+        return 0.7
+    if ".conv_t1." in name:
+        return 0.6
+    if name.startswith("decoder.conv2."):
+        return 0.2
+    return 1.0
 
 
 def checksum(weights: Dict[str, torch.Tensor], names: Iterable[str] = None) -> float:

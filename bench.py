@@ -1,0 +1,313 @@
+#!/usr/bin/env python
+"""bench.py - songs/s + RTF of the native denoise + decode path (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input on every rank:
+  RCCL broadcast of the conditioning bundle (N > 1) -> cross-K/V build for the cond / null slots ->
+  27-step flow-matching sampler with CFG 7.0 + APG (2B sequences per DiT forward) -> Oobleck decode to
+  48 kHz stereo fp32 -> peak normalise.   Workload at N=1: 30 s audio, 27 steps, batch 8 (the metric's config).
+Scaling is weak: every rank runs the reference's per-call cap of 8 songs (handler/service_generate_request.py:12).
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job songs/s with inputs resident
+in HBM, plus `roofline` (dominant kernel = the bf16 MFMA GEMM, HIP-event timed) and `cpu_baseline`
+(the oracle/ restatement timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--duration", type=float, default=30.0, help="seconds of audio per song")
+    ap.add_argument("--infer-steps", type=int, default=27)
+    ap.add_argument("--batch", type=int, default=8, help="songs per rank per step")
+    ap.add_argument("--enc-len", type=int, default=769, help="encoder tokens (256 text + 512 lyric + 1 timbre)")
+    ap.add_argument("--guidance", type=float, default=7.0)
+    ap.add_argument("--no-vae", action="store_true", help="DiT-only (BASELINE configs 0/1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="tiny architecture (smoke/debug only; result is not a benchmark)")
+    return ap.parse_args()
+
+
+def synth_weights_gpu(shapes, hidden, device, seed, kind):
+    """Random-init weights of the real architecture, generated on the device (fast; same on every rank)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    for name, shape in shapes.items():
+        if kind == "dit":
+            if name.endswith("scale_shift_table"):
+                w = torch.randn(shape, device=device, generator=g) / hidden ** 0.5
+            elif name.endswith("norm.weight") or name.endswith("norm_out.weight"):
+                w = torch.ones(shape, device=device)
+            elif name.endswith(".bias"):
+                w = torch.zeros(shape, device=device)
+            else:
+                w = 0.02 * torch.randn(shape, device=device, generator=g)
+        else:
+            from ace355.weightgen import _vae_gain
+            if name.endswith("weight_v"):
+                fan_in = shape[0] * 2 if ".conv_t1." in name else shape[1] * shape[2]
+                w = torch.randn(shape, device=device, generator=g) / fan_in ** 0.5
+            elif name.endswith("weight_g"):
+                w = None  # filled after its weight_v
+            elif name.endswith(".bias") or name.endswith(".alpha") or name.endswith(".beta"):
+                w = torch.zeros(shape, device=device)
+        yield name, shape, w
+
+
+def build_models(args, device):
+    import ace355
+    from ace355.dit import NativeDit
+    from ace355.vae import NativeVae
+    if args.tiny:
+        dcfg = ace355.DitConfig(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1)
+        vcfg = ace355.VaeConfig(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6))
+    else:
+        dcfg, vcfg = ace355.DitConfig(), ace355.VaeConfig()
+    dit = NativeDit(dcfg, device)
+    sd = {}
+    for name, shape, w in synth_weights_gpu(dcfg.weight_shapes(), dcfg.hidden_size, device, 1234, "dit"):
+        sd[name] = w
+    dit.load_state_dict(sd)
+    vae = None
+    vsd = {}
+    if not args.no_vae:
+        vae = NativeVae(vcfg, device)
+        for name, shape, w in synth_weights_gpu(vcfg.weight_shapes(), 0, device, 4321, "vae"):
+            vsd[name] = w
+        from ace355.weightgen import _vae_gain
+        for name in list(vsd):
+            if name.endswith("weight_g"):
+                v = vsd[name[:-1] + "v"]
+                vsd[name] = v.reshape(v.shape[0], -1).norm(dim=1).reshape(vcfg.weight_shapes()[name]) * _vae_gain(name)
+        vae.load_state_dict(vsd)
+    return dcfg, vcfg, dit, vae, sd, vsd
+
+
+def dit_flops_per_forward_per_seq(cfg, S, L):
+    """F_fwd(S, L) with band-limited sliding layers, dense full/cross attention, cached cross K/V."""
+    D, Fh, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    q, kv = cfg.num_attention_heads * hd, cfg.num_key_value_heads * hd
+    macs_tok = (q * D + 2 * kv * D + D * q) + (q * D + D * q) + 3 * D * Fh  # 9 projections
+    W = cfg.sliding_window
+    p_band = sum(min(S - 1, i + W) - max(0, i - W) + 1 for i in range(S))
+    n_sl = sum(1 for t in cfg.layer_types if t == "sliding_attention")
+    n_fl = cfg.num_hidden_layers - n_sl
+    attn = 4 * q * (n_fl * S * S + n_sl * p_band + cfg.num_hidden_layers * S * L)
+    io = 2 * S * (2 * cfg.in_channels * D + D * 2 * cfg.audio_acoustic_hidden_dim)
+    return 2 * cfg.num_hidden_layers * S * macs_tok + attn + io
+
+
+def vae_flops_per_frame(vcfg):
+    f = 2 * vcfg.decoder_input_channels * vcfg.block_dims()[0][0] * 7
+    rate = 1
+    for cin, cout, s in vcfg.block_dims():
+        rate *= s
+        f += rate * (2 * 2 * cin * cout)          # transposed conv: 2 taps per output sample
+        f += rate * 3 * (2 * cout * cout * 8)      # 3 residual units: k7 + k1
+    f += rate * 2 * vcfg.decoder_channels * vcfg.audio_channels * 7
+    return f
+
+
+def usable_cpus() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a 128-thread default on a
+    quota-limited container oversubscribes and slows the CPU baseline several-fold)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(args, dcfg, vcfg, sd, vsd, enc_cpu, null_cpu, ctx_cpu, T, L):
+    """Time the oracle (port of the reference's CPU path) on this box's host cores on a bounded sample."""
+    from oracle import dit as o_dit
+    from oracle import oobleck as o_vae
+    from oracle import sampler as o_sampler
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    o_cfg = o_dit.DitConfig(hidden_size=dcfg.hidden_size, intermediate_size=dcfg.intermediate_size,
+                            num_hidden_layers=dcfg.num_hidden_layers, num_attention_heads=dcfg.num_attention_heads,
+                            num_key_value_heads=dcfg.num_key_value_heads, sliding_window=dcfg.sliding_window)
+    # DiT: batch 1 with CFG (2 sequences), first step fills the cross K/V, then 2 steady steps are timed
+    enc2 = torch.cat([enc_cpu[None], null_cpu.reshape(1, 1, -1).expand(1, L, -1)], 0)
+    ctx2 = ctx_cpu[:1].repeat(2, 1, 1)
+    x = torch.randn(2, T, 64, generator=torch.Generator().manual_seed(1))
+    cache = o_dit.CrossCache()
+    tt = torch.full((2,), 0.9)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o_dit.dit_forward(o_cfg, w, x, tt, tt, enc2, ctx2, cache)
+        t_first = time.perf_counter() - t0
+        n_steady = 2
+        t0 = time.perf_counter()
+        for _ in range(n_steady):
+            o_dit.dit_forward(o_cfg, w, x, tt, tt, enc2, ctx2, cache)
+        t_step = (time.perf_counter() - t0) / n_steady
+    dit_song_s = t_first + (args.infer_steps - 1) * t_step
+    vae_song_s = 0.0
+    vae_T = 0
+    if vsd:
+        vw = {k: v.float().cpu() for k, v in vsd.items()}
+        ocfg = o_vae.VaeConfig(decoder_channels=vcfg.decoder_channels, channel_multiples=tuple(vcfg.channel_multiples),
+                               downsampling_ratios=tuple(vcfg.downsampling_ratios))
+        vae_T = 16
+        z = torch.randn(1, 64, vae_T, generator=torch.Generator().manual_seed(2))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            o_vae.decode(ocfg, vw, z)
+            t_dec = time.perf_counter() - t0
+        vae_song_s = t_dec * (T / vae_T)
+    song_s = dit_song_s + vae_song_s
+    return {
+        "value": 1.0 / song_s, "unit": "songs/s", "cores": threads, "kind": "port",
+        "sample": (f"oracle (fp32 torch restatement of the reference CPU path) on {threads} host threads: 1 cold + {n_steady} steady "
+                   f"DiT forwards at N=2 (CFG of 1 song), T={T}, L={L} ({t_first:.2f}s / {t_step:.2f}s per step) extrapolated to "
+                   f"{args.infer_steps} steps" + (f"; VAE decode of {vae_T} latent frames scaled to {T} ({vae_song_s:.1f}s per song)" if vsd else "")),
+        "dit_s_per_step": t_step, "s_per_song": song_s, "logical_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the native HIP path has no CPU fallback")
+    device = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import ace355  # noqa: F401
+    from ace355 import dist as a_dist
+    from ace355.dit import SLOT_COND, SLOT_NULL, prepare_noise, schedule
+    from ace355.vae import peak_normalize
+
+    dcfg, vcfg, dit, vae, sd, vsd = build_models(args, device)
+    B, L = args.batch, args.enc_len
+    T = int(round(args.duration * 25))
+    S = (T + 1) // 2
+    D = dcfg.hidden_size
+
+    # synthetic request: one caption for the batch, per-item seeds
+    g = torch.Generator().manual_seed(99)
+    if rank == 0:
+        enc = torch.randn(L, D, generator=g).to(device)
+        null = torch.randn(D, generator=g).to(device)
+        ctx_shared = torch.cat([0.5 * torch.randn(T, 64, generator=g), torch.ones(T, 64)], -1).to(device)
+    else:
+        enc = torch.empty(L, D, device=device)
+        null = torch.empty(D, device=device)
+        ctx_shared = torch.empty(T, 128, device=device)
+    ts = schedule(args.infer_steps, 1.0)
+    seeds = [1000 + rank * B + i for i in range(B)]
+    noise = prepare_noise((B, T, 64), seeds).to(device)  # CPU generator (reference CPU stream), uploaded once
+
+    def one_pass():
+        bundle = a_dist.broadcast_conditioning({"enc": enc, "null": null, "ctx": ctx_shared}, src=0) if world > 1 else \
+            {"enc": enc, "null": null, "ctx": ctx_shared}
+        ctx = bundle["ctx"][None].expand(B, -1, -1).contiguous()
+        dit.set_condition(SLOT_COND, bundle["enc"])
+        dit.set_condition(SLOT_NULL, bundle["null"].reshape(1, -1), L=L)
+        lat = dit.sample(noise, ctx, ts, guidance_scale=args.guidance)
+        if vae is None:
+            return lat
+        wav = vae.decode(lat.transpose(1, 2).contiguous())
+        return peak_normalize(wav)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite output"
+
+    songs = world * B * args.steps
+    value = songs / elapsed
+    result = {
+        "metric": "songs/sec (30 s audio @ 27 DiT steps, CFG 7.0 + APG, batch 8 per GPU, DiT + VAE decode)" if not args.no_vae
+        else "songs/sec (DiT-only)",
+        "value": value, "unit": "songs/s", "rtf": value * args.duration, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"acestep-5Hz base DiT (24L/2048d, 1.575B params, random init) + Oobleck decoder, {args.duration:g} s audio "
+                               f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward), L={L}, "
+                               f"batch {B}/GPU" + (", DiT-only" if args.no_vae else ""),
+                   "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "global_batch": world * B,
+                   "parallelism": f"dp{world}", "tiny": bool(args.tiny)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel = gemm_kernel: algorithmic FLOPs per launch / HIP-event launch time, one extra profiled pass
+        dit.set_profile(True)
+        if vae is not None:
+            vae.set_profile(True)
+        one_pass()
+        torch.cuda.synchronize()
+        p = dit.get_profile()
+        dit.set_profile(False)
+        gemm_tf = p["gemm_flops"] / (p["gemm_ms"] * 1e-3) / 1e12 if p["gemm_ms"] > 0 else 0.0
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 32x32x16, 128x128x64 tile)",
+                              "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
+                              "traffic": None, "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
+                              "avg_launch_us": 1000.0 * p["gemm_ms"] / max(p["gemm_launches"], 1),
+                              "flops_per_launch": p["gemm_flops"] / max(p["gemm_launches"], 1),
+                              "attn_tflops": p["attn_flops"] / (p["attn_ms"] * 1e-3) / 1e12 if p["attn_ms"] > 0 else 0.0,
+                              "attn_ms_per_pass": p["attn_ms"]}
+        if vae is not None:
+            vp = vae.get_profile()
+            vae.set_profile(False)
+            result["roofline"]["vae_conv_tflops"] = vp["conv_flops"] / (vp["conv_ms"] * 1e-3) / 1e12 if vp["conv_ms"] > 0 else 0.0
+            result["roofline"]["vae_conv_ms_per_pass"] = vp["conv_ms"]
+        alg = B * (2 * args.infer_steps * dit_flops_per_forward_per_seq(dcfg, S, L) + (0 if args.no_vae else T * vae_flops_per_frame(vcfg)))
+        result["algorithmic_tflop_per_step"] = alg / 1e12
+        result["achieved_tflops_whole_path"] = alg / 1e12 / (elapsed / args.steps)
+
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, dcfg, vcfg, sd, vsd, enc.cpu(), null.cpu(), ctx_shared.cpu()[None], T, L)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,31 +76,45 @@ def _w(w: Dict[str, Tensor], base: str) -> Tensor:
     return fuse_weight_norm(w[base + ".weight_g"], w[base + ".weight_v"])
 
 
-def residual_unit(w: Dict[str, Tensor], p: str, x: Tensor, dilation: int) -> Tensor:
-    """vae_model.py:62-87: x + conv_k1(snake2(conv_k7_dil(snake1(x)))), pad = 3*dilation."""
-    y = F.conv1d(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"]), _w(w, p + ".conv1"), w[p + ".conv1.bias"],
-                 dilation=dilation, padding=3 * dilation)
-    y = F.conv1d(snake(y, w[p + ".snake2.alpha"], w[p + ".snake2.beta"]), _w(w, p + ".conv2"), w[p + ".conv2.bias"])
-    return x + y
-
-
-def decoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int) -> Tensor:
-    """vae_model.py:119-142: snake -> ConvTranspose1d(k=2s, stride=s, pad=ceil(s/2)) -> res units d=1,3,9."""
-    x = snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"])
-    x = F.conv_transpose1d(x, _w(w, p + ".conv_t1"), w[p + ".conv_t1.bias"], stride=stride, padding=math.ceil(stride / 2))
-    x = residual_unit(w, p + ".res_unit1", x, 1)
-    x = residual_unit(w, p + ".res_unit2", x, 3)
-    x = residual_unit(w, p + ".res_unit3", x, 9)
+def _ident(x: Tensor) -> Tensor:
     return x
 
 
-def decode(cfg: VaeConfig, w: Dict[str, Tensor], z: Tensor) -> Tensor:
-    """vae_model.py:190-230: z [B,64,T] -> waveform [B,2,hop*T] (== vae.decode(z).sample)."""
-    x = F.conv1d(z, _w(w, "decoder.conv1"), w["decoder.conv1.bias"], padding=3)
+def _bf16(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def residual_unit(w: Dict[str, Tensor], p: str, x: Tensor, dilation: int, q=_ident) -> Tensor:
+    """vae_model.py:62-87: x + conv_k1(snake2(conv_k7_dil(snake1(x)))), pad = 3*dilation."""
+    y = q(F.conv1d(q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"])), q(_w(w, p + ".conv1")), w[p + ".conv1.bias"],
+                   dilation=dilation, padding=3 * dilation))
+    y = F.conv1d(q(snake(y, w[p + ".snake2.alpha"], w[p + ".snake2.beta"])), q(_w(w, p + ".conv2")), w[p + ".conv2.bias"])
+    return q(x + y)
+
+
+def decoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int, q=_ident) -> Tensor:
+    """vae_model.py:119-142: snake -> ConvTranspose1d(k=2s, stride=s, pad=ceil(s/2)) -> res units d=1,3,9."""
+    x = q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"]))
+    x = q(F.conv_transpose1d(x, q(_w(w, p + ".conv_t1")), w[p + ".conv_t1.bias"], stride=stride, padding=math.ceil(stride / 2)))
+    x = residual_unit(w, p + ".res_unit1", x, 1, q)
+    x = residual_unit(w, p + ".res_unit2", x, 3, q)
+    x = residual_unit(w, p + ".res_unit3", x, 9, q)
+    return x
+
+
+def decode(cfg: VaeConfig, w: Dict[str, Tensor], z: Tensor, emulate_bf16: bool = False) -> Tensor:
+    """vae_model.py:190-230: z [B,64,T] -> waveform [B,2,hop*T] (== vae.decode(z).sample).
+
+    ``emulate_bf16=True`` rounds weights and every inter-layer activation to bfloat16 (fp32 arithmetic in
+    between): the storage precision of the reference's own GPU VAE (handler/memory_utils.py:157-166, bf16 on
+    cuda) and of the HIP path, used to separate kernel error from storage-precision drift.
+    """
+    q = _bf16 if emulate_bf16 else _ident
+    x = q(F.conv1d(q(z), q(_w(w, "decoder.conv1")), w["decoder.conv1.bias"], padding=3))
     for i, (_cin, _cout, s) in enumerate(cfg.block_dims()):
-        x = decoder_block(w, f"decoder.block.{i}", x, s)
-    x = snake(x, w["decoder.snake1.alpha"], w["decoder.snake1.beta"])
-    return F.conv1d(x, _w(w, "decoder.conv2"), None, padding=3)
+        x = decoder_block(w, f"decoder.block.{i}", x, s, q)
+    x = q(snake(x, w["decoder.snake1.alpha"], w["decoder.snake1.beta"]))
+    return F.conv1d(x, q(_w(w, "decoder.conv2")), None, padding=3)
 
 
 def decoder_weight_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test collected on a box without a GPU: run with -m 'not gpu' here")
+    # the native library is the product: its absence is a failure, never a skip
+    import ace355
+    from ace355 import native
+    native.lib()
+    return torch.device("cuda:0")

@@ -1,0 +1,230 @@
+"""GPU parity of the individual HIP kernels (through the C ABI test hooks) against the oracle / plain fp32 torch.
+
+Inputs are rounded to bf16 first, so the comparison isolates the kernel's arithmetic (fp32 accumulate,
+bf16 output rounding) from input quantisation.  Tolerances are written next to each check.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def lib(gpu_device):
+    from ace355 import native
+    return native.lib()
+
+
+def _p(t):
+    from ace355 import native
+    return native.ptr(t)
+
+
+def _chk(rc):
+    from ace355 import native
+    native.check(rc, "test")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (6000, 2048, 2048), (130, 512, 384), (1, 256, 256), (257, 128, 6144), (750, 12288, 2048)])
+def test_gemm_store(lib, gpu_device, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    # asymmetric, non-symmetric operands (transpose-detecting, cdna guide 5.4 rule 16)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    W = _bf(torch.randn(N, K, generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-3).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    ref = A.float() @ W.float().t() + bias
+    out = torch.empty(M, N, device=gpu_device, dtype=torch.float32)
+    _chk(lib.ace355_gemm_bf16(_p(A), _p(W), _p(out), M, N, K, 0, _p(bias), None))
+    assert _rel(out, ref) < 2e-5, _rel(out, ref)  # fp32 accumulate of exact bf16 products, f32 store
+    outb = torch.empty(M, N, device=gpu_device, dtype=torch.bfloat16)
+    _chk(lib.ace355_gemm_bf16(_p(A), _p(W), _p(outb), M, N, K, 1, None, None))
+    ref2 = (A.float() @ W.float().t())
+    assert _rel(outb, ref2) < 4e-3  # bf16 output rounding (2^-9 relative)
+    assert torch.equal(outb, ref2.to(torch.bfloat16)) or float((outb.float() - ref2).abs().max() / ref2.abs().max()) < 8e-3
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(375 * 4, 2048, 2048, 375), (60, 256, 256, 20), (130, 256, 768, 65)])
+def test_gemm_residual_gate(lib, gpu_device, M, N, K, rows):
+    g = torch.Generator().manual_seed(7)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    W = _bf(torch.randn(N, K, generator=g) * 0.05).to(gpu_device)
+    H = torch.randn(M, N, generator=g).to(gpu_device)
+    nseq = M // rows + (1 if M % rows else 0)
+    g1 = torch.randn(N, generator=g).to(gpu_device)
+    g2 = torch.randn(nseq, 6, N, generator=g).to(gpu_device)  # stride 6*N like timestep_proj
+    seq = torch.arange(M, device=gpu_device) // rows
+    gate = g1[None, :] + g2[seq, 2, :]
+    ref = H + gate * (A.float() @ W.float().t())
+    out = H.clone()
+    _chk(lib.ace355_gemm_bf16_fused(_p(A), _p(W), _p(out), M, N, K, 0, _p(g1), g2[:, 2].data_ptr(), 6 * N, rows, None))
+    assert _rel(out, ref) < 2e-5, _rel(out, ref)
+    out2 = H.clone()  # plain residual (cross-attention, base.py:526)
+    _chk(lib.ace355_gemm_bf16_fused(_p(A), _p(W), _p(out2), M, N, K, 0, None, None, 0, rows, None))
+    assert _rel(out2, H + A.float() @ W.float().t()) < 2e-5
+
+
+@pytest.mark.parametrize("M,Fh,K", [(300, 768, 256), (1000, 6144, 2048)])
+def test_gemm_swiglu(lib, gpu_device, M, Fh, K):
+    g = torch.Generator().manual_seed(9)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    Wg = _bf(torch.randn(Fh, K, generator=g) * 0.05).to(gpu_device)
+    Wu = _bf(torch.randn(Fh, K, generator=g) * 0.05).to(gpu_device)
+    # library layout: rows interleaved [32 gate | 32 up]
+    Wp = torch.stack([Wg.view(Fh // 32, 32, K), Wu.view(Fh // 32, 32, K)], dim=1).reshape(2 * Fh, K).contiguous()
+    ref = F.silu(A.float() @ Wg.float().t()) * (A.float() @ Wu.float().t())
+    out = torch.empty(M, Fh, device=gpu_device, dtype=torch.bfloat16)
+    _chk(lib.ace355_gemm_bf16_fused(_p(A), _p(Wp), _p(out), M, 2 * Fh, K, 1, None, None, 0, 0, None))
+    assert _rel(out, ref) < 4e-3, _rel(out, ref)
+
+
+@pytest.mark.parametrize("M,D,rows,mod", [(750, 2048, 375, True), (41, 256, 21, True), (64, 2048, 64, False)])
+def test_rmsnorm_mod(lib, gpu_device, M, D, rows, mod):
+    from oracle import dit as o_dit
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(M, D, generator=g) * 3).to(gpu_device)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(gpu_device)
+    nseq = (M + rows - 1) // rows
+    t1 = torch.randn(6, D, generator=g).to(gpu_device) / D ** 0.5
+    t2 = torch.randn(nseq, 6, D, generator=g).to(gpu_device)
+    ref = o_dit.rms_norm(x.cpu(), w.cpu(), 1e-6)
+    if mod:
+        seq = torch.arange(M) // rows
+        ref = ref * (1 + (t1[1].cpu() + t2[seq, 1].cpu())) + (t1[0].cpu() + t2[seq, 0].cpu())
+    y = torch.empty(M, D, device=gpu_device, dtype=torch.bfloat16)
+    if mod:
+        _chk(lib.ace355_rmsnorm_mod(_p(x), _p(w), _p(y), M, D, 1e-6, t1[1].data_ptr(), t2[:, 1].data_ptr(), t1[0].data_ptr(),
+                                    t2[:, 0].data_ptr(), 6 * D, rows, None))
+    else:
+        _chk(lib.ace355_rmsnorm_mod(_p(x), _p(w), _p(y), M, D, 1e-6, None, None, None, None, 0, rows, None))
+    assert _rel(y.cpu(), ref) < 3e-3  # bf16 output rounding
+
+
+@pytest.mark.parametrize("N,S,heads,rope", [(2, 375, 16, True), (1, 20, 3, True), (2, 77, 8, False)])
+def test_headnorm_rope(lib, gpu_device, N, S, heads, rope):
+    from oracle import dit as o_dit
+    g = torch.Generator().manual_seed(5)
+    M = N * S
+    ld = heads * 128 + 256
+    x = _bf(torch.randn(M, ld, generator=g) * 2)
+    w = 1 + 0.1 * torch.randn(128, generator=g)
+    xh = x[:, 128:128 + heads * 128].float().view(N, S, heads, 128)
+    ref = o_dit.rms_norm(xh, w, 1e-6).transpose(1, 2)  # [N,H,S,128]
+    if rope:
+        cos, sin = o_dit.rope_cos_sin(S, 128, 1e6)
+        ref, _ = o_dit.apply_rope(ref, ref, cos, sin)
+    xd = x.clone().to(gpu_device)
+    wd = w.to(gpu_device)
+    _chk(lib.ace355_headnorm_rope(_p(xd), M, ld, 128, heads, _p(wd), 1e-6, 1 if rope else 0, S, 1e6, None))
+    got = xd.cpu()[:, 128:128 + heads * 128].float().view(N, S, heads, 128).transpose(1, 2)
+    assert _rel(got, ref) < 3e-3
+    # columns outside the head range are untouched
+    assert torch.equal(xd.cpu()[:, :128], x[:, :128]) and torch.equal(xd.cpu()[:, 128 + heads * 128:], x[:, 128 + heads * 128:])
+
+
+@pytest.mark.parametrize("N,Sq,Skv,Hq,Hkv,window", [
+    (2, 375, 375, 16, 8, -1), (2, 375, 375, 16, 8, 128), (1, 300, 300, 2, 1, 16), (2, 375, 769, 16, 8, -1),
+    (1, 20, 33, 2, 1, -1), (1, 1500, 1500, 4, 2, 128), (1, 129, 129, 2, 2, 128), (1, 64, 1, 2, 1, -1)])
+def test_attention(lib, gpu_device, N, Sq, Skv, Hq, Hkv, window):
+    from oracle import dit as o_dit
+    g = torch.Generator().manual_seed(Sq + Skv + Hq)
+    q = _bf(torch.randn(N, Sq, Hq * 128, generator=g))
+    k = _bf(torch.randn(N, Skv, Hkv * 128, generator=g))
+    v = _bf(torch.randn(N, Skv, Hkv * 128, generator=g) + torch.arange(Skv)[None, :, None] * 0.01)
+    scale = 128 ** -0.5
+    mask = None
+    if window >= 0:
+        mask = o_dit.additive_mask(o_dit.band_valid(Sq, window))[None, None]
+    ref = o_dit.attention(q.float().view(N, Sq, Hq, 128).transpose(1, 2), k.float().view(N, Skv, Hkv, 128).transpose(1, 2),
+                          v.float().view(N, Skv, Hkv, 128).transpose(1, 2), mask, scale)
+    out = torch.empty(N, Sq, Hq * 128, device=gpu_device, dtype=torch.bfloat16)
+    qd, kd, vd = q.to(gpu_device), k.to(gpu_device), v.to(gpu_device)
+    _chk(lib.ace355_attention(_p(qd), _p(kd), _p(vd), _p(out), N, Sq, Skv, Hq, Hkv, window, scale, None))
+    # P is rounded to bf16 before PV (like every flash kernel) and O to bf16: 1e-2 relative L2
+    assert _rel(out.cpu(), ref) < 1e-2, _rel(out.cpu(), ref)
+
+
+def test_attention_rescale_branch(lib, gpu_device):
+    """A key spike late in the sequence forces the online-softmax rescale (cdna guide 5.4 rule 26)."""
+    from oracle import dit as o_dit
+    g = torch.Generator().manual_seed(1)
+    N, S, H = 1, 320, 2
+    q = torch.randn(N, S, H * 128, generator=g)
+    k = torch.randn(N, S, H * 128, generator=g)
+    v = torch.randn(N, S, H * 128, generator=g)
+    k[0, 250] = q[0, 7] * 3.0  # huge score for query 7 at key 250 (4th tile)
+    q, k, v = _bf(q), _bf(k), _bf(v)
+    ref = o_dit.attention(q.float().view(N, S, H, 128).transpose(1, 2), k.float().view(N, S, H, 128).transpose(1, 2),
+                          v.float().view(N, S, H, 128).transpose(1, 2), None, 128 ** -0.5)
+    out = torch.empty(N, S, H * 128, device=gpu_device, dtype=torch.bfloat16)
+    qd, kd, vd = q.to(gpu_device), k.to(gpu_device), v.to(gpu_device)
+    _chk(lib.ace355_attention(_p(qd), _p(kd), _p(vd), _p(out), N, S, S, H, H, -1, 128 ** -0.5, None))
+    assert float((out.cpu().float() - ref).abs().max()) < 5e-2
+    assert _rel(out.cpu(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("B,T", [(2, 50), (8, 750), (1, 7)])
+def test_apg_euler(lib, gpu_device, B, T):
+    from oracle import apg as o_apg
+    g = torch.Generator().manual_seed(B * T)
+    xt = torch.randn(B, T, 64, generator=g)
+    x_ref = xt.clone()
+    mb = o_apg.MomentumBuffer()
+    xd = xt.to(gpu_device)
+    avg = torch.zeros(B, T, 64, device=gpu_device)
+    for i in range(3):
+        v = torch.randn(2 * B, T, 64, generator=g) * (1 + 2 * i)  # growing norms exercise the 2.5 clip
+        dt = 0.05 * (i + 1)
+        vv = o_apg.apg_forward(v[:B], v[B:], 7.0, mb, dims=[1])
+        x_ref = x_ref - vv * dt
+        vd = v.to(gpu_device)
+        _chk(lib.ace355_apg_euler_step(_p(vd), _p(avg), _p(xd), B, T, 7.0, dt, 1, 1 if i == 0 else 0, None))
+        assert float((xd.cpu() - x_ref).abs().max()) < 2e-5 * (1 + float(x_ref.abs().max())), i
+    # outside the cfg interval: v = cond, momentum untouched (base.py:1965-1966)
+    v = torch.randn(2 * B, T, 64, generator=g)
+    avg_before = avg.clone()
+    x_ref = x_ref - v[:B] * 0.1
+    vd = v.to(gpu_device)
+    _chk(lib.ace355_apg_euler_step(_p(vd), _p(avg), _p(xd), B, T, 7.0, 0.1, 0, 0, None))
+    assert float((xd.cpu() - x_ref).abs().max()) < 2e-5 * (1 + float(x_ref.abs().max()))
+    assert torch.equal(avg, avg_before)
+
+
+@pytest.mark.parametrize("B,L,Cin,Cout,taps,dil,snake,res", [
+    (2, 300, 128, 128, 7, 1, True, False), (1, 517, 128, 128, 7, 9, True, False), (2, 200, 256, 256, 7, 3, True, False),
+    (2, 300, 128, 128, 1, 1, True, True), (1, 40, 64, 2048, 7, 1, False, False), (1, 1000, 128, 2, 7, 1, True, False)])
+def test_conv1d_nlc(lib, gpu_device, B, L, Cin, Cout, taps, dil, snake, res):
+    from oracle import oobleck as o_vae
+    g = torch.Generator().manual_seed(L + Cin + taps + dil)
+    x = _bf(torch.randn(B, L, Cin, generator=g))
+    w = _bf(torch.randn(Cout, Cin, taps, generator=g) / (Cin * taps) ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    alpha = torch.randn(Cin, generator=g) * 0.3
+    beta = torch.randn(Cin, generator=g) * 0.3
+    r = _bf(torch.randn(B, L, Cout, generator=g))
+    xin = x.float().transpose(1, 2)
+    if snake:
+        # the kernel rounds snake(x) to bf16 before the MFMA, so does the reference here
+        xin = _bf(o_vae.snake(xin, alpha.view(1, -1, 1), beta.view(1, -1, 1))).float()
+    ref = F.conv1d(xin, w.float(), bias, dilation=dil, padding=(taps // 2) * dil).transpose(1, 2)
+    if res:
+        ref = ref + r.float()
+    y = torch.empty(B, L, Cout, device=gpu_device, dtype=torch.bfloat16)
+    wp = w.permute(0, 2, 1).contiguous().to(gpu_device)  # [Cout][taps][Cin]
+    xd, bd, ad, btd, rd = x.to(gpu_device), bias.to(gpu_device), alpha.to(gpu_device), beta.to(gpu_device), r.to(gpu_device)
+    _chk(lib.ace355_conv1d_nlc(_p(xd), _p(wp), _p(bd), _p(ad) if snake else None, _p(btd) if snake else None,
+                               _p(rd) if res else None, _p(y), B, L, Cin, Cout, taps, dil, None))
+    # fast sin + bf16 rounding of snake(x) may flip a bf16 ulp on a few inputs: 6e-3 relative L2
+    assert _rel(y.cpu(), ref) < 6e-3, _rel(y.cpu(), ref)

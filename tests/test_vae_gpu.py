@@ -1,0 +1,85 @@
+"""GPU parity of the native Oobleck decoder (through the C ABI) against the oracle restatement.
+
+The oracle for this part is parity-UNPINNED (third-party diffusers arithmetic, see oracle/oobleck.py); what is
+asserted is agreement of the HIP path with that restatement: bf16 activations through ~36 conv layers.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _snr_db(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float(10 * torch.log10(b.pow(2).sum() / ((a - b).pow(2).sum() + 1e-30)))
+
+
+def _build(cfg_kw, device, seed=1):
+    import ace355
+    from ace355 import weightgen
+    from ace355.vae import NativeVae
+    cfg = ace355.VaeConfig(**cfg_kw)
+    w = weightgen.make_vae_weights(cfg.weight_shapes(), seed=seed, mode="test")
+    vae = NativeVae(cfg, device)
+    vae.load_state_dict(w)
+    return cfg, w, vae
+
+
+@pytest.mark.parametrize("cfg_kw,B,T", [
+    (dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6)), 2, 37),
+    (dict(), 1, 24),
+    (dict(), 2, 9),
+])
+def test_decode_vs_oracle(gpu_device, cfg_kw, B, T):
+    from oracle import oobleck as o_vae
+    cfg, w, vae = _build(cfg_kw, gpu_device)
+    assert vae.hop == cfg.hop
+    g = torch.Generator().manual_seed(T)
+    z = torch.randn(B, 64, T, generator=g)
+    wav = vae.decode(z)
+    assert wav.shape == (B, cfg.audio_channels, cfg.hop * T) and wav.dtype == torch.float32
+    o_cfg = o_vae.VaeConfig(**cfg_kw)
+    ref = o_vae.decode(o_cfg, w, z)                       # fp32 restatement
+    emu = o_vae.decode(o_cfg, w, z, emulate_bf16=True)    # same restatement, bf16 storage between layers
+    snr_fp32, snr_emu, drift = _snr_db(wav, ref), _snr_db(wav, emu), _snr_db(emu, ref)
+    print(f"vae decode {cfg_kw or 'full'} B={B} T={T}: SNR vs fp32 oracle {snr_fp32:.1f} dB, vs bf16-storage oracle "
+          f"{snr_emu:.1f} dB (bf16-storage drift of the oracle itself: {drift:.1f} dB); wav rms {float(ref.pow(2).mean().sqrt()):.3f}")
+    # stated tolerance (SURVEY 8d parity gate): the HIP waveform may differ from the fp32 restatement by at most 2x
+    # (6 dB) the drift the restatement shows against itself when it stores activations in bf16 ...
+    assert snr_fp32 > drift - 6.0, (snr_fp32, drift)
+    # ... and must agree with the bf16-storage restatement (identical rounding points) to >= 30 dB.
+    assert snr_emu > 30.0, snr_emu
+
+
+def test_whole_sequence_equals_tiled(gpu_device):
+    """the reference's overlap-discard tiling equals the un-tiled decode away from fp order."""
+    from oracle import tiling as o_tiling
+    cfg_kw = dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6))
+    cfg, w, vae = _build(cfg_kw, gpu_device)
+    z = torch.randn(1, 64, 200, generator=torch.Generator().manual_seed(3))
+    whole = vae.decode(z)
+    tiled = o_tiling.tiled_decode(lambda c: vae.decode(c).cpu(), z, chunk_size=96, overlap=24)
+    assert tiled.shape == whole.shape
+    assert _snr_db(tiled, whole) > 35.0
+
+
+def test_peak_normalize_and_latent_check(gpu_device):
+    from ace355.vae import latent_check, peak_normalize
+    from oracle import tiling as o_tiling
+    wav = torch.randn(3, 2, 5000, generator=torch.Generator().manual_seed(0))
+    wav[1] *= 0.1
+    ref = o_tiling.peak_normalize(wav.clone())
+    got = peak_normalize(wav.clone().to(gpu_device))
+    assert float((got.cpu() - ref).abs().max()) < 1e-6
+    quiet = torch.rand(2, 2, 100) * 0.5
+    assert torch.equal(peak_normalize(quiet.clone().to(gpu_device)).cpu(), quiet)
+    assert latent_check(torch.zeros(4, 5, device=gpu_device)) == (False, True)
+    assert latent_check(torch.ones(4, 5, device=gpu_device)) == (False, False)
+    bad = torch.ones(4, 5, device=gpu_device)
+    bad[1, 2] = float("nan")
+    assert latent_check(bad)[0] is True

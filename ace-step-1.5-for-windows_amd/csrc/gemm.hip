@@ -10,6 +10,8 @@
 // Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace ace355 {
 
 namespace {
@@ -17,6 +19,71 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+
+// Epilogue shared by both mainloops.  Lane holds column n = .. + (lane&31) and 16 rows m = .. + mfma_row(r, lane) of
+// each 32x32 accumulator tile.
+template <int MODE, int MT>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __restrict__ Cv, int ldc, int M, int N,
+                                              const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane) {
+    const int frow = lane & 31, fhalf = lane >> 5;
+    if (MODE == 3) {
+        // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up of the same column
+        bf16_t* out = reinterpret_cast<bf16_t*>(Cv);
+        const int col = ((n0 + wn * 64) >> 1) + frow;
+        const bool nok = (n0 + wn * 64 + 32 + frow) < N;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (MT * 32) + i * 32 + mfma_row(r, lane);
+                if (m < M && nok) {
+                    const float g = acc[i][0][r], u = acc[i][1][r];
+                    out[(long)m * ldc + col] = f2bf(silu_f(g) * u);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + frow;
+        if (n >= N) continue;
+        float bias = 0.f, g1 = 1.f;
+        if (MODE <= 1 && ep.bias) bias = ep.bias[n];
+        if (MODE == 2 && ep.g1) g1 = ep.g1[n];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * (MT * 32) + i * 32 + 4 * fhalf;
+            int seq0 = 0, rem0 = 0;
+            if (MODE == 2 && ep.g1) {
+                seq0 = mb / ep.rows_per_seq;
+                rem0 = mb - seq0 * ep.rows_per_seq;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int off = (r & 3) + 8 * (r >> 2);
+                const int m = mb + off;
+                if (m >= M) continue;
+                const float v = acc[i][j][r];
+                if (MODE == 0) {
+                    reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + bias);
+                } else if (MODE == 1) {
+                    reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + bias;
+                } else {
+                    float gate = 1.f;
+                    if (ep.g1) {
+                        int seq = seq0, rem = rem0 + off;
+                        while (rem >= ep.rows_per_seq) { rem -= ep.rows_per_seq; ++seq; }
+                        gate = g1 + ep.g2[(long)seq * ep.g2_stride + n];
+                    }
+                    float* h = reinterpret_cast<float*>(Cv) + (long)m * ldc + n;
+                    *h = *h + gate * v;
+                }
+            }
+        }
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
@@ -106,67 +173,112 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
         __syncthreads();
     }
 
-    // ---------------------------------------------------------------- epilogue
-    // lane holds column n = .. + (lane&31) and 16 rows m = .. + mfma_row(r, lane) of each 32x32 tile
-    if (MODE == 3) {
-        // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up of the same column
-        bf16_t* out = reinterpret_cast<bf16_t*>(Cv);
-        const int col = ((n0 + wn * 64) >> 1) + frow;
-        const bool nok = (n0 + wn * 64 + 32 + frow) < N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + mfma_row(r, lane);
-                if (m < M && nok) {
-                    const float g = acc[i][0][r], u = acc[i][1][r];
-                    out[(long)m * ldc + col] = f2bf(silu_f(g) * u);
-                }
-            }
-        }
-        return;
+    gemm_epilogue<MODE, 2>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------ v2: direct-to-LDS
+// Same tile math, but A/W tiles go HBM -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
+// round trip and no ds_write pass).  The DMA writes LDS linearly (wave-uniform base + lane*16), so the bank swizzle is
+// applied on the SOURCE address (cdna guide rule 21): lane (row r, physical slot p) fetches logical k-slot p ^ ((r>>1)&7).
+// MT = 32-row accumulator tiles per wave along M: MT=2 -> 128x128 block tile, MT=3 -> 192x128 (M=6000, N=2048 is then
+// exactly 512 tiles = one full wave of 2 blocks/CU instead of 1.47 waves).
+template <int MODE, int MT>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                            int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                            GemmEpilogue ep, int tiles_n, int nwg) {
+    constexpr int BMv = MT * 64;
+    constexpr int A_BYTES = BMv * 128;
+    constexpr int STAGE = A_BYTES + 16384;
+    constexpr int AJ = BMv / 32;  // A DMA instructions per wave per K-step
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMv, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lrow = lane >> 3, pslot = lane & 7;
+    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);  // (r>>1)&7 for r = 8*(wave+4j) + lrow, any j
+    const bf16_t* a_src[AJ];
+    const bf16_t* w_src[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + frow;
-        if (n >= N) continue;
-        float bias = 0.f, g1 = 1.f;
-        if (MODE <= 1 && ep.bias) bias = ep.bias[n];
-        if (MODE == 2 && ep.g1) g1 = ep.g1[n];
+    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + 4 * j) + lrow, M - 1) * lda + sslot * 8;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mb = m0 + wm * 64 + i * 32 + 4 * fhalf;
-            int seq0 = 0, rem0 = 0;
-            if (MODE == 2 && ep.g1) {
-                seq0 = mb / ep.rows_per_seq;
-                rem0 = mb - seq0 * ep.rows_per_seq;
-            }
+    for (int j = 0; j < 4; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + 4 * j) + lrow, N - 1) * ldw + sslot * 8;
+
+    f32x16 acc[MT][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                const int m = mb + off;
-                if (m >= M) continue;
-                const float v = acc[i][j][r];
-                if (MODE == 0) {
-                    reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + bias);
-                } else if (MODE == 1) {
-                    reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + bias;
-                } else {
-                    float gate = 1.f;
-                    if (ep.g1) {
-                        int seq = seq0, rem = rem0 + off;
-                        while (rem >= ep.rows_per_seq) { rem -= ep.rows_per_seq; ++seq; }
-                        gate = g1 + ep.g2[(long)seq * ep.g2_stride + n];
-                    }
-                    float* h = reinterpret_cast<float*>(Cv) + (long)m * ldc + n;
-                    *h = *h + gate * v;
-                }
-            }
-        }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define GLDS(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define ISSUE_TILE(kt_, stage_)                                                                      \
+    {                                                                                                \
+        char* sb_ = smem + (stage_) * STAGE;                                                         \
+        _Pragma("unroll") for (int j = 0; j < AJ; ++j) GLDS(a_src[j] + (kt_) * BK, sb_ + (wave + 4 * j) * 1024); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS(w_src[j] + (kt_) * BK, sb_ + A_BYTES + (wave + 4 * j) * 1024); \
     }
+
+    const int nk = K / BK;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    ISSUE_TILE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) ISSUE_TILE(kt + 1, (kt + 1) & 1)
+        const char* As = smem + (kt & 1) * STAGE;
+        const char* Ws = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[MT], fw[2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(wm * (MT * 32) + i * 32 + frow, kk * 2 + fhalf)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * 64 + j * 32 + frow, kk * 2 + fhalf)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef ISSUE_TILE
+#undef GLDS
+    gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
 }
 
 }  // namespace
+
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ACE355_GEMM");  // "v1" = register-staged kernel (A/B testing); default = direct-to-LDS
+        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 2;
+    }
+    return v;
+}
+
+template <int MODE>
+static void launch_mode(int variant, int mt, dim3 grid, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C,
+                        int ldc, int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
+    if (variant == 1) hipLaunchKernelGGL(gemm_kernel<MODE>, grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+    else if (mt == 3) hipLaunchKernelGGL((gemm_glds_kernel<MODE, 3>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+    else hipLaunchKernelGGL((gemm_glds_kernel<MODE, 2>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+}
 
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s) {
@@ -175,14 +287,25 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ACE_CHECK((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-B rows)");
     ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int variant = gemm_variant();
+    const int tiles_n = (N + BN - 1) / BN;
+    // block-tile height: minimise (#waves of 512 resident blocks) x (rows per tile); ties -> 128
+    int mt = 2;
+    if (variant == 2) {
+        const long slots = 512;
+        const long t128 = (long)((M + 127) / 128) * tiles_n, t192 = (long)((M + 191) / 192) * tiles_n;
+        const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
+        if (c192 < c128) mt = 3;
+    }
+    const int bm = mt * 64;
+    const int tiles_m = (M + bm - 1) / bm;
     const int nwg = tiles_m * tiles_n;
-    dim3 grid(nwg), block(256);
+    dim3 grid(nwg);
     switch (ep.mode) {
-        case 0: hipLaunchKernelGGL(gemm_kernel<0>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 1: hipLaunchKernelGGL(gemm_kernel<1>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 2: hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 3: hipLaunchKernelGGL(gemm_kernel<3>, grid, block, 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 0: launch_mode<0>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 1: launch_mode<1>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 2: launch_mode<2>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 3: launch_mode<3>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         default: ACE_CHECK(false, "gemm: bad epilogue mode");
     }
     ACE_LAUNCH_CHECK();

@@ -1,0 +1,331 @@
+"""The reference's backend seam, re-implemented for the native MI355X path.
+
+The reference selects an alternate DiT / VAE backend through handler flags and a pair of mixin methods introduced
+for MLX:
+  * ``_init_mlx_dit`` / ``_init_mlx_vae``   (handler/mlx_dit_init.py:9-43, handler/mlx_vae_init.py:12-96)
+  * ``_mlx_run_diffusion``                  (handler/diffusion.py:18-140), called from
+    ``_execute_service_generate_diffusion`` (handler/service_generate_execute.py:144-194)
+  * ``_mlx_vae_decode`` via ``tiled_decode`` (handler/vae_decode.py:39-48, handler/generate_music_decode.py:165-167)
+
+``NativeDitMixin`` / ``NativeVaeMixin`` provide the same-shaped methods over the C ABI, so a maintainer mixes them
+into ``AceStepHandler``.  Because the reference's Python cannot travel to the GPU box,
+``NativeHandler`` is this repo's own counterpart of the handler for that path: ``initialize_service`` /
+``service_generate`` / ``generate_music`` with the reference's keyword names and return-dict shapes, fed by
+pre-embedded conditioning tensors instead of raw text (the text/LM stages are out of scope).
+
+Error contract (reference): backend failure = Python exception, caught at the seam, fall back / error payload;
+``generate_music`` never raises (handler/generate_music.py:181-190).  The native methods themselves never fall back
+to a CPU implementation: a missing library or a failed HIP call raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import logging
+import time
+import traceback
+from typing import Any, Dict, List, Optional, Sequence, Union
+
+import torch
+
+from .config import DitConfig, VaeConfig
+
+logger = logging.getLogger("ace355")
+
+MAX_BATCH_SIZE = 8  # handler/service_generate_request.py:12
+
+
+class NativeDitMixin:
+    """Required host attributes: ``model`` (with ``.decoder``, ``.null_condition_emb``, ``.config``), ``device``, ``dtype``."""
+
+    use_native_dit: bool = False
+    native_dit = None
+
+    def _init_native_dit(self) -> bool:
+        """Counterpart of ``_init_mlx_dit``: convert weights from the already-loaded PyTorch module. Never raises."""
+        try:
+            if getattr(self, "use_lora", False) or getattr(self, "quantization", None) or getattr(self, "offload_to_cpu", False):
+                logger.info("[native-dit] LoRA / quantization / CPU offload active; keeping the PyTorch path")
+                self.use_native_dit, self.native_dit = False, None
+                return False
+            from .dit import NativeDit
+            cfg = DitConfig.from_reference(self.model.config) if not isinstance(getattr(self.model, "config", None), DitConfig) \
+                else self.model.config
+            dit = NativeDit(cfg, self.device)
+            dit.load_state_dict(self.model.decoder.state_dict())
+            self.native_dit, self.use_native_dit = dit, True
+            logger.info("[native-dit] decoder packed for gfx950 (%d layers, hidden %d)", cfg.num_hidden_layers, cfg.hidden_size)
+            return True
+        except Exception as exc:  # same policy as handler/mlx_dit_init.py:36-43
+            logger.warning("[native-dit] init failed (%s: %s); PyTorch path stays active", type(exc).__name__, exc)
+            self.use_native_dit, self.native_dit = False, None
+            return False
+
+    def _native_run_diffusion(
+        self,
+        encoder_hidden_states,
+        encoder_attention_mask,
+        context_latents,
+        src_latents,
+        seed,
+        infer_method: str = "ode",
+        shift: float = 3.0,
+        timesteps=None,
+        audio_cover_strength: float = 1.0,
+        encoder_hidden_states_non_cover=None,
+        encoder_attention_mask_non_cover=None,
+        context_latents_non_cover=None,
+        disable_tqdm: bool = False,
+        # base/sft knobs the MLX path lacks (handler/service_generate_execute.py:78-104)
+        infer_steps: int = 30,
+        guidance_scale: float = 7.0,
+        cfg_interval_start: float = 0.0,
+        cfg_interval_end: float = 1.0,
+        use_adg: bool = False,
+        cover_noise_strength: float = 0.0,
+    ) -> Dict[str, Any]:
+        """Same contract as ``_mlx_run_diffusion`` (handler/diffusion.py:18-140): returns
+        ``{"target_latents": Tensor[B,T,64] on self.device in self.dtype, "time_costs": {...}}``.
+        The attention masks are accepted and unused: the DiT discards them (modeling_acestep_v15_base.py:1384-1385)."""
+        _ = encoder_attention_mask, encoder_attention_mask_non_cover, disable_tqdm
+        for attr in ("native_dit", "device", "dtype", "model"):
+            if not hasattr(self, attr):
+                raise AttributeError(f"NativeDitMixin host is missing required attribute '{attr}'")
+        if self.native_dit is None:
+            raise RuntimeError("native DiT backend is not initialised (call _init_native_dit)")
+        if infer_method not in {"ode", "sde"}:
+            raise ValueError(f"Unsupported infer_method '{infer_method}'. Expected 'ode' or 'sde'.")
+        if timesteps is not None and not (hasattr(timesteps, "__iter__") or hasattr(timesteps, "tolist")):
+            raise TypeError("timesteps must be iterable, tensor-like, or None")
+        if encoder_hidden_states.shape[0] != context_latents.shape[0]:
+            raise ValueError("Batch dimension mismatch: encoder_hidden_states and context_latents must share dim 0")
+        if encoder_hidden_states.shape[0] != src_latents.shape[0]:
+            raise ValueError("Batch dimension mismatch: encoder_hidden_states and src_latents must share dim 0")
+        if encoder_hidden_states_non_cover is not None and encoder_hidden_states_non_cover.shape[0] != encoder_hidden_states.shape[0]:
+            raise ValueError("Batch dimension mismatch: encoder_hidden_states_non_cover must share dim 0 with encoder_hidden_states")
+        if context_latents_non_cover is not None and context_latents_non_cover.shape[0] != context_latents.shape[0]:
+            raise ValueError("Batch dimension mismatch: context_latents_non_cover must share dim 0 with context_latents")
+        ts_list = None
+        if timesteps is not None:
+            ts_list = timesteps.tolist() if hasattr(timesteps, "tolist") else list(timesteps)
+        from .dit import generate_latents
+        out = generate_latents(
+            self.native_dit, self.model.null_condition_emb.detach(), encoder_hidden_states, context_latents, seed=seed,
+            infer_method=infer_method, infer_steps=infer_steps, diffusion_guidance_sale=guidance_scale,
+            cfg_interval_start=cfg_interval_start, cfg_interval_end=cfg_interval_end, use_adg=use_adg, shift=shift,
+            timesteps=ts_list, audio_cover_strength=audio_cover_strength, cover_noise_strength=cover_noise_strength,
+            src_latents=src_latents, encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
+            context_latents_non_cover=context_latents_non_cover)
+        out["target_latents"] = out["target_latents"].to(device=self.device, dtype=self.dtype)
+        return out
+
+
+class NativeVaeMixin:
+    """Required host attributes: ``vae`` (state_dict + config) or ``vae_state_dict``/``vae_config``, ``device``."""
+
+    use_native_vae: bool = False
+    native_vae = None
+
+    def _init_native_vae(self) -> bool:
+        """Counterpart of ``_init_mlx_vae``: fuse weight-norm + pack from the loaded ``AutoencoderOobleck``. Never raises."""
+        try:
+            from .vae import NativeVae
+            vae_mod = getattr(self, "vae", None)
+            cfg = getattr(self, "vae_config", None)
+            if cfg is None:
+                cfg = VaeConfig.from_reference(vae_mod.config)
+            sd = getattr(self, "vae_state_dict", None) or vae_mod.state_dict()
+            nv = NativeVae(cfg, self.device)
+            nv.load_state_dict(sd)
+            self.native_vae, self.use_native_vae = nv, True
+            logger.info("[native-vae] decoder packed for gfx950 (hop %d)", nv.hop)
+            return True
+        except Exception as exc:
+            logger.warning("[native-vae] init failed (%s: %s); PyTorch path stays active", type(exc).__name__, exc)
+            self.use_native_vae, self.native_vae = False, None
+            return False
+
+    def _native_vae_decode(self, latents: torch.Tensor) -> torch.Tensor:
+        """``latents [B,64,T]`` -> fp32 waveform ``[B,2,hop*T]`` on the device (``_mlx_vae_decode`` returns CPU fp32;
+        both are accepted downstream: ``.float()``, ``amax``, ``.cpu()`` follow, handler/generate_music_decode.py:191)."""
+        if self.native_vae is None:
+            raise RuntimeError("native VAE backend is not initialised (call _init_native_vae)")
+        return self.native_vae.decode(latents)
+
+    def tiled_decode(self, latents, chunk_size: Optional[int] = None, overlap: int = 64, offload_wav_to_cpu: Optional[bool] = None):
+        """Same signature as handler/vae_decode.py:16-85.  Native fast path first (whole-sequence decode, which equals
+        the overlap-discard tiling up to fp summation order); on failure the host's PyTorch
+        ``_tiled_decode_inner`` runs if the host has one, exactly like the MLX seam (handler/vae_decode.py:39-48)."""
+        if self.use_native_vae and self.native_vae is not None:
+            try:
+                return self._native_vae_decode(latents)
+            except Exception as exc:
+                logger.warning("[tiled_decode] native VAE decode failed (%s: %s)", type(exc).__name__, exc)
+                if not hasattr(self, "_tiled_decode_inner"):
+                    raise
+        if not hasattr(self, "_tiled_decode_inner"):
+            raise RuntimeError("no VAE decode backend available")
+        if chunk_size is None:
+            chunk_size = self._get_auto_decode_chunk_size()
+        if offload_wav_to_cpu is None:
+            offload_wav_to_cpu = self._should_offload_wav_to_cpu()
+        return self._tiled_decode_inner(latents, chunk_size, overlap, offload_wav_to_cpu)
+
+
+class _ModelShell:
+    """What the mixins read from ``self.model``: decoder state dict, null embedding, config."""
+
+    class _Dec:
+        def __init__(self, sd):
+            self._sd = sd
+
+        def state_dict(self):
+            return self._sd
+
+    def __init__(self, cfg: DitConfig, decoder_sd: Dict[str, torch.Tensor], null_condition_emb: torch.Tensor):
+        self.config = cfg
+        self.decoder = self._Dec(decoder_sd)
+        self.null_condition_emb = null_condition_emb
+
+
+class NativeHandler(NativeDitMixin, NativeVaeMixin):
+    """Self-contained counterpart of ``AceStepHandler`` for the denoise + decode path.
+
+    Differences from the reference handler are confined to what is out of scope: conditioning arrives pre-embedded
+    (``encoder_hidden_states``, ``context_latents``) instead of captions/lyrics; there is no LM phase.
+    """
+
+    sample_rate = 48000  # acestep/handler.py:120
+
+    def __init__(self):
+        self.model = None
+        self.vae = None
+        self.device = "cpu"
+        self.dtype = torch.float32
+        self.use_lora = False
+        self.quantization = None
+        self.offload_to_cpu = False
+        self.current_offload_cost = 0.0
+
+    def initialize_service(self, dit_config: DitConfig, decoder_state_dict: Dict[str, torch.Tensor],
+                           null_condition_emb: torch.Tensor, vae_config: Optional[VaeConfig] = None,
+                           vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, device: str = "auto",
+                           use_native: bool = True):
+        """Counterpart of ``initialize_service`` (handler/init_service_orchestrator.py:15-110) for pre-loaded weights.
+        Re-entry is allowed (:30-31).  Returns ``(status_message, success)`` like the reference."""
+        try:
+            if device == "auto":
+                device = "cuda" if torch.cuda.is_available() else "cpu"
+            if device == "cuda":
+                device = f"cuda:{torch.cuda.current_device()}"
+            self.device = device
+            self.dtype = torch.bfloat16 if str(device).startswith("cuda") else torch.float32  # orchestrator :51
+            self.model = _ModelShell(dit_config, decoder_state_dict, null_condition_emb)
+            self.vae_config, self.vae_state_dict = vae_config, vae_state_dict
+            if not use_native:
+                return "native backend disabled", False
+            if not str(device).startswith("cuda"):
+                raise RuntimeError("the native backend needs a ROCm GPU (no CPU fallback)")
+            ok = self._init_native_dit()
+            if ok and vae_state_dict is not None:
+                ok = self._init_native_vae()
+            return ("native backend ready" if ok else "native backend failed to initialise"), bool(ok)
+        except Exception as exc:
+            logger.exception("initialize_service failed")
+            return f"Error: {exc!s}", False
+
+    # ------------------------------------------------------------------ service_generate
+    def service_generate(self, encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor,
+                         src_latents: Optional[torch.Tensor] = None, seed: Union[int, List[int], None] = None,
+                         infer_steps: int = 30, guidance_scale: float = 7.0, audio_cover_strength: float = 1.0,
+                         cover_noise_strength: float = 0.0, infer_method: str = "ode", use_adg: bool = False,
+                         cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0, shift: float = 1.0,
+                         timesteps: Optional[Sequence[float]] = None, encoder_hidden_states_non_cover=None,
+                         context_latents_non_cover=None) -> Dict[str, Any]:
+        """The diffusion half of ``service_generate`` (handler/service_generate.py:21-146) from prepared conditions."""
+        B = context_latents.shape[0]
+        if B > MAX_BATCH_SIZE:  # handler/service_generate_request.py:66-75 clamps; we refuse explicitly
+            raise ValueError(f"batch size {B} exceeds the per-call cap of {MAX_BATCH_SIZE}")
+        if src_latents is None:
+            src_latents = context_latents[..., : context_latents.shape[-1] // 2]
+        with torch.inference_mode():
+            outputs = self._native_run_diffusion(
+                encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=None, context_latents=context_latents,
+                src_latents=src_latents, seed=seed, infer_method=infer_method, shift=shift, timesteps=timesteps,
+                audio_cover_strength=audio_cover_strength, encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
+                context_latents_non_cover=context_latents_non_cover, infer_steps=infer_steps, guidance_scale=guidance_scale,
+                cfg_interval_start=cfg_interval_start, cfg_interval_end=cfg_interval_end, use_adg=use_adg,
+                cover_noise_strength=cover_noise_strength)
+        outputs.update({"src_latents": src_latents, "encoder_hidden_states": encoder_hidden_states,
+                        "context_latents": context_latents, "encoder_attention_mask": None})
+        return outputs
+
+    # ------------------------------------------------------------------ generate_music
+    def generate_music(self, encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor, seed=None,
+                       inference_steps: int = 27, guidance_scale: float = 7.0, shift: float = 1.0, infer_method: str = "ode",
+                       timesteps=None, use_tiled_decode: bool = True, latent_shift: float = 0.0, latent_rescale: float = 1.0,
+                       cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0, use_adg: bool = False,
+                       progress=None, **service_kwargs) -> Dict[str, Any]:
+        """Counterpart of ``AceStepHandler.generate_music`` (handler/generate_music.py:22-190) from prepared conditions.
+        Never raises: every exception becomes the reference's error payload."""
+        try:
+            if progress:
+                progress(0.52, desc="Generating music...")
+            outputs = self.service_generate(encoder_hidden_states, context_latents, seed=seed, infer_steps=inference_steps,
+                                            guidance_scale=guidance_scale, shift=shift, infer_method=infer_method,
+                                            timesteps=timesteps, cfg_interval_start=cfg_interval_start,
+                                            cfg_interval_end=cfg_interval_end, use_adg=use_adg, **service_kwargs)
+            pred_latents, time_costs = self._prepare_decode_state(outputs, latent_shift, latent_rescale)
+            if progress:
+                progress(0.8, desc="Decoding audio...")
+            t0 = time.time()
+            with torch.inference_mode():
+                pred_latents_cpu = pred_latents.detach().cpu()
+                z = pred_latents.transpose(1, 2).contiguous()  # handler/generate_music_decode.py:123
+                pred_wavs = self.tiled_decode(z) if use_tiled_decode else self._native_vae_decode(z)
+                if pred_wavs.dtype != torch.float32:
+                    pred_wavs = pred_wavs.float()
+                if pred_wavs.is_cuda:
+                    from .vae import peak_normalize
+                    pred_wavs = peak_normalize(pred_wavs.contiguous())
+                else:
+                    peak = pred_wavs.abs().amax(dim=[1, 2], keepdim=True)
+                    if torch.any(peak > 1.0):
+                        pred_wavs = pred_wavs / peak.clamp(min=1.0)
+                if pred_wavs.is_cuda:
+                    torch.cuda.synchronize(pred_wavs.device)
+            time_costs["vae_decode_time_cost"] = time.time() - t0
+            time_costs["total_time_cost"] = time_costs["total_time_cost"] + time_costs["vae_decode_time_cost"]
+            time_costs["offload_time_cost"] = self.current_offload_cost
+            B = pred_wavs.shape[0]
+            audios = [{"tensor": pred_wavs[i].cpu(), "sample_rate": self.sample_rate} for i in range(B)]
+            seed_value = seed[0] if isinstance(seed, (list, tuple)) and seed else seed
+            extra = {"pred_latents": pred_latents_cpu, "target_latents": None,
+                     "src_latents": outputs["src_latents"].detach().cpu(), "chunk_masks": None, "latent_masks": None, "spans": [],
+                     "time_costs": time_costs, "seed_value": seed_value,
+                     "encoder_hidden_states": outputs["encoder_hidden_states"].detach().cpu(), "encoder_attention_mask": None,
+                     "context_latents": outputs["context_latents"].detach().cpu(), "lyric_token_idss": None}
+            return {"audios": audios, "status_message": "Generation completed successfully!", "extra_outputs": extra,
+                    "success": True, "error": None}
+        except Exception as exc:  # handler/generate_music.py:181-190
+            logger.exception("[generate_music] Generation failed")
+            return {"audios": [], "status_message": f"Error: {exc!s}\n{traceback.format_exc()}", "extra_outputs": {},
+                    "success": False, "error": f"{exc!s}"}
+
+    def _prepare_decode_state(self, outputs: Dict[str, Any], latent_shift: float, latent_rescale: float):
+        """handler/generate_music_decode.py:16-96: NaN/Inf and all-zero guards, latent * rescale + shift."""
+        pred = outputs["target_latents"]
+        time_costs = outputs["time_costs"]
+        time_costs["offload_time_cost"] = self.current_offload_cost
+        if pred.is_cuda:
+            from .vae import latent_check
+            bad, zero = latent_check(pred)
+        else:
+            bad = bool(torch.isnan(pred).any() or torch.isinf(pred).any())
+            zero = bool(pred.numel() > 0 and pred.abs().sum() == 0)
+        if bad:
+            raise RuntimeError("Generation produced NaN or Inf latents. This usually indicates a checkpoint/config mismatch "
+                               "or unsupported quantization/backend combination.")
+        if zero:
+            raise RuntimeError("Generation produced zero latents. This usually indicates a checkpoint/config mismatch or unsupported setup.")
+        if latent_shift != 0.0 or latent_rescale != 1.0:
+            pred = pred * latent_rescale + latent_shift
+        return pred.float(), time_costs

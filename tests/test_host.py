@@ -1,0 +1,148 @@
+"""CPU: host-side logic of the product package (no GPU, no native compute), in the reference's mixin-host stub style
+(handler/diffusion_test.py, handler/vae_decode_mixin_test.py)."""
+import math
+
+import pytest
+import torch
+
+import ace355
+from ace355 import weightgen
+from ace355.backend import NativeDitMixin, NativeHandler, NativeVaeMixin
+from ace355.dit import prepare_noise, schedule
+
+
+def test_config_matches_reference_constants():
+    c = ace355.DitConfig()
+    assert (c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.head_dim) == \
+        (2048, 6144, 24, 16, 8, 128)
+    assert c.layer_types[0] == "sliding_attention" and c.layer_types[1] == "full_attention"  # cfg.py:251-254
+    shapes = c.weight_shapes()
+    assert len(shapes) == 476 and sum(math.prod(s) for s in shapes.values()) == 1575458880  # 1.575 B
+    v = ace355.VaeConfig()
+    assert v.hop == 1920 and v.upsampling_ratios == (10, 6, 4, 4, 2)
+    assert [d[:2] for d in v.block_dims()] == [(2048, 1024), (1024, 512), (512, 256), (256, 128), (128, 128)]
+
+
+def test_oracle_and_product_agree_on_names():
+    from oracle import dit as o_dit
+    from oracle import oobleck as o_vae
+    assert ace355.DitConfig().weight_shapes() == o_dit.dit_weight_shapes(o_dit.DitConfig())
+    assert ace355.VaeConfig().weight_shapes() == o_vae.decoder_weight_shapes(o_vae.VaeConfig())
+
+
+def test_weightgen_is_deterministic_and_per_tensor():
+    c = ace355.DitConfig(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1)
+    a = weightgen.make_dit_weights(c.weight_shapes(), 256, seed=3, mode="test")
+    one = weightgen.make_dit_weights({"layers.1.mlp.up_proj.weight": (768, 256)}, 256, seed=3, mode="test")
+    assert torch.equal(a["layers.1.mlp.up_proj.weight"], one["layers.1.mlp.up_proj.weight"])
+    b = weightgen.make_dit_weights(c.weight_shapes(), 256, seed=4, mode="test")
+    assert not torch.equal(a["layers.0.mlp.up_proj.weight"], b["layers.0.mlp.up_proj.weight"])
+    init = weightgen.make_dit_weights(c.weight_shapes(), 256, seed=3, mode="init")
+    assert float(init["proj_in.1.bias"].abs().sum()) == 0 and float(init["norm_out.weight"].sum()) == 256
+
+
+def test_prepare_noise_follows_reference_cpu_semantics():
+    from oracle import sampler as o_sampler
+    a = prepare_noise((3, 11, 64), [5, -1, 7])
+    b = o_sampler.prepare_noise((3, 11, 64), [5, -1, 7])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and not torch.equal(a[1], b[1])  # seed < 0 -> random
+    assert torch.equal(prepare_noise((2, 4, 64), 9), o_sampler.prepare_noise((2, 4, 64), 9))
+    assert schedule(27, 1.0).dtype == torch.float32 and float(schedule(27, 3.0)[0]) == 1.0
+    assert torch.equal(schedule(0, 1.0, [1.0, 0.5, 0.0]), torch.tensor([1.0, 0.5, 0.0]))
+
+
+class _DitHost(NativeDitMixin):
+    def __init__(self):
+        self.device, self.dtype = "cpu", torch.float32
+        self.model = type("M", (), {"null_condition_emb": torch.zeros(1, 1, 8)})()
+        self.native_dit = object()
+
+
+def _args(B=2, T=6, L=3, D=8):
+    return dict(encoder_hidden_states=torch.zeros(B, L, D), encoder_attention_mask=None, context_latents=torch.zeros(B, T, 128),
+                src_latents=torch.zeros(B, T, 64), seed=[1, 2])
+
+
+def test_native_run_diffusion_validation_mirrors_mlx_seam():
+    h = _DitHost()
+    with pytest.raises(ValueError, match="Unsupported infer_method"):
+        h._native_run_diffusion(**_args(), infer_method="euler")
+    with pytest.raises(TypeError, match="timesteps"):
+        h._native_run_diffusion(**_args(), timesteps=3.0)
+    bad = _args()
+    bad["context_latents"] = torch.zeros(3, 6, 128)
+    with pytest.raises(ValueError, match="Batch dimension mismatch"):
+        h._native_run_diffusion(**bad)
+    bad = _args()
+    bad["src_latents"] = torch.zeros(1, 6, 64)
+    with pytest.raises(ValueError, match="src_latents"):
+        h._native_run_diffusion(**bad)
+    with pytest.raises(ValueError, match="non_cover"):
+        h._native_run_diffusion(**_args(), encoder_hidden_states_non_cover=torch.zeros(5, 3, 8))
+    h2 = _DitHost()
+    del h2.native_dit
+    NativeDitMixin.native_dit  # class default exists; instance without init is reported as uninitialised
+    h2.native_dit = None
+    with pytest.raises(RuntimeError, match="not initialised"):
+        h2._native_run_diffusion(**_args())
+    h3 = _DitHost()
+    del h3.dtype
+    with pytest.raises(AttributeError, match="dtype"):
+        h3._native_run_diffusion(**_args())
+
+
+def test_init_native_refuses_lora_quant_offload_and_never_raises():
+    for flag in ("use_lora", "quantization", "offload_to_cpu"):
+        h = _DitHost()
+        setattr(h, flag, True if flag != "quantization" else "int8_weight_only")
+        assert h._init_native_dit() is False and h.use_native_dit is False and h.native_dit is None
+    h = _DitHost()
+    h.model = object()  # no config / decoder: failure is swallowed like handler/mlx_dit_init.py:36-43
+    assert h._init_native_dit() is False
+
+
+class _VaeHost(NativeVaeMixin):
+    def __init__(self):
+        self.device = "cpu"
+        self.calls = []
+
+    def _get_auto_decode_chunk_size(self):
+        return 512
+
+    def _should_offload_wav_to_cpu(self):
+        return False
+
+    def _tiled_decode_inner(self, latents, chunk_size, overlap, offload):
+        self.calls.append((chunk_size, overlap, offload))
+        return torch.ones(latents.shape[0], 2, latents.shape[-1] * 2)
+
+
+def test_tiled_decode_native_first_then_pytorch_fallback():
+    h = _VaeHost()
+    out = h.tiled_decode(torch.zeros(1, 64, 5))  # native not initialised -> host PyTorch path (vae_decode.py:50-85)
+    assert out.shape == (1, 2, 10) and h.calls == [(512, 64, False)]
+    h.use_native_vae, h.native_vae = True, type("V", (), {"decode": lambda self, z: (_ for _ in ()).throw(RuntimeError("boom"))})()
+    out = h.tiled_decode(torch.zeros(1, 64, 5), chunk_size=128, overlap=16)  # failure -> fallback (vae_decode.py:44-48)
+    assert out.shape == (1, 2, 10) and h.calls[-1] == (128, 16, False)
+    h.native_vae = type("V", (), {"decode": lambda self, z: torch.full((1, 2, 7), 3.0)})()
+    assert float(h.tiled_decode(torch.zeros(1, 64, 5)).mean()) == 3.0 and len(h.calls) == 2
+
+
+def test_generate_music_never_raises_and_returns_reference_payload_shape():
+    h = NativeHandler()  # not initialised: no native backend
+    res = h.generate_music(torch.zeros(1, 3, 8), torch.zeros(1, 4, 128), seed=[1])
+    assert res["success"] is False and res["audios"] == [] and res["extra_outputs"] == {} and isinstance(res["error"], str)
+    assert set(res) == {"audios", "status_message", "extra_outputs", "success", "error"}  # handler/generate_music.py:181-190
+    msg, ok = h.initialize_service(ace355.DitConfig(), {}, torch.zeros(1, 1, 2048), device="cpu")
+    assert ok is False and "GPU" in msg
+    with pytest.raises(ValueError, match="per-call cap"):
+        h.service_generate(torch.zeros(9, 3, 8), torch.zeros(9, 4, 128))
+
+
+def test_flop_model_matches_survey():
+    import bench
+    S, L = 375, 769
+    f = bench.dit_flops_per_forward_per_seq(ace355.DitConfig(), S, L)
+    assert abs(f / 1e12 - 1.136) < 0.002  # SURVEY 8d / BASELINE.md section 4
+    assert abs(bench.vae_flops_per_frame(ace355.VaeConfig()) / 1e9 - 4.874) < 0.002
+    assert abs(bench.dit_flops_per_forward_per_seq(ace355.DitConfig(), 125, L) / 1e12 - 0.375) < 0.001

@@ -74,6 +74,8 @@ struct GemmEpilogue {
     const float* g2;
     int g2_stride;
     int rows_per_seq;
+    const float* cvec;  // mode 2: rows m >= cvec_row0 additionally get + cvec[n] (constant cross-attention term of broadcast slots)
+    int cvec_row0;
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
@@ -110,6 +112,7 @@ int launch_pack_xin(const float* x, const float* ctx, bf16_t* xin, int N, int T,
 int launch_set_xin_latent(const float* xt, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s);
 int launch_set_xin_ctx(const float* ctx, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s);
 int launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
+int launch_expand_kv_heads(const bf16_t* v_row, bf16_t* out, int hq, int hkv, hipStream_t s);
 int launch_bcast_rows(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s);
 int launch_copy_v(const float* vpad, float* v, int N, int T, int Tpad, hipStream_t s);
 int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, bf16_t* xin, int copies, int B, int T,

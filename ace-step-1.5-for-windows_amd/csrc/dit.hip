@@ -31,6 +31,8 @@ struct CondSlot {
     bf16_t* kv = nullptr;  // [layers][L][2*KVD]   (K | V rows as produced by the GEMM; K head-normed in place)
     bf16_t* vt = nullptr;  // [layers][KVH][128][Lpad]
     bool valid = false;
+    bool broadcast = false;       // all L keys identical (rows == 1): cross-attention output is a per-layer constant
+    float* cross_const = nullptr; // [layers][D] = o_proj(v) of that constant, fp32
 };
 
 }  // namespace
@@ -266,6 +268,14 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ACE_CHECK(h->slots[slots[i]].L == L, "forward: all condition slots of one call must share L");
     }
     const int Lpad = ((L + 63) / 64) * 64;
+    // trailing sequences that attend a broadcast slot (the CFG null branch) skip cross-attention entirely: their
+    // residual term is the slot's per-layer constant, folded into the self-attention epilogue below.
+    int n_sc = 0;
+    while (n_sc < N && h->slots[slots[N - 1 - n_sc]].broadcast) ++n_sc;
+    for (int i = N - n_sc; i < N; ++i)
+        if (slots[i] != slots[N - 1]) { n_sc = 0; break; }  // one constant per call
+    const int Nc = N - n_sc, Mc = Nc * S;
+    const float* cconst = n_sc ? h->slots[slots[N - 1]].cross_const : nullptr;
 
     // patchify: Conv1d(192 -> D, k=2, s=2) == GEMM over [M, 384] (base.py:1358)
     ep = GemmEpilogue{1, h->b_in, nullptr, nullptr, 0, 0};
@@ -311,23 +321,24 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             rc = launch_attention(a, s);
             if (rc) return rc;
         }
-        ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S};
+        ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S, cconst ? cconst + (size_t)li * D : nullptr, Mc};
         rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
 
         // ---- cross attention (base.py:515-526): un-modulated norm, plain residual, cached K/V, no RoPE
-        rc = launch_rmsnorm_mod(h->h, W.n_ca, h->xn, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
+        if (Nc > 0) {
+        rc = launch_rmsnorm_mod(h->h, W.n_ca, h->xn, Mc, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
-        rc = gemm(h, h->xn, D, W.wq_c, D, h->qkv, QD, M, QD, D, ep, s);
+        rc = gemm(h, h->xn, D, W.wq_c, D, h->qkv, QD, Mc, QD, D, ep, s);
         if (rc) return rc;
-        rc = launch_headnorm_rope(h->qkv, M, QD, 0, h->HQ, W.qn_c, eps, nullptr, nullptr, S, s);
+        rc = launch_headnorm_rope(h->qkv, Mc, QD, 0, h->HQ, W.qn_c, eps, nullptr, nullptr, S, s);
         if (rc) return rc;
         {
             AttnArgs a{};
             a.q = h->qkv; a.q_seq_stride = (long)S * QD; a.q_row_stride = QD;
             a.use_tab = 1;
-            for (int i = 0; i < N; ++i) {
+            for (int i = 0; i < Nc; ++i) {
                 const CondSlot& cs = h->slots[slots[i]];
                 a.k_tab[i] = (unsigned long long)(cs.kv + (size_t)li * cs.L * 2 * KVD);
                 a.vt_tab[i] = (unsigned long long)(cs.vt + (size_t)li * h->KVH * 128 * cs.Lpad);
@@ -335,15 +346,16 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.k_head_stride = 128; a.k_row_stride = 2 * KVD;
             a.vt_head_stride = 128L * Lpad; a.vt_ld = Lpad;
             a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
-            a.N = N; a.Sq = S; a.Skv = L; a.Hq = h->HQ; a.Hkv = h->KVH; a.window = -1; a.scale = scale;
+            a.N = Nc; a.Sq = S; a.Skv = L; a.Hq = h->HQ; a.Hkv = h->KVH; a.window = -1; a.scale = scale;
             EvScope ev(h, &h->attn_ev, s);
-            if (h->profile) h->attn_flops += 4.0 * N * h->HQ * (double)S * L * 128.0;
+            if (h->profile) h->attn_flops += 4.0 * Nc * h->HQ * (double)S * L * 128.0;
             rc = launch_attention(a, s);
             if (rc) return rc;
         }
         ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};
-        rc = gemm(h, h->ao, QD, W.wo_c, QD, h->h, D, M, D, QD, ep, s);
+        rc = gemm(h, h->ao, QD, W.wo_c, QD, h->h, D, Mc, D, QD, ep, s);
         if (rc) return rc;
+        }
 
         // ---- SwiGLU MLP (base.py:530-533)
         rc = launch_rmsnorm_mod(h->h, W.n_mlp, h->xn, M, D, eps, W.sst + 4 * D, h->tproj + 4 * D, W.sst + 3 * D, h->tproj + 3 * D,
@@ -428,6 +440,7 @@ void ace355_dit_destroy(ace355_dit* h) {
     for (CondSlot& c : h->slots) {
         if (c.kv) hipFree(c.kv);
         if (c.vt) hipFree(c.vt);
+        if (c.cross_const) hipFree(c.cross_const);
     }
     if (h->stage) hipFree(h->stage);
     if (h->enc_bf) hipFree(h->enc_bf);
@@ -501,7 +514,7 @@ int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int 
         ACE_HIP(hipStreamSynchronize(s));
         if (h->enc_bf) hipFree(h->enc_bf);
         if (h->enc_emb) hipFree(h->enc_emb);
-        ACE_HIP(hipMalloc((void**)&h->enc_bf, (size_t)L * D * 2 + 256));
+        ACE_HIP(hipMalloc((void**)&h->enc_bf, ((size_t)L * D + h->QD) * 2 + 256));
         ACE_HIP(hipMalloc((void**)&h->enc_emb, (size_t)2 * L * D * 2 + 256));
         h->enc_cap = L;
     }
@@ -514,6 +527,7 @@ int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int 
         ACE_HIP(hipMalloc((void**)&cs.vt, (size_t)h->NL * h->KVH * 128 * Lpad * 2 + 256));
         cs.cap = L;
     }
+    if (!cs.cross_const) ACE_HIP(hipMalloc((void**)&cs.cross_const, (size_t)h->NL * D * 4 + 256));
     cs.valid = false;
     int rc = launch_f32_to_bf16(enc_dev, h->enc_bf, (long)rows * D, s);
     if (rc) return rc;
@@ -538,7 +552,17 @@ int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int 
         if (rc) return rc;
         rc = launch_transpose_v(kv, 2 * KVD, KVD, 1, L, h->KVH, cs.vt + (size_t)li * h->KVH * 128 * Lpad, Lpad, s);
         if (rc) return rc;
+        if (rows == 1) {
+            // softmax over L identical keys is uniform, so cross-attention returns V's (single) row for every query:
+            // the layer's cross-attention residual is the constant o_proj(expand_heads(v)) ("degenerate null branch")
+            rc = launch_expand_kv_heads(kv + KVD, h->enc_bf, h->HQ, h->KVH, s);  // enc_bf is free again (>= D >= QD elements? see check)
+            if (rc) return rc;
+            ep = GemmEpilogue{1, nullptr, nullptr, nullptr, 0, 0};
+            rc = gemm(h, h->enc_bf, h->QD, W.wo_c, h->QD, cs.cross_const + (size_t)li * D, D, 1, D, h->QD, ep, s);
+            if (rc) return rc;
+        }
     }
+    cs.broadcast = rows == 1;
     cs.L = L;
     cs.Lpad = Lpad;
     cs.valid = true;

@@ -219,6 +219,14 @@ __global__ void bcast_rows_kernel(const bf16_t* __restrict__ in, bf16_t* __restr
     out[i] = in[i % cols];
 }
 
+// attention output row of a sequence whose keys are all identical: out[h*128+d] = v[(h / group)*128 + d]
+__global__ void expand_kv_heads_kernel(const bf16_t* __restrict__ v_row, bf16_t* __restrict__ out, int hq, int hkv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hq * 128) return;
+    const int h = i >> 7, d = i & 127;
+    out[i] = v_row[(h / (hq / hkv)) * 128 + d];
+}
+
 __global__ void copy_v_kernel(const float* __restrict__ vpad, float* __restrict__ v, int T, int Tpad, long total) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 units: N*T*16
     if (i >= total) return;
@@ -472,6 +480,11 @@ int launch_set_xin_ctx(const float* ctx, bf16_t* xin, int B, int copies, int T, 
 
 int launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s) {
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, s, in, out, n);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_expand_kv_heads(const bf16_t* v_row, bf16_t* out, int hq, int hkv, hipStream_t s) {
+    hipLaunchKernelGGL(expand_kv_heads_kernel, dim3((hq * 128 + 255) / 256), dim3(256), 0, s, v_row, out, hq, hkv);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -49,7 +49,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __rest
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + frow;
         if (n >= N) continue;
-        float bias = 0.f, g1 = 1.f;
+        float bias = 0.f, g1 = 1.f, cv = 0.f;
+        if (MODE == 2 && ep.cvec) cv = ep.cvec[n];
         if (MODE <= 1 && ep.bias) bias = ep.bias[n];
         if (MODE == 2 && ep.g1) g1 = ep.g1[n];
 #pragma unroll
@@ -78,7 +79,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __rest
                         gate = g1 + ep.g2[(long)seq * ep.g2_stride + n];
                     }
                     float* h = reinterpret_cast<float*>(Cv) + (long)m * ldc + n;
-                    *h = *h + gate * v;
+                    float add = gate * v;
+                    if (ep.cvec && m >= ep.cvec_row0) add += cv;
+                    *h = *h + add;
                 }
             }
         }

@@ -28,20 +28,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
     char* Ks = smem;
     char* Vs = smem + 16384;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
     const int hkv = h / (a.Hq / a.Hkv);
     const int q0 = qb * QB;
     const int lq = lane & 31, half = lane >> 5;
-    const int qrow = q0 + wave * 32 + lq;  // this lane's query row
+    const int qw0 = q0 + wave * 32;        // first query row of this wave
+    const int qrow = qw0 + lq;             // this lane's query row
     const int qrow_c = min(qrow, a.Sq - 1);
+    const int win = a.window < 0 ? (1 << 28) : a.window;  // "no band" as a band wider than any sequence
 
     // Q fragments (B operand of S^T = K Q^T): lane holds q = lq, d = ks*16 + half*8 .. +8
     bf16x8 qf[8];
     {
         const bf16_t* qp = a.q + (long)n * a.q_seq_stride + (long)qrow_c * a.q_row_stride + h * 128 + half * 8;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(qp + ks * 16));
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
     }
 
     f32x16 o[4];
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;  // running max in log2-scaled units
 
     // key tile range for this query block
     int kt_lo = 0, kt_hi = (a.Skv + KB - 1) / KB;
@@ -61,27 +64,47 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
     const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
     const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
 
+    // staging assignment: K chunk c = tid + i*256 -> key = (tid>>4) + 16 i, slot = tid & 15;
+    //                     V^T chunk            -> d = (tid>>3) + 32 i, j = tid & 7
+    const int skey = tid >> 4, sslot = tid & 15, sd = tid >> 3, sj = tid & 7;
+    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+#define LOAD_KV(key0_)                                                                                          \
+    {                                                                                                           \
+        const bf16_t* kp_ = kbase + sslot * 8;                                                                  \
+        rk0 = ldg16(kp_ + (long)min((key0_) + skey, a.Skv - 1) * a.k_row_stride);      \
+        rk1 = ldg16(kp_ + (long)min((key0_) + skey + 16, a.Skv - 1) * a.k_row_stride); \
+        rk2 = ldg16(kp_ + (long)min((key0_) + skey + 32, a.Skv - 1) * a.k_row_stride); \
+        rk3 = ldg16(kp_ + (long)min((key0_) + skey + 48, a.Skv - 1) * a.k_row_stride); \
+        const bf16_t* vp_ = vbase + (key0_) + sj * 8;                                                           \
+        rv0 = ldg16(vp_ + (long)(sd)*a.vt_ld);                                        \
+        rv1 = ldg16(vp_ + (long)(sd + 32) * a.vt_ld);                                 \
+        rv2 = ldg16(vp_ + (long)(sd + 64) * a.vt_ld);                                 \
+        rv3 = ldg16(vp_ + (long)(sd + 96) * a.vt_ld);                                 \
+    }
+    // (d>>1)&15 for d = sd + 32 i is i-invariant; so is key&15 for key = skey + 16 i
+    const int vx = (sd >> 1) & 15;
+    const int k_st = skey * 256 + ((sslot ^ (skey & 15)) << 4);
+    const int v_st = sd * 128 + ((sj ^ (vx >> 1)) << 4);
+#define SWAPH(v) ((vx & 1) ? make_uint4((v).z, (v).w, (v).x, (v).y) : (v))  /* 8-B halves swap places under the XOR */
+#define STORE_KV()                                                   \
+    {                                                                \
+        *reinterpret_cast<uint4*>(Ks + k_st) = rk0;                  \
+        *reinterpret_cast<uint4*>(Ks + k_st + 4096) = rk1;           \
+        *reinterpret_cast<uint4*>(Ks + k_st + 8192) = rk2;           \
+        *reinterpret_cast<uint4*>(Ks + k_st + 12288) = rk3;          \
+        *reinterpret_cast<uint4*>(Vs + v_st) = SWAPH(rv0);           \
+        *reinterpret_cast<uint4*>(Vs + v_st + 4096) = SWAPH(rv1);    \
+        *reinterpret_cast<uint4*>(Vs + v_st + 8192) = SWAPH(rv2);    \
+        *reinterpret_cast<uint4*>(Vs + v_st + 12288) = SWAPH(rv3);   \
+    }
+
+    if (kt_lo < kt_hi) LOAD_KV(kt_lo * KB)
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int key0 = kt * KB;
         __syncthreads();  // previous tile fully consumed
-        // ---- stage K tile: 64 keys x 16 slots of 16 B
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256, key = c >> 4, slot = c & 15;
-            const int kr = min(key0 + key, a.Skv - 1);
-            const uint4 v = *reinterpret_cast<const uint4*>(kbase + (long)kr * a.k_row_stride + slot * 8);
-            *reinterpret_cast<uint4*>(Ks + k_off(key, slot)) = v;
-        }
-        // ---- stage V^T tile: 128 d x 8 chunks of 16 B (8 keys)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + i * 256, d = c >> 3, j = c & 7;
-            uint4 v = *reinterpret_cast<const uint4*>(vbase + (long)d * a.vt_ld + key0 + j * 8);
-            const int x = (d >> 1) & 15;
-            if (x & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // the two 8-B halves swap places under the XOR
-            *reinterpret_cast<uint4*>(Vs + d * 128 + ((j ^ (x >> 1)) << 4)) = v;
-        }
+        STORE_KV()
         __syncthreads();
+        if (kt + 1 < kt_hi) LOAD_KV(key0 + KB)  // next tile's HBM/L2 latency hides under this tile's MFMAs
 
         // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
         f32x16 s[2];
@@ -96,41 +119,46 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
             }
         }
 
-        // ---- mask + online softmax (lane owns query qrow; its 32 scores are keys key0 + t2*32 + mfma_row(r))
-        float mx = -INFINITY;
+        // ---- mask (edge tiles only; wave-uniform test) + online softmax.  Lane owns query qrow; its 32 scores are
+        //      keys key0 + t2*32 + (r&3) + 8*(r>>2) + 4*half.
+        const bool interior = (key0 + KB <= a.Skv) && (qw0 + 31 - key0 <= win) && (key0 + KB - 1 - qw0 <= win);
+        if (!interior) {
+            const int kb = key0 + 4 * half;
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+            for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                bool ok = key < a.Skv;
-                if (a.window >= 0) {
-                    const int dlt = qrow - key;
-                    ok = ok && dlt <= a.window && dlt >= -a.window;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb + t2 * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool ok = (key < a.Skv) & ((unsigned)(qrow - key + win) <= (unsigned)(2 * win));
+                    s[t2][r] = ok ? s[t2][r] : -INFINITY;
                 }
-                const float v = ok ? s[t2][r] * scale_log2 : -INFINITY;
-                s[t2][r] = v;
-                mx = fmaxf(mx, v);
-            }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
+        const float m_new = fmaxf(m_run, mx * scale_log2);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[t2][r] - m_use);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t2][r], scale_log2, -m_use));
                 s[t2][r] = p;
                 psum += p;
             }
         l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.0f)) {  // wave-uniform: skip the 64-multiply rescale when no row's max moved
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 
         // ---- O^T[d][q] += sum_key V^T[d][key] P^T[key][q]
         // k-slot e of MFMA step (t2, t) on lane-half `half` <-> key t2*32 + 16t + 4*half + (e&3) + 8*(e>>2):
@@ -156,6 +184,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
                 }
             }
     }
+#undef LOAD_KV
+#undef STORE_KV
+#undef SWAPH
 
     // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = dt*32 + 8g + 4*half + {0..3} for g = 0..3
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

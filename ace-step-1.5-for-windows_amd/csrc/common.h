@@ -33,14 +33,28 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even (inputs are finite on this path)
-    return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// round-to-nearest-even fp32 -> bf16 pair in one v_cvt_pk_bf16_f32 (gfx950)
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf_lo(uint32_t p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+
+// 16-byte load through the GLOBAL address space: a pointer that went through a select / table lookup is "flat" to the
+// compiler, and flat loads also tick lgkmcnt, which would serialise them against every LDS wait.
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    const u32x4_t v = *reinterpret_cast<const __attribute__((address_space(1))) u32x4_t*>(reinterpret_cast<uintptr_t>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 

@@ -264,23 +264,148 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restr
     gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------ v3: counted pipeline
+// hipcc treats the global_load_lds builtin as a store to LDS that may alias the fragment reads and drains it
+// (s_waitcnt vmcnt(0)) before the first ds_read of the same iteration: v2 never overlaps a tile's DMA with MFMAs inside
+// a workgroup.  v3 issues the DMA from inline asm (invisible to the compiler's dependence tracking), keeps NS LDS stages
+// with NS-1 tiles in flight, waits with a COUNTED vmcnt for exactly the tile about to be consumed, and uses the raw
+// s_barrier (no implicit drain).  Per K-step:  wait(tile kt) -> barrier -> issue(tile kt+NS-1) -> MFMAs(tile kt).
+//   RAW: a wave's vmcnt covers its own DMA pieces; the barrier extends that to every wave's pieces.
+//   WAR: tile kt+NS-1 lands in the stage read at kt-1; every wave passed this iteration's barrier after finishing kt-1.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <int MODE, int MT, int NS>
+__global__ __launch_bounds__(256, (NS == 2 ? 2 : 1)) void gemm_pipe_kernel(const bf16_t* __restrict__ A, int lda,
+                                                                            const bf16_t* __restrict__ W, int ldw,
+                                                                            void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                                            GemmEpilogue ep, int tiles_n, int nwg) {
+    constexpr int BMv = MT * 64;
+    constexpr int A_BYTES = BMv * 128;
+    constexpr int STAGE = A_BYTES + 16384;
+    constexpr int AJ = BMv / 32;   // A DMA pieces per wave per tile
+    constexpr int LPT = AJ + 4;    // DMA pieces per wave per tile (A + W)
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
+
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const int m0 = tm * BMv, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int lrow = lane >> 3, pslot = lane & 7;
+    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
+    const bf16_t* a_src[AJ];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + 4 * j) + lrow, M - 1) * lda + sslot * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + 4 * j) + lrow, N - 1) * ldw + sslot * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    auto issue = [&](int kt) {
+        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) glds16_asm(a_src[j] + kt * BK, sb + j * 4096);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_asm(w_src[j] + kt * BK, sb + A_BYTES + j * 4096);
+    };
+    // prologue: NS-1 tiles in flight
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(t);
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles issued so far: min(nk, kt + NS - 1); tile kt must have landed: allow (issued - kt - 1) tiles outstanding
+        const int ahead = min(nk, kt + NS - 1) - kt - 1;
+        if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
+        else if (NS >= 3 && ahead == 1) wait_vmcnt<LPT>();
+        else if (ahead <= 0) wait_vmcnt<0>();
+        else wait_vmcnt<(NS >= 3 ? LPT : 0)>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue(kt + NS - 1);
+        const char* As = smem + (kt % NS) * STAGE;
+        const char* Ws = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[MT], fw[2];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(wm * (MT * 32) + i * 32 + frow, kk * 2 + fhalf)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * 64 + j * 32 + frow, kk * 2 + fhalf)));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
+        }
+        asm volatile("" ::: "memory");  // keep this tile's ds_reads above the next iteration's barrier
+    }
+    gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+}
+
 }  // namespace
 
+static int g_cfg_mt = 0, g_cfg_ns = 0;
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("ACE355_GEMM");  // "v1" = register-staged kernel (A/B testing); default = direct-to-LDS
-        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 2;
+        // ACE355_GEMM = v1 (register-staged) | v2 (DMA, compiler-scheduled) | v3 (DMA, counted pipeline; default)
+        // ACE355_GEMM_CFG = "MT,NS" pins v3's tile height (MT*64) and stage count for experiments.
+        const char* e = getenv("ACE355_GEMM");
+        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : (e && e[0] == 'v' && e[1] == '2') ? 2 : 3;
+        const char* c = getenv("ACE355_GEMM_CFG");
+        if (c && c[0] >= '2' && c[0] <= '4' && c[1] == ',' && c[2] >= '2' && c[2] <= '4') {
+            g_cfg_mt = c[0] - '0';
+            g_cfg_ns = c[2] - '0';
+        }
     }
     return v;
 }
 
 template <int MODE>
-static void launch_mode(int variant, int mt, dim3 grid, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C,
-                        int ldc, int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
-    if (variant == 1) hipLaunchKernelGGL(gemm_kernel<MODE>, grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
-    else if (mt == 3) hipLaunchKernelGGL((gemm_glds_kernel<MODE, 3>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
-    else hipLaunchKernelGGL((gemm_glds_kernel<MODE, 2>), grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+static void launch_mode(int variant, int mt, int ns, dim3 grid, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw,
+                        void* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
+#define ACE_LAUNCH(kern) hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg)
+    if (variant == 1) ACE_LAUNCH(gemm_kernel<MODE>);
+    else if (variant == 2) {
+        if (mt == 3) ACE_LAUNCH((gemm_glds_kernel<MODE, 3>));
+        else ACE_LAUNCH((gemm_glds_kernel<MODE, 2>));
+    } else {
+        if (mt == 2 && ns == 2) ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 2>));
+        else if (mt == 3 && ns == 2) ACE_LAUNCH((gemm_pipe_kernel<MODE, 3, 2>));
+        else if (mt == 2 && ns == 4) ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 4>));
+        else if (mt == 3 && ns == 3) ACE_LAUNCH((gemm_pipe_kernel<MODE, 3, 3>));
+        else if (mt == 4 && ns == 3) ACE_LAUNCH((gemm_pipe_kernel<MODE, 4, 3>));
+        else ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 2>));
+    }
+#undef ACE_LAUNCH
 }
 
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
@@ -292,23 +417,24 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");
     const int variant = gemm_variant();
     const int tiles_n = (N + BN - 1) / BN;
-    // block-tile height: minimise (#waves of 512 resident blocks) x (rows per tile); ties -> 128
-    int mt = 2;
-    if (variant == 2) {
+    // block-tile height: minimise (#waves of resident blocks) x (rows per tile); ties -> 128
+    int mt = 2, ns = 2;
+    if (variant >= 2) {
         const long slots = 512;
         const long t128 = (long)((M + 127) / 128) * tiles_n, t192 = (long)((M + 191) / 192) * tiles_n;
         const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
         if (c192 < c128) mt = 3;
+        if (variant == 3 && g_cfg_mt) { mt = g_cfg_mt; ns = g_cfg_ns; }
     }
     const int bm = mt * 64;
     const int tiles_m = (M + bm - 1) / bm;
     const int nwg = tiles_m * tiles_n;
     dim3 grid(nwg);
     switch (ep.mode) {
-        case 0: launch_mode<0>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 1: launch_mode<1>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 2: launch_mode<2>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 3: launch_mode<3>(variant, mt, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 0: launch_mode<0>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 1: launch_mode<1>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 2: launch_mode<2>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 3: launch_mode<3>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         default: ACE_CHECK(false, "gemm: bad epilogue mode");
     }
     ACE_LAUNCH_CHECK();

@@ -21,23 +21,25 @@ constexpr int BM = 128, BN = 128, BK = 64;
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 
-// Epilogue shared by both mainloops.  Lane holds column n = .. + (lane&31) and 16 rows m = .. + mfma_row(r, lane) of
-// each 32x32 accumulator tile.
-template <int MODE, int MT>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __restrict__ Cv, int ldc, int M, int N,
-                                              const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane) {
+// Epilogue shared by all mainloops.  Lane holds column n = .. + (lane&31) and 16 rows m = .. + mfma_row(r, lane) of each
+// 32x32 accumulator tile.  FULL = the whole block tile is inside [0,M) x [0,N): no per-element predicates.  The fp32
+// residual update (mode 2) issues its 16 loads per accumulator tile back to back, then the FMAs, then the stores - a
+// predicated load/add/store per element serialises ~100 dependent HBM round trips per lane.
+template <int MODE, int MT, bool FULL>
+__device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[MT][2], void* __restrict__ Cv, int ldc, int M, int N,
+                                                   const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
     if (MODE == 3) {
         // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up of the same column
         bf16_t* out = reinterpret_cast<bf16_t*>(Cv);
         const int col = ((n0 + wn * 64) >> 1) + frow;
-        const bool nok = (n0 + wn * 64 + 32 + frow) < N;
+        const bool nok = FULL || (n0 + wn * 64 + 32 + frow) < N;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (MT * 32) + i * 32 + mfma_row(r, lane);
-                if (m < M && nok) {
+                if (FULL || (m < M && nok)) {
                     const float g = acc[i][0][r], u = acc[i][1][r];
                     out[(long)m * ldc + col] = f2bf(silu_f(g) * u);
                 }
@@ -48,7 +50,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __rest
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + frow;
-        if (n >= N) continue;
+        if (!FULL && n >= N) continue;
         float bias = 0.f, g1 = 1.f, cv = 0.f;
         if (MODE == 2 && ep.cvec) cv = ep.cvec[n];
         if (MODE <= 1 && ep.bias) bias = ep.bias[n];
@@ -56,36 +58,60 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __rest
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mb = m0 + wm * (MT * 32) + i * 32 + 4 * fhalf;
-            int seq0 = 0, rem0 = 0;
-            if (MODE == 2 && ep.g1) {
-                seq0 = mb / ep.rows_per_seq;
-                rem0 = mb - seq0 * ep.rows_per_seq;
-            }
+            if (MODE == 2) {
+                float* hp = reinterpret_cast<float*>(Cv) + n;
+                const int rps = ep.rows_per_seq;
+                // this lane's 16 rows span 28 consecutive rows: with rps >= 28 they touch at most two sequences
+                float gA = 1.f, gB = 1.f;
+                int seq0 = 0, rem0 = 0;
+                if (ep.g1) {
+                    seq0 = mb / rps;
+                    rem0 = mb - seq0 * rps;
+                    const int last = (M - 1) / rps;
+                    gA = g1 + ep.g2[(long)min(seq0, last) * ep.g2_stride + n];
+                    gB = g1 + ep.g2[(long)min(seq0 + 1, last) * ep.g2_stride + n];
+                }
+                float hv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int off = (r & 3) + 8 * (r >> 2);
-                const int m = mb + off;
-                if (m >= M) continue;
-                const float v = acc[i][j][r];
-                if (MODE == 0) {
-                    reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + bias);
-                } else if (MODE == 1) {
-                    reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + bias;
-                } else {
-                    float gate = 1.f;
-                    if (ep.g1) {
-                        int seq = seq0, rem = rem0 + off;
-                        while (rem >= ep.rows_per_seq) { rem -= ep.rows_per_seq; ++seq; }
-                        gate = g1 + ep.g2[(long)seq * ep.g2_stride + n];
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    const int m = FULL ? (mb + off) : min(mb + off, M - 1);
+                    hv[r] = hp[(long)m * ldc];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int off = (r & 3) + 8 * (r >> 2);
+                    const int m = mb + off;
+                    float gate = (rem0 + off >= rps) ? gB : gA;
+                    if (ep.g1 && rps < 28) {  // short sequences (tiny configs): generic per-row lookup
+                        const int sq = min(m, M - 1) / rps;
+                        gate = g1 + ep.g2[(long)sq * ep.g2_stride + n];
                     }
-                    float* h = reinterpret_cast<float*>(Cv) + (long)m * ldc + n;
-                    float add = gate * v;
+                    float add = gate * acc[i][j][r];
                     if (ep.cvec && m >= ep.cvec_row0) add += cv;
-                    *h = *h + add;
+                    if (FULL || m < M) hp[(long)m * ldc] = hv[r] + add;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // one tile's 16 loads in flight at a time: hoisting all MT*2 tiles spills
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (!FULL && m >= M) continue;
+                    const float v = acc[i][j][r];
+                    if (MODE == 0) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + bias);
+                    else reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + bias;
                 }
             }
         }
     }
+}
+
+template <int MODE, int MT>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __restrict__ Cv, int ldc, int M, int N,
+                                              const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane, int bm = MT * 64,
+                                              int bn = 128) {
+    if (m0 + bm <= M && n0 + bn <= N) gemm_epilogue_impl<MODE, MT, true>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+    else gemm_epilogue_impl<MODE, MT, false>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
 }
 
 template <int MODE>
@@ -370,6 +396,141 @@ __global__ __launch_bounds__(256, (NS == 2 ? 2 : 1)) void gemm_pipe_kernel(const
     gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------ v4: rotated pipeline
+// v3 still parks the matrix pipe at every K-step boundary: after the barrier a wave must issue its DMA pieces and wait
+// a full LDS round trip for the first fragments before any MFMA can start.  v4 rotates the loop by half a K-step so the
+// barrier sits BETWEEN two MFMA groups whose operands are already in registers:
+//     ds_read frags(kt, kk=2,3) -> Q   |  MFMA(kt, kk=0,1) from P            (P was loaded before the previous barrier)
+//     lgkmcnt(0); vmcnt(0) [tile kt+1]; s_barrier                            (stage kt&1 is now dead for every wave)
+//     DMA tile kt+2 -> stage kt&1;  ds_read frags(kt+1, kk=0,1) -> P  |  MFMA(kt, kk=2,3) from Q
+// Two LDS stages (2 workgroups per CU), one barrier per K-step, >= 8 MFMAs of cover on both sides of every LDS read.
+// WNW = waves along N (2 -> BN 128, 256 threads, 2 workgroups/CU; 4 -> BN 256, 512 threads, 1 workgroup/CU).
+// ABL (timing ablation only, results garbage): 1 no DMA in loop, 2 no LDS fragment reads in loop, 3 both, 4 no barrier
+template <int MODE, int MT, int WNW, int ABL = 0>
+__global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+                                                          int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
+                                                          GemmEpilogue ep, int tiles_n, int nwg, int group_m) {
+    constexpr int BMv = MT * 64;
+    constexpr int A_BYTES = BMv * 128;
+    constexpr int BNv = WNW * 64;
+    constexpr int NW = 2 * WNW;                 // waves per workgroup
+    constexpr int W_BYTES = BNv * 128;
+    constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr int AJ = BMv / (8 * NW);          // A DMA pieces per wave per tile (8 rows each)
+    constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
+    static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // grouped rasterisation inside the XCD's contiguous range: the ~32-64 workgroups resident on one XCD cover a
+    // (group_m x k) patch of tiles, so both the A row-panels and the W column-panels they stage are shared in that L2.
+    int tm, tn;
+    if (group_m > 1) {
+        const int tiles_m = nwg / tiles_n;
+        const int gsz = group_m * tiles_n;
+        const int grp = bid / gsz, rem = bid - grp * gsz;
+        const int first_m = grp * group_m;
+        const int gm = min(tiles_m - first_m, group_m);
+        tm = first_m + rem % gm;
+        tn = rem / gm;
+    } else {
+        tm = bid / tiles_n;
+        tn = bid - tm * tiles_n;
+    }
+    const int m0 = tm * BMv, n0 = tn * BNv;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+
+    const int lrow = lane >> 3, pslot = lane & 7;
+    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
+    const bf16_t* a_src[AJ];
+    const bf16_t* w_src[WJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + NW * j) + lrow, M - 1) * lda + sslot * 8;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * ldw + sslot * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    auto issue = [&](int kt) {
+        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) glds16_asm(a_src[j] + kt * BK, sb + j * (NW * 1024));
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) glds16_asm(w_src[j] + kt * BK, sb + A_BYTES + j * (NW * 1024));
+    };
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // per-lane fragment byte offsets inside a stage for kk = 0 (the kk term only flips slot bits: see lds_off)
+    int a_off[MT], w_off[2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_off[i] = (wm * (MT * 32) + i * 32 + frow) * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w_off[j] = A_BYTES + (wn * 64 + j * 32 + frow) * 128;
+    const int swz = ((wm * (MT * 32) + frow) >> 1) & 7;   // (row>>1)&7 is the same for every 32-row tile of this lane
+    const int swzw = ((wn * 64 + frow) >> 1) & 7;
+    auto load_frags = [&](const char* st, int kk0, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int slot = (kk0 + h) * 2 + fhalf;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[h][i] = as_bf16x8(*reinterpret_cast<const uint4*>(st + a_off[i] + ((slot ^ swz) << 4)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
+        }
+    };
+    auto mma = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[h][i], fw[h][j], acc[i][j]);
+    };
+
+    bf16x8 pa[2][MT], pw[2][2], qa[2][MT], qw[2][2];
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) wait_vmcnt<AJ + WJ>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    load_frags(smem, 0, pa, pw);
+
+    if (ABL & 2) load_frags(smem, 2, qa, qw);
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + (kt & 1) * STAGE;
+        if (!(ABL & 2)) load_frags(st, 2, qa, qw);
+        else { _Pragma("unroll") for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(qa[0][i]), "+v"(qa[1][i])); } }
+        mma(pa, pw);
+        __builtin_amdgcn_sched_barrier(0);
+        // lgkmcnt(0) in the builtin form (simm16 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0) so hipcc's own scoreboard knows the Q
+        // fragments have landed; an asm wait is invisible to it and it would make MFMA(Q) wait on the NEW P loads instead.
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (kt + 1 < nk) {
+            wait_vmcnt<0>();  // only tile kt+1 is in flight here
+            if (ABL != 4) __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk && !(ABL & 1)) issue(kt + 2);
+            if (!(ABL & 2)) load_frags(smem + ((kt + 1) & 1) * STAGE, 0, pa, pw);
+            else { _Pragma("unroll") for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(pa[0][i]), "+v"(pa[1][i])); } }
+        }
+        mma(qa, qw);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
+}
+
 }  // namespace
 
 static int g_cfg_mt = 0, g_cfg_ns = 0;
@@ -379,7 +540,7 @@ static int gemm_variant() {
         // ACE355_GEMM = v1 (register-staged) | v2 (DMA, compiler-scheduled) | v3 (DMA, counted pipeline; default)
         // ACE355_GEMM_CFG = "MT,NS" pins v3's tile height (MT*64) and stage count for experiments.
         const char* e = getenv("ACE355_GEMM");
-        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : (e && e[0] == 'v' && e[1] == '2') ? 2 : 3;
+        v = (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? (e[1] - '0') : 4;  // v4 = rotated pipeline (default)
         const char* c = getenv("ACE355_GEMM_CFG");
         if (c && c[0] >= '2' && c[0] <= '4' && c[1] == ',' && c[2] >= '2' && c[2] <= '4') {
             g_cfg_mt = c[0] - '0';
@@ -392,11 +553,27 @@ static int gemm_variant() {
 template <int MODE>
 static void launch_mode(int variant, int mt, int ns, dim3 grid, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw,
                         void* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
-#define ACE_LAUNCH(kern) hipLaunchKernelGGL(kern, grid, dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg)
+#define ACE_LAUNCH_T(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg)
+#define ACE_LAUNCH(kern) ACE_LAUNCH_T(kern, 256)
+#define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m)
     if (variant == 1) ACE_LAUNCH(gemm_kernel<MODE>);
     else if (variant == 2) {
         if (mt == 3) ACE_LAUNCH((gemm_glds_kernel<MODE, 3>));
         else ACE_LAUNCH((gemm_glds_kernel<MODE, 2>));
+    } else if (variant == 4) {
+        static int abl = -1, group_m = -1;
+        if (group_m < 0) { const char* e = getenv("ACE355_GEMM_GROUPM"); group_m = e ? atoi(e) : 4; }
+        if (abl < 0) { const char* e = getenv("ACE355_GEMM_ABL"); abl = e ? atoi(e) : 0; }
+        if (ns == 8) {  // 192x256 tile, 8 waves
+            if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
+            else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 3>), 512);
+            else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+        } else if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 1>), 256);
+        else if (abl == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2>), 256);
+        else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 3>), 256);
+        else if (abl == 4) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 4>), 256);
+        else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
+        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2>), 256);
     } else {
         if (mt == 2 && ns == 2) ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 2>));
         else if (mt == 3 && ns == 2) ACE_LAUNCH((gemm_pipe_kernel<MODE, 3, 2>));
@@ -406,6 +583,8 @@ static void launch_mode(int variant, int mt, int ns, dim3 grid, hipStream_t s, c
         else ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 2>));
     }
 #undef ACE_LAUNCH
+#undef ACE_LAUNCH_T
+#undef ACE_LAUNCH_SP
 }
 
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
@@ -416,16 +595,26 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");
     const int variant = gemm_variant();
-    const int tiles_n = (N + BN - 1) / BN;
-    // block-tile height: minimise (#waves of resident blocks) x (rows per tile); ties -> 128
-    int mt = 2, ns = 2;
+    // Tile choice.  The kernel is L2->LDS bandwidth bound (ablation in DESIGN.md), so the biggest tile that still fills
+    // the chip wins: 192x256 (8 waves, 110 flop per staged byte) when it yields >= ~0.8 x 256 workgroups, else the
+    // 4-wave 128/192 x 128 tiles with the height that minimises (rounds of 512 resident workgroups) x rows.
+    int mt = 2, ns = 2, bn = BN;
     if (variant >= 2) {
         const long slots = 512;
-        const long t128 = (long)((M + 127) / 128) * tiles_n, t192 = (long)((M + 191) / 192) * tiles_n;
+        const long tn128 = (N + 127) / 128;
+        const long t128 = (long)((M + 127) / 128) * tn128, t192 = (long)((M + 191) / 192) * tn128;
         const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
         if (c192 < c128) mt = 3;
-        if (variant == 3 && g_cfg_mt) { mt = g_cfg_mt; ns = g_cfg_ns; }
+        if (variant >= 3 && g_cfg_mt) { mt = g_cfg_mt; ns = g_cfg_ns; }
+        if (variant == 4 && mt > 3) mt = 3;
+        if (variant == 4) {
+            static int big = -1;
+            if (big < 0) { const char* e = getenv("ACE355_GEMM_BIG"); big = e ? atoi(e) : 1; }
+            const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
+            if (big == 2 || (big == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; ns = 8; bn = 256; }
+        }
     }
+    const int tiles_n = (N + bn - 1) / bn;
     const int bm = mt * 64;
     const int tiles_m = (M + bm - 1) / bm;
     const int nwg = tiles_m * tiles_n;

@@ -133,6 +133,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue
+    // lane holds output column n and 16 rows per accumulator tile.  Interior tiles (no row/column/crop predicate) take a
+    // branch-free path whose residual loads are issued 16 at a time before the adds (a predicated load->add->store per
+    // element serialises one memory round trip per element and made the k=1 convs slower than the k=7 ones).
+    const bool full = (m0 + 128 <= a.M) && (n0 + BN <= a.N) &&
+                      ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + 127) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn * (NT * 32) + j * 32 + lq;
@@ -140,9 +145,28 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
         const float bias = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+            const int mb = m0 + wm * (MT * 32) + i * 32 + 4 * half;
+            if (a.out_mode == 0 && full) {
+                const long base = (long)b * a.y_batch_stride + (long)mb * a.N + n + a.y_shift;
+                bf16_t* yp = reinterpret_cast<bf16_t*>(a.y) + base;
+                float rv[16];
+                if (a.res) {
+                    const bf16_t* rp = a.res + (long)b * a.res_batch_stride + (long)mb * a.N + n + a.y_shift;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = bf2f(rp[(long)((r & 3) + 8 * (r >> 2)) * a.N]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + bias;
+                    if (a.res) v += rv[r];
+                    yp[(long)((r & 3) + 8 * (r >> 2)) * a.N] = f2bf(v);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (MT * 32) + i * 32 + mfma_row(r, lane);
+                const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (a.out_mode == 0) {

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256, (NS == 2 ? 2 : 1)) void gemm_pipe_kernel(const
 // Two LDS stages (2 workgroups per CU), one barrier per K-step, >= 8 MFMAs of cover on both sides of every LDS read.
 // WNW = waves along N (2 -> BN 128, 256 threads, 2 workgroups/CU; 4 -> BN 256, 512 threads, 1 workgroup/CU).
 // ABL (timing ablation only, results garbage): 1 no DMA in loop, 2 no LDS fragment reads in loop, 3 both, 4 no barrier
-template <int MODE, int MT, int WNW, int ABL = 0>
+template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m) {
@@ -509,6 +509,68 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     load_frags(smem, 0, pa, pw);
 
     if (ABL & 2) load_frags(smem, 2, qa, qw);
+    // ---- ILV: explicit instruction interleave.  An LDS-DMA piece costs 60-185 cycles to ISSUE (TA queue); seven of them
+    // back to back right after the barrier stall the in-order wave before its first MFMA.  Here every MFMA is followed
+    // by at most one DMA piece or two fragment reads, pinned with sched_barrier.
+    if (ILV) {
+        constexpr int NM = 2 * MT * 2;  // MFMAs per half K-step
+        constexpr int NF = 2 * (MT + 2);  // fragment reads per half K-step
+        auto frag_ptr = [&](const char* st, int kk0, int f) -> const uint4* {
+            const int h = f / (MT + 2), e = f % (MT + 2);
+            const int slot = (kk0 + h) * 2 + fhalf;
+            return reinterpret_cast<const uint4*>(e < MT ? st + a_off[e] + ((slot ^ swz) << 4) : st + w_off[e - MT] + ((slot ^ swzw) << 4));
+        };
+        auto frag_store = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][2], int f, uint4 v) {
+            const int h = f / (MT + 2), e = f % (MT + 2);
+            if (e < MT) fa[h][e] = as_bf16x8(v); else fw[h][e - MT] = as_bf16x8(v);
+        };
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * STAGE;
+            // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int h = m / (MT * 2), i = (m / 2) % MT, j = m % 2;
+                acc[i][j] = mfma32(pa[h][i], pw[h][j], acc[i][j]);
+#pragma unroll
+                for (int f = 2 * m; f < 2 * m + 2; ++f)
+                    if (f < NF) frag_store(qa, qw, f, *frag_ptr(st, 2, f));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const bool more = kt + 1 < nk;
+            if (more) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
+            const char* stn = smem + ((kt + 1) & 1) * STAGE;
+            const bool dma = kt + 2 < nk;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const int h = m / (MT * 2), i = (m / 2) % MT, j = m % 2;
+                acc[i][j] = mfma32(qa[h][i], qw[h][j], acc[i][j]);
+                if (m < AJ + WJ) {
+                    if (dma) {
+                        if (m < AJ) glds16_asm(a_src[m] + (kt + 2) * BK, sb + m * (NW * 1024));
+                        else glds16_asm(w_src[m - AJ] + (kt + 2) * BK, sb + A_BYTES + (m - AJ) * (NW * 1024));
+                    }
+                }
+                if (more) {
+                    constexpr int F0 = (AJ + WJ < NM) ? (AJ + WJ) : 0;  // first MFMA slot that carries fragment reads
+                    constexpr int PER = (NF + (NM - F0) - 1) / (NM - F0);
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int f = (m - F0) * PER + q;
+                        if (m >= F0 && f < NF) frag_store(pa, pw, f, *frag_ptr(stn, 0, f));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
+        return;
+    }
+
     for (int kt = 0; kt < nk; ++kt) {
         const char* st = smem + (kt & 1) * STAGE;
         if (!(ABL & 2)) load_frags(st, 2, qa, qw);
@@ -566,7 +628,13 @@ static void launch_mode(int variant, int mt, int ns, dim3 grid, hipStream_t s, c
         static int abl = -1, group_m = -1;
         if (group_m < 0) { const char* e = getenv("ACE355_GEMM_GROUPM"); group_m = e ? atoi(e) : 4; }
         if (abl < 0) { const char* e = getenv("ACE355_GEMM_ABL"); abl = e ? atoi(e) : 0; }
-        if (ns == 8) {  // 192x256 tile, 8 waves
+        static int ilv = -1;
+        if (ilv < 0) { const char* e = getenv("ACE355_GEMM_ILV"); ilv = e ? atoi(e) : 1; }  // interleaved schedule (default on)
+        if (ilv && !abl) {
+            if (ns == 8) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
+            else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
+            else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
+        } else if (ns == 8) {  // 192x256 tile, 8 waves
             if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
             else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 3>), 512);
             else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);

@@ -1,0 +1,17 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc counter_collection CSVs: per-kernel-family totals and per-launch averages."""
+import collections, csv, glob, json, sys
+root, out = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(set)
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        fam = "gemm" if "gemm_" in k else "attn" if "attn_kernel" in k else "conv" if "conv_kernel" in k else "rmsnorm" if "rmsnorm" in k else "other"
+        agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[(fam, r["Counter_Name"])].add(r["Dispatch_Id"])
+res = {}
+for fam, cs in agg.items():
+    res[fam] = {c: {"total": v, "launches": len(launches[(fam, c)]), "per_launch": v / max(1, len(launches[(fam, c)]))} for c, v in cs.items()}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps({f: {c: round(d["per_launch"], 1) for c, d in cs.items()} for f, cs in res.items()}))

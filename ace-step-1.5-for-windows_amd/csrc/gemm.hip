@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, (NS == 2 ? 2 : 1)) void gemm_pipe_kernel(const
 template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
-                                                          GemmEpilogue ep, int tiles_n, int nwg, int group_m) {
+                                                          GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
     constexpr int BMv = MT * 64;
     constexpr int A_BYTES = BMv * 128;
     constexpr int BNv = WNW * 64;
@@ -422,25 +422,26 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // grouped rasterisation inside the XCD's contiguous range: the ~32-64 workgroups resident on one XCD cover a
-    // (group_m x k) patch of tiles, so both the A row-panels and the W column-panels they stage are shared in that L2.
+    // Workgroup -> tile map.  Block b runs on XCD b % 8 (observed, speed only).  The 8 XCDs (private L2s) form an
+    // xcd_m x xcd_n grid of rectangular tile regions, chosen per GEMM to minimise the bytes each L2 must pull from
+    // HBM/MALL (xcd_n * |A| + xcd_m * |W|); inside a region tiles are walked in groups of `group_m` rows so the ~32
+    // workgroups resident on one XCD share both A row-panels and W column-panels.
     int tm, tn;
-    if (group_m > 1) {
+    {
         const int tiles_m = nwg / tiles_n;
-        const int gsz = group_m * tiles_n;
-        const int grp = bid / gsz, rem = bid - grp * gsz;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd_n = 8 / xcd_m;
+        const int rm = (tiles_m + xcd_m - 1) / xcd_m, rn = (tiles_n + xcd_n - 1) / xcd_n;  // region size in tiles
+        const int xi = xcd / xcd_n, xj = xcd - xi * xcd_n;
+        const int m_lo = xi * rm, n_lo = xj * rn;
+        const int hm = min(rm, tiles_m - m_lo), hn = min(rn, tiles_n - n_lo);  // this region's extent (may be ragged / empty)
+        if (hm <= 0 || hn <= 0 || idx >= hm * hn) return;
+        const int gsz = group_m * hn;
+        const int grp = idx / gsz, rem = idx - grp * gsz;
         const int first_m = grp * group_m;
-        const int gm = min(tiles_m - first_m, group_m);
-        tm = first_m + rem % gm;
-        tn = rem / gm;
-    } else {
-        tm = bid / tiles_n;
-        tn = bid - tm * tiles_n;
+        const int gm = min(hm - first_m, group_m);
+        tm = m_lo + first_m + rem % gm;
+        tn = n_lo + rem / gm;
     }
     const int m0 = tm * BMv, n0 = tn * BNv;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -619,14 +620,31 @@ static void launch_mode(int variant, int mt, int ns, dim3 grid, hipStream_t s, c
                         void* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
 #define ACE_LAUNCH_T(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg)
 #define ACE_LAUNCH(kern) ACE_LAUNCH_T(kern, 256)
-#define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m)
+#define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, sp_grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if (variant == 1) ACE_LAUNCH(gemm_kernel<MODE>);
     else if (variant == 2) {
         if (mt == 3) ACE_LAUNCH((gemm_glds_kernel<MODE, 3>));
         else ACE_LAUNCH((gemm_glds_kernel<MODE, 2>));
     } else if (variant == 4) {
-        static int abl = -1, group_m = -1;
+        static int abl = -1, group_m = -1, xcd_m_env = -1;
         if (group_m < 0) { const char* e = getenv("ACE355_GEMM_GROUPM"); group_m = e ? atoi(e) : 4; }
+        if (xcd_m_env < 0) { const char* e = getenv("ACE355_GEMM_XCDM"); xcd_m_env = e ? atoi(e) : 0; }
+        // XCD grid: minimise xcd_n*|A| + xcd_m*|W| = (8/xm) * M + xm * N (same K), over xm in {1,2,4,8}
+        const int tiles_m_ = nwg / tiles_n;
+        int xcd_m = 8;
+        {
+            double best = 1e30;
+            for (int xm = 1; xm <= 8; xm *= 2) {
+                const int xn = 8 / xm;
+                if (xm > tiles_m_ || xn > tiles_n) continue;
+                const double cost = (double)xn * M + (double)xm * N;
+                if (cost < best) { best = cost; xcd_m = xm; }
+            }
+            if (xcd_m_env == 1 || xcd_m_env == 2 || xcd_m_env == 4 || xcd_m_env == 8) xcd_m = xcd_m_env;
+        }
+        const int xcd_n_ = 8 / xcd_m;
+        const int region = ((tiles_m_ + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n_ - 1) / xcd_n_);
+        const dim3 sp_grid(8 * region);
         if (abl < 0) { const char* e = getenv("ACE355_GEMM_ABL"); abl = e ? atoi(e) : 0; }
         static int ilv = -1;
         if (ilv < 0) { const char* e = getenv("ACE355_GEMM_ILV"); ilv = e ? atoi(e) : 1; }  // interleaved schedule (default on)

@@ -123,6 +123,21 @@ def vae_flops_per_frame(vcfg):
     return f
 
 
+def pmc_traffic_bytes_per_launch():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (profiles/*.json,
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950 tallies
+    128-B requests at 64 B; both counters are in KiB).  None when no profile is present: bench.py cannot collect PMCs."""
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")))[-1]
+        w = f.replace("FETCH_SIZE", "WRITE_SIZE")
+        fetch = json.load(open(f))["gemm"]["FETCH_SIZE"]["per_launch"]
+        write = json.load(open(w))["gemm"]["WRITE_SIZE"]["per_launch"]
+        return (2.0 * fetch + write) * 1024.0
+    except Exception:
+        return None
+
+
 def usable_cpus() -> int:
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (a 128-thread default on a
     quota-limited container oversubscribes and slows the CPU baseline several-fold)."""
@@ -283,9 +298,9 @@ def main():
         p = dit.get_profile()
         dit.set_profile(False)
         gemm_tf = p["gemm_flops"] / (p["gemm_ms"] * 1e-3) / 1e12 if p["gemm_ms"] > 0 else 0.0
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel (bf16 MFMA 32x32x16, 128x128x64 tile)",
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_sp_kernel (bf16 MFMA 32x32x16; 192x256x64 8-wave / 128-192x128x64 4-wave tiles, LDS-DMA staging)",
                               "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
-                              "traffic": None, "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
+                              "traffic": pmc_traffic_bytes_per_launch(), "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
                               "avg_launch_us": 1000.0 * p["gemm_ms"] / max(p["gemm_launches"], 1),
                               "flops_per_launch": p["gemm_flops"] / max(p["gemm_launches"], 1),
                               "attn_tflops": p["attn_flops"] / (p["attn_ms"] * 1e-3) / 1e12 if p["attn_ms"] > 0 else 0.0,

@@ -146,6 +146,31 @@ def test_full_size_forward_vs_reference_golden(gpu_device, golden_dir):
     assert not torch.isnan(v).any()
 
 
+def test_null_branch_shortcut_equals_generic_path(gpu_device):
+    """A broadcast slot (rows == 1: null_condition_emb.expand_as) takes the constant-cross-attention shortcut; the same
+    condition uploaded as L identical rows takes the generic attention path.  Both must agree."""
+    cfg, w, dit = _make(TINY, 21, gpu_device)
+    g = torch.Generator().manual_seed(8)
+    N, T, L = 4, 64, 37
+    x = torch.randn(N, T, 64, generator=g)
+    ctx = torch.cat([0.5 * torch.randn(N, T, 64, generator=g), torch.ones(N, T, 64)], -1)
+    enc = torch.randn(L, cfg.hidden_size, generator=g)
+    null = torch.randn(1, cfg.hidden_size, generator=g)
+    t = [0.8] * N
+    dit.set_condition(0, enc)
+    dit.set_condition(1, null, L=L)                      # broadcast -> shortcut for the trailing sequences
+    v_short = dit.forward(x, ctx, t, t, [0, 0, 1, 1])
+    dit.set_condition(2, null.expand(L, -1).contiguous())  # same keys, generic path
+    v_gen = dit.forward(x, ctx, t, t, [0, 0, 2, 2])
+    assert torch.equal(v_short[:2], v_gen[:2])             # conditional half is untouched by the shortcut
+    r = _rel(v_short[2:], v_gen[2:])
+    print(f"null-branch shortcut vs generic attention: rel L2 {r:.2e}")
+    assert r < 5e-3, r
+    # a non-suffix layout must fall back to the generic path and still be right
+    v_mixed = dit.forward(x, ctx, t, t, [1, 0, 1, 0])
+    assert _rel(v_mixed[0], dit.forward(x[:1], ctx[:1], t[:1], t[:1], [2])[0]) < 5e-3
+
+
 def test_errors_are_reported_not_fatal(gpu_device):
     import ace355
     from ace355 import native

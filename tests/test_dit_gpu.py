@@ -146,6 +146,48 @@ def test_full_size_forward_vs_reference_golden(gpu_device, golden_dir):
     assert not torch.isnan(v).any()
 
 
+def test_baseline_config0_full_size_sampler_and_decode_vs_oracle(gpu_device):
+    """BASELINE.json configs[0]: acestep-5Hz DiT-only... 10 s audio, 10 steps, batch 1 - the reference's CPU-runnable case -
+    at the real architecture (random init, bf16-representable weights on both sides), CFG 7 + APG, then decoded.
+    Stated tolerance (north_star: 'within a stated fp tolerance on the decoded waveform'): latents rel-L2 <= 5e-2,
+    waveform SNR >= 20 dB vs the fp32 oracle chain."""
+    import time
+    import ace355
+    from ace355 import weightgen
+    from ace355.dit import NativeDit, generate_latents
+    from ace355.vae import NativeVae
+    from oracle import dit as o_dit, oobleck as o_vae, sampler as o_sampler
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    cfg = ace355.DitConfig()
+    w = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=7, mode="init")
+    w = {k: (v.to(torch.bfloat16).float() if v.ndim >= 2 and "scale_shift" not in k else v) for k, v in w.items()}
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=7)
+    dit = NativeDit(cfg, gpu_device)
+    dit.load_state_dict(w)
+    g = torch.Generator().manual_seed(70)
+    B, T, L, steps = 1, 250, 769, 10
+    enc = torch.randn(B, L, cfg.hidden_size, generator=g)
+    ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1)
+    out = generate_latents(dit, null, enc, ctx, seed=[1000], infer_steps=steps, diffusion_guidance_sale=7.0)
+    lat = out["target_latents"].cpu()
+    t0 = time.time()
+    ref = o_sampler.generate_audio(o_dit.DitConfig(), w, null, enc, ctx, seed=[1000], infer_steps=steps, diffusion_guidance_sale=7.0)
+    cpu_s = time.time() - t0
+    r = _rel(lat, ref)
+    print(f"config0 full-size sampler: latents rel L2 {r:.3e} (GPU {out['time_costs']['diffusion_time_cost']:.3f}s, CPU oracle {cpu_s:.1f}s)")
+    assert r < 5e-2, r
+    vcfg = ace355.VaeConfig()
+    vw = weightgen.make_vae_weights(vcfg.weight_shapes(), seed=7, mode="init")
+    vae = NativeVae(vcfg, gpu_device)
+    vae.load_state_dict(vw)
+    Tv = 48  # decode a 48-frame excerpt of both latents (the fp32 CPU decoder costs ~5 GFLOP per frame)
+    wav = vae.decode(lat[:, :Tv].transpose(1, 2).contiguous()).cpu()
+    wref = o_vae.decode(o_vae.VaeConfig(), vw, ref[:, :Tv].transpose(1, 2).contiguous())
+    snr = float(10 * torch.log10(wref.pow(2).sum() / (wav - wref).pow(2).sum()))
+    print(f"config0 decoded waveform (native latents -> native VAE vs oracle latents -> oracle VAE): SNR {snr:.1f} dB")
+    assert snr > 20.0, snr
+
+
 def test_null_branch_shortcut_equals_generic_path(gpu_device):
     """A broadcast slot (rows == 1: null_condition_emb.expand_as) takes the constant-cross-attention shortcut; the same
     condition uploaded as L identical rows takes the generic attention path.  Both must agree."""

@@ -143,7 +143,8 @@ int ace355_apg_euler_step(const float* v, float* avg, float* xt, int B, int T, f
                           void* stream) {
     ACE_CHECK(v && avg && xt && B > 0 && T > 0, "apg_euler_step: bad argument");
     const int do_cfg = guidance > 1.0f ? 1 : 0;
-    return launch_apg_euler(v, (long)B * T * 64, avg, xt, nullptr, 0, B, T, T, guidance, dt, apply_cfg, do_cfg, first,
+    const StepUpdate up{nullptr, 0.f, 0.f};
+    return launch_apg_euler(v, (long)B * T * 64, avg, xt, nullptr, 0, B, T, T, guidance, dt, apply_cfg, do_cfg, first, up,
                             (hipStream_t)stream);
 }
 

@@ -129,8 +129,14 @@ int launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
 int launch_expand_kv_heads(const bf16_t* v_row, bf16_t* out, int hq, int hkv, hipStream_t s);
 int launch_bcast_rows(const bf16_t* in, bf16_t* out, int rows, int cols, hipStream_t s);
 int launch_copy_v(const float* vpad, float* v, int N, int T, int Tpad, hipStream_t s);
+struct StepUpdate {          // how x_t advances after the guided velocity is known
+    const float* sde_noise;  // null: ODE Euler step x -= v*dt (base.py:1974-1979); else [B,T,64] fresh noise of this step:
+    float t_curr, t_next;    //       x0 = x - v*t_curr; x = t_next*noise + (1-t_next)*x0 (base.py:1968-1973)
+};
 int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, bf16_t* xin, int copies, int B, int T,
-                     int Tpad, float guidance, float dt, int apply_cfg, int do_cfg, int first, hipStream_t s);
+                     int Tpad, float guidance, float dt, int apply_cfg, int do_cfg, int first, const StepUpdate& up, hipStream_t s);
+int launch_adg_step(const float* v, long uncond_offset, float* xt, bf16_t* xin, int copies, int B, int T, int Tpad, float guidance,
+                    float sigma, float dt, const StepUpdate& up, hipStream_t s);
 int launch_peak_normalize(float* wav, int B, long per_item, float* scratch, hipStream_t s);
 int launch_latent_check(const float* x, long n, int* flags_dev, hipStream_t s);
 

@@ -592,8 +592,8 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     ACE_CHECK(h && xt0_dev && ctx_dev && p && latents_out_dev && p->t_sched_host, "dit_sample: null argument");
     if (!h->finalized) { set_error("dit_sample: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
     ACE_CHECK(B > 0 && T > 0 && p->num_steps > 0, "dit_sample: empty problem");
-    if (p->infer_method != 0) { set_error("dit_sample: only infer_method 'ode' is supported (sde uses an unseeded RNG)"); return ACE355_ERR_UNSUPPORTED; }
-    if (p->use_adg) { set_error("dit_sample: use_adg is not supported by the native path this round"); return ACE355_ERR_UNSUPPORTED; }
+    ACE_CHECK(p->infer_method == 0 || p->infer_method == 1, "dit_sample: infer_method must be 0 (ode) or 1 (sde)");
+    ACE_CHECK(p->infer_method == 0 || p->sde_noise_dev != nullptr, "dit_sample: infer_method sde needs sde_noise_dev [steps,B,T,64]");
     const bool do_cfg = p->guidance_scale > 1.0f;
     const int copies = do_cfg ? 2 : 1, N = B * copies;
     ACE_CHECK(N <= ACE355_MAX_SEQS, "dit_sample: at most 64 sequences per call");
@@ -637,10 +637,18 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         if (rc) return rc;
         const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
         const float dt = t_curr - t_prev;
-        rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
-                              apply, do_cfg ? 1 : 0, apg_calls == 0 ? 1 : 0, s);
+        StepUpdate up{nullptr, t_curr, 0.f};
+        if (p->infer_method == 1) {
+            up.sde_noise = p->sde_noise_dev + (size_t)i * B * T * h->OUTC;
+            up.t_next = 1.0f - (float)(i + 1) / (float)p->num_steps;  // base.py:1972
+        }
+        if (do_cfg && apply && p->use_adg)
+            rc = launch_adg_step(h->vpad, (long)B * Tpad * h->OUTC, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, t_curr, dt, up, s);
+        else
+            rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
+                                  apply, do_cfg ? 1 : 0, apg_calls == 0 ? 1 : 0, up, s);
         if (rc) return rc;
-        if (do_cfg && apply) ++apg_calls;
+        if (do_cfg && apply && !p->use_adg) ++apg_calls;
         if (per_step_ms_host) hipEventRecord(evs[i + 1], s);
     }
     ACE_HIP(hipMemcpyAsync(latents_out_dev, h->xt, lat_bytes, hipMemcpyDeviceToDevice, s));

@@ -245,7 +245,7 @@ __global__ void copy_v_kernel(const float* __restrict__ vpad, float* __restrict_
 __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict__ v, long uncond_off, float* __restrict__ avg,
                                                         float* __restrict__ xt, bf16_t* __restrict__ xin, int copies, int B,
                                                         int T, int Tpad, float guidance, float dt, int apply_cfg, int do_cfg,
-                                                        int first) {
+                                                        int first, StepUpdate up) {
     __shared__ double red[3][16][16];
     __shared__ double tot[3][16];
     const int b = blockIdx.x, cl = threadIdx.x & 15, ts = threadIdx.x >> 4;
@@ -315,12 +315,57 @@ __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict_
             const float orth = (float)((double)d - dotf * u);
             vv = pc + (guidance - 1.f) * orth;
         }
-        const float xn = x[(long)t * 64] - vv * dt;
+        float xn;
+        if (up.sde_noise) {  // base.py:1968-1973: x0 = x - v*t_curr; x = t_next*noise + (1 - t_next)*x0
+            const float x0 = x[(long)t * 64] - vv * up.t_curr;
+            xn = up.t_next * up.sde_noise[((long)b * T + t) * 64 + c] + (1.f - up.t_next) * x0;
+        } else {
+            xn = x[(long)t * 64] - vv * dt;
+        }
         x[(long)t * 64] = xn;
         if (xin) {
             const bf16_t xb = f2bf(xn);
             for (int cp = 0; cp < copies; ++cp) xin[((long)(cp * B + b) * Tpad + t) * 192 + 128 + c] = xb;
         }
+    }
+}
+
+// ADG (apg_guidance.py:107-180, angle clip pi/6 written 3.14/6, no norm) + update; one wave per (item, frame) row of 64
+// channels.  Angle / cos / sin in fp64 like the reference (`.to(float)` = float64 there); the projection in fp32.
+__global__ __launch_bounds__(256) void adg_step_kernel(const float* __restrict__ v, long uncond_off, float* __restrict__ xt,
+                                                       bf16_t* __restrict__ xin, int copies, int B, int T, int Tpad, float guidance,
+                                                       float sigma, float dt, StepUpdate up) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = threadIdx.x & 63;
+    if (row >= (long)B * T) return;
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    const float pc = v[((long)b * Tpad + t) * 64 + c], pu = v[uncond_off + ((long)b * Tpad + t) * 64 + c];
+    const float x = xt[row * 64 + c];
+    float w = guidance - 1.f;
+    w = w * (w > 0.f ? 1.f : 0.f) + 1e-3f;
+    const float xtxt = x - sigma * pc, xunc = x - sigma * pu, diff = xtxt - xunc;
+    const double ntt = wave_sum_d((double)xtxt * xtxt), nuu = wave_sum_d((double)xunc * xunc), dtu = wave_sum_d((double)xtxt * xunc);
+    double cosv = dtu / (sqrt(ntt) * sqrt(nuu));
+    const double theta = acos(cosv);
+    const double clipv = 3.14 / 6;
+    const double th_new = fmin(fmax((double)w * theta, -clipv), clipv);
+    const float du = wave_sum(diff * xunc), uu = wave_sum(xunc * xunc);
+    const float perp = diff - (du / (uu + 1e-8f)) * xunc;
+    const double sth = sin(theta);
+    const double pnew = (sth > 1e-3) ? (double)perp * sin(th_new) / sth : (double)perp * (double)w;
+    const double xnew = cos(th_new) * (double)xtxt + pnew;
+    const float vv = (float)(((double)x - xnew) / (double)sigma);
+    float xn;
+    if (up.sde_noise) {
+        const float x0 = x - vv * up.t_curr;
+        xn = up.t_next * up.sde_noise[row * 64 + c] + (1.f - up.t_next) * x0;
+    } else {
+        xn = x - vv * dt;
+    }
+    xt[row * 64 + c] = xn;
+    if (xin) {
+        const bf16_t xb = f2bf(xn);
+        for (int cp = 0; cp < copies; ++cp) xin[((long)(cp * B + b) * Tpad + t) * 192 + 128 + c] = xb;
     }
 }
 
@@ -501,9 +546,17 @@ int launch_copy_v(const float* vpad, float* v, int N, int T, int Tpad, hipStream
 }
 
 int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, bf16_t* xin, int copies, int B, int T, int Tpad,
-                     float guidance, float dt, int apply_cfg, int do_cfg, int first, hipStream_t s) {
+                     float guidance, float dt, int apply_cfg, int do_cfg, int first, const StepUpdate& up, hipStream_t s) {
     hipLaunchKernelGGL(apg_euler_kernel, dim3(B, 4), dim3(256), 0, s, v, uncond_offset, avg, xt, xin, copies, B, T, Tpad, guidance,
-                       dt, apply_cfg, do_cfg, first);
+                       dt, apply_cfg, do_cfg, first, up);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_adg_step(const float* v, long uncond_offset, float* xt, bf16_t* xin, int copies, int B, int T, int Tpad, float guidance,
+                    float sigma, float dt, const StepUpdate& up, hipStream_t s) {
+    const long rows = (long)B * T;
+    hipLaunchKernelGGL(adg_step_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, v, uncond_offset, xt, xin, copies, B, T,
+                       Tpad, guidance, sigma, dt, up);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -125,7 +125,7 @@ class NativeDit:
                cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0, infer_method: str = "ode", use_adg: bool = False,
                cond_slot: int = SLOT_COND, null_slot: int = SLOT_NULL, cover_switch_step: Optional[int] = None,
                non_cover_slot: int = SLOT_NON_COVER, ctx_non_cover: Optional[torch.Tensor] = None,
-               return_step_ms: bool = False):
+               return_step_ms: bool = False, sde_noise: Optional[torch.Tensor] = None):
         if infer_method not in {"ode", "sde"}:
             raise ValueError(f"Unsupported infer_method '{infer_method}'. Expected 'ode' or 'sde'.")
         B, T, _ = xt0.shape
@@ -136,10 +136,18 @@ class NativeDit:
         sched = (C.c_float * (steps + 1))(*ts.tolist())
         if ctx_non_cover is not None:
             ctx_non_cover = ctx_non_cover.detach().to(self.device, torch.float32).contiguous()
+        if infer_method == "sde":
+            if sde_noise is None:  # the reference's unseeded torch.randn_like on the model device (base.py:1777)
+                sde_noise = torch.randn(steps, B, T, xt0.shape[-1], device=self.device, dtype=torch.float32)
+            sde_noise = sde_noise.detach().to(self.device, torch.float32).contiguous()
+            if tuple(sde_noise.shape) != (steps, B, T, xt0.shape[-1]):
+                raise ValueError("sde_noise must be [steps, B, T, 64]")
+        else:
+            sde_noise = None
         p = native.SampleParamsC(steps, C.cast(sched, C.POINTER(C.c_float)), float(guidance_scale), float(cfg_interval_start),
                                  float(cfg_interval_end), 0 if infer_method == "ode" else 1, 1 if use_adg else 0, cond_slot,
                                  null_slot, steps if cover_switch_step is None else int(cover_switch_step), non_cover_slot,
-                                 native.ptr(ctx_non_cover))
+                                 native.ptr(ctx_non_cover), native.ptr(sde_noise))
         out = torch.empty_like(xt0)
         ms = (C.c_float * steps)() if return_step_ms else None
         with torch.cuda.device(self.device):
@@ -166,7 +174,8 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
                      use_adg: bool = False, shift: float = 1.0, timesteps=None, audio_cover_strength: float = 1.0,
                      cover_noise_strength: float = 0.0, src_latents: Optional[torch.Tensor] = None,
                      encoder_hidden_states_non_cover: Optional[torch.Tensor] = None,
-                     context_latents_non_cover: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> Dict:
+                     context_latents_non_cover: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                     sde_noise: Optional[torch.Tensor] = None) -> Dict:
     """The part of ``generate_audio`` (modeling_acestep_v15_base.py:1861-1989) after ``prepare_condition``.
 
     The reference replicates ONE caption across the batch (handler/batch_prep.py:93-96), so the cross-attention
@@ -208,8 +217,11 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
         dit.set_condition(SLOT_NON_COVER, enc_nc[0])
         ctx_nc = context_latents_non_cover
     t1 = time.time()
+    if use_adg and B > 1:
+        # the reference's adg_forward only broadcasts for batch 1 (apg_guidance.py:150-168 multiplies [n*t,1] by [n,t,c])
+        raise ValueError("use_adg is only defined for batch size 1 in the reference")
     out = dit.sample(xt0, context_latents, ts, diffusion_guidance_sale, cfg_interval_start, cfg_interval_end, infer_method,
-                     use_adg, cover_switch_step=cover_steps, ctx_non_cover=ctx_nc)
+                     use_adg, cover_switch_step=cover_steps, ctx_non_cover=ctx_nc, sde_noise=sde_noise)
     torch.cuda.synchronize(dit.device)
     t2 = time.time()
     return {"target_latents": out,

@@ -34,6 +34,7 @@ class SampleParamsC(C.Structure):
         ("cfg_interval_start", C.c_float), ("cfg_interval_end", C.c_float), ("infer_method", C.c_int32),
         ("use_adg", C.c_int32), ("cond_slot", C.c_int32), ("null_slot", C.c_int32),
         ("cover_switch_step", C.c_int32), ("non_cover_slot", C.c_int32), ("ctx_non_cover_dev", C.c_void_p),
+        ("sde_noise_dev", C.c_void_p),
     ]
 
 

@@ -100,13 +100,15 @@ typedef struct ace355_sample_params {
     float guidance_scale;       /* diffusion_guidance_sale; > 1 enables CFG batch doubling (base.py:1905) */
     float cfg_interval_start;   /* base.py:1945 */
     float cfg_interval_end;
-    int32_t infer_method;       /* 0 = "ode" (base.py:1974-1979); 1 = "sde" -> ERR_UNSUPPORTED (unseeded RNG) */
-    int32_t use_adg;            /* 1 -> ERR_UNSUPPORTED this round (apg_guidance.py:107-180) */
+    int32_t infer_method;       /* 0 = "ode" (base.py:1974-1979); 1 = "sde" (base.py:1968-1973), needs sde_noise_dev */
+    int32_t use_adg;            /* 1 = angle-based guidance (apg_guidance.py:107-180) instead of APG inside the cfg interval */
     int32_t cond_slot;          /* slot of the cover/main condition */
     int32_t null_slot;          /* slot holding null_condition_emb (ignored when guidance <= 1) */
     int32_t cover_switch_step;  /* = int(steps * audio_cover_strength); >= num_steps: never switch (base.py:1916-1927) */
     int32_t non_cover_slot;     /* slot + context used from cover_switch_step on */
     const float* ctx_non_cover_dev; /* dev f32 [B,T,128] or NULL */
+    const float* sde_noise_dev;     /* "sde" only: dev f32 [num_steps,B,T,64], the per-step randn_like(x) draws of base.py:1777
+                                     * (the reference draws them unseeded on the model device; the caller owns the RNG) */
 } ace355_sample_params;
 
 /* The sampling loop of generate_audio (base.py:1913-1981): CFG doubling, steps x {decoder forward,

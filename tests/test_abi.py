@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     from ace355 import native
     assert ctypes.sizeof(native.DitConfigC) == 10 * 4 + 2 * 4 + 8
     assert ctypes.sizeof(native.VaeConfigC) == 4 * 4 + 2 * 8 * 4
-    assert ctypes.sizeof(native.SampleParamsC) == 64
+    assert ctypes.sizeof(native.SampleParamsC) == 72
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -188,6 +188,37 @@ def test_baseline_config0_full_size_sampler_and_decode_vs_oracle(gpu_device):
     assert snr > 20.0, snr
 
 
+def test_adg_and_sde_branches_vs_oracle(gpu_device):
+    """D16 (ADG, batch 1 as in the reference) and the D17 SDE update with the per-step noise the oracle draws."""
+    from ace355 import weightgen
+    from ace355.dit import generate_latents
+    from oracle import dit as o_dit, sampler as o_sampler
+    cfg, w, dit = _make(TINY, 31, gpu_device)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=31)
+    g = torch.Generator().manual_seed(4)
+    B, T, L, steps = 1, 44, 13, 6
+    enc = torch.randn(B, L, cfg.hidden_size, generator=g)
+    ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1)
+    o_cfg = o_dit.DitConfig(**TINY)
+    ref = o_sampler.generate_audio(o_cfg, w, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, use_adg=True)
+    out = generate_latents(dit, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, use_adg=True)["target_latents"]
+    r = _rel(out, ref)
+    print(f"ADG sampler: rel L2 {r:.3e}")
+    assert r < 5e-2, r
+    with pytest.raises(ValueError, match="batch size 1"):
+        generate_latents(dit, null, enc.expand(2, -1, -1), ctx.expand(2, -1, -1).contiguous(), seed=[1, 2], infer_steps=2, use_adg=True)
+    # SDE: the oracle draws randn_like(x) once per step from the global CPU generator; replay the same draws natively
+    torch.manual_seed(99)
+    ref = o_sampler.generate_audio(o_cfg, w, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, infer_method="sde")
+    torch.manual_seed(99)
+    noise = torch.stack([torch.randn(B, T, 64) for _ in range(steps)])
+    out = generate_latents(dit, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, infer_method="sde",
+                           sde_noise=noise)["target_latents"]
+    r = _rel(out, ref)
+    print(f"SDE sampler: rel L2 {r:.3e}")
+    assert r < 5e-2, r
+
+
 def test_null_branch_shortcut_equals_generic_path(gpu_device):
     """A broadcast slot (rows == 1: null_condition_emb.expand_as) takes the constant-cross-attention shortcut; the same
     condition uploaded as L identical rows takes the generic attention path.  Both must agree."""

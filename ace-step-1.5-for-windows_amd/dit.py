@@ -185,9 +185,31 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
     t0 = time.time()
     B, T, _ = context_latents.shape
     enc = encoder_hidden_states
-    if enc.shape[0] > 1 and not bool((enc == enc[:1]).all()):
-        raise NotImplementedError("ace355: per-item encoder_hidden_states in one call are not supported; "
-                                  "the handler replicates one caption across the batch")
+    per_item = enc.shape[0] > 1 and not bool((enc == enc[:1]).all())
+    if not per_item and encoder_hidden_states_non_cover is not None and encoder_hidden_states_non_cover.shape[0] > 1:
+        nc = encoder_hidden_states_non_cover
+        per_item = not bool((nc == nc[:1]).all())
+    if per_item:
+        # Items with different conditions: one native call per item (the cross-K/V slots hold one condition each).
+        # The product path never needs this (one caption per batch); it keeps the generic contract of generate_audio.
+        seeds = seed if isinstance(seed, (list, tuple)) else [seed] * B
+        if noise is None:
+            noise = prepare_noise((B, T, context_latents.shape[-1] // 2), list(seeds) if isinstance(seed, (list, tuple)) else seed)
+        outs, tc = [], None
+        for b in range(B):
+            sl = slice(b, b + 1)
+            o = generate_latents(
+                dit, null_condition_emb, enc[sl], context_latents[sl], seed=None, infer_method=infer_method, infer_steps=infer_steps,
+                diffusion_guidance_sale=diffusion_guidance_sale, cfg_interval_start=cfg_interval_start, cfg_interval_end=cfg_interval_end,
+                use_adg=use_adg, shift=shift, timesteps=timesteps, audio_cover_strength=audio_cover_strength,
+                cover_noise_strength=cover_noise_strength, src_latents=None if src_latents is None else src_latents[sl],
+                encoder_hidden_states_non_cover=None if encoder_hidden_states_non_cover is None else encoder_hidden_states_non_cover[sl],
+                context_latents_non_cover=None if context_latents_non_cover is None else context_latents_non_cover[sl],
+                noise=noise[sl], sde_noise=None if sde_noise is None else sde_noise[:, sl])
+            outs.append(o["target_latents"])
+            tc = o["time_costs"] if tc is None else {k: tc[k] + o["time_costs"][k] for k in tc}
+        tc["diffusion_per_step_time_cost"] = tc["diffusion_time_cost"] / max(1, (len(timesteps) - 1) if timesteps is not None else infer_steps)
+        return {"target_latents": torch.cat(outs, dim=0), "time_costs": tc}
     ts = schedule(infer_steps, shift, timesteps)
     steps = ts.numel() - 1
     cover_steps = int(steps * audio_cover_strength)

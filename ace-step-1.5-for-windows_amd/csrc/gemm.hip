@@ -3,11 +3,14 @@
 // Replaces the nn.Linear contractions of AceStepDiTLayer (q/k/v/o_proj, base.py:279-282; Qwen3MLP gate/up/down,
 // base.py:469), proj_in/proj_out as GEMMs (base.py:1264-1274, 1287-1297) and condition_embedder (base.py:1282).
 //
-// gfx950 design: 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA 32x32x16 bf16
-// accumulators (64 acc VGPRs).  A and W tiles are K-contiguous, staged global -> registers -> LDS (16-B
-// vectors), double-buffered in LDS with one barrier per K-step; the LDS image is XOR-swizzled at 16-B
-// granularity (slot ^= (row>>1)&7) so every ds_read_b128 fragment read is bank-conflict free.
-// Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles.
+// Two kernels:
+//   gemm_kernel     (v1)  register-staged 128x128x64 tile: the simple bring-up / A-B reference (ACE355_GEMM=v1).
+//   gemm_sp_kernel  (v4)  the product kernel: A/W tiles HBM -> LDS by DMA (global_load_lds, issued from asm so hipcc does
+//                         not drain it), two LDS stages, K loop rotated by half a step, DMA pieces / fragment reads
+//                         interleaved one per MFMA, 192x256 (8 waves) or 128/192x128 (4 waves) block tiles,
+//                         grouped XCD-local rasterisation.  DESIGN.md section 5 has the measured ladder and the ablation.
+// Common: MFMA 32x32x16 bf16, K-contiguous operands, LDS image XOR-swizzled at 16-B granularity (slot ^= (row>>1)&7:
+// every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 
 #include <stdlib.h>
@@ -206,92 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
 }
 
 
-// ------------------------------------------------------------------------------------------------ v2: direct-to-LDS
-// Same tile math, but A/W tiles go HBM -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
-// round trip and no ds_write pass).  The DMA writes LDS linearly (wave-uniform base + lane*16), so the bank swizzle is
-// applied on the SOURCE address (cdna guide rule 21): lane (row r, physical slot p) fetches logical k-slot p ^ ((r>>1)&7).
-// MT = 32-row accumulator tiles per wave along M: MT=2 -> 128x128 block tile, MT=3 -> 192x128 (M=6000, N=2048 is then
-// exactly 512 tiles = one full wave of 2 blocks/CU instead of 1.47 waves).
-template <int MODE, int MT>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
-                                                            int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
-                                                            GemmEpilogue ep, int tiles_n, int nwg) {
-    constexpr int BMv = MT * 64;
-    constexpr int A_BYTES = BMv * 128;
-    constexpr int STAGE = A_BYTES + 16384;
-    constexpr int AJ = BMv / 32;  // A DMA instructions per wave per K-step
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int m0 = tm * BMv, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int lrow = lane >> 3, pslot = lane & 7;
-    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);  // (r>>1)&7 for r = 8*(wave+4j) + lrow, any j
-    const bf16_t* a_src[AJ];
-    const bf16_t* w_src[4];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + 4 * j) + lrow, M - 1) * lda + sslot * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + 4 * j) + lrow, N - 1) * ldw + sslot * 8;
-
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#define GLDS(src, dst) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-#define ISSUE_TILE(kt_, stage_)                                                                      \
-    {                                                                                                \
-        char* sb_ = smem + (stage_) * STAGE;                                                         \
-        _Pragma("unroll") for (int j = 0; j < AJ; ++j) GLDS(a_src[j] + (kt_) * BK, sb_ + (wave + 4 * j) * 1024); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) GLDS(w_src[j] + (kt_) * BK, sb_ + A_BYTES + (wave + 4 * j) * 1024); \
-    }
-
-    const int nk = K / BK;
-    const int frow = lane & 31, fhalf = lane >> 5;
-    ISSUE_TILE(0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) ISSUE_TILE(kt + 1, (kt + 1) & 1)
-        const char* As = smem + (kt & 1) * STAGE;
-        const char* Ws = As + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[MT], fw[2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(wm * (MT * 32) + i * 32 + frow, kk * 2 + fhalf)));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * 64 + j * 32 + frow, kk * 2 + fhalf)));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#undef ISSUE_TILE
-#undef GLDS
-    gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
-}
-
-
-// ------------------------------------------------------------------------------------------------ v3: counted pipeline
+// ------------------------------------------------------------------------------------------------ LDS-DMA helpers
 // hipcc treats the global_load_lds builtin as a store to LDS that may alias the fragment reads and drains it
 // (s_waitcnt vmcnt(0)) before the first ds_read of the same iteration: v2 never overlaps a tile's DMA with MFMAs inside
 // a workgroup.  v3 issues the DMA from inline asm (invisible to the compiler's dependence tracking), keeps NS LDS stages
@@ -310,92 +228,6 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
-
-template <int MODE, int MT, int NS>
-__global__ __launch_bounds__(256, (NS == 2 ? 2 : 1)) void gemm_pipe_kernel(const bf16_t* __restrict__ A, int lda,
-                                                                            const bf16_t* __restrict__ W, int ldw,
-                                                                            void* __restrict__ Cv, int ldc, int M, int N, int K,
-                                                                            GemmEpilogue ep, int tiles_n, int nwg) {
-    constexpr int BMv = MT * 64;
-    constexpr int A_BYTES = BMv * 128;
-    constexpr int STAGE = A_BYTES + 16384;
-    constexpr int AJ = BMv / 32;   // A DMA pieces per wave per tile
-    constexpr int LPT = AJ + 4;    // DMA pieces per wave per tile (A + W)
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const int m0 = tm * BMv, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int lrow = lane >> 3, pslot = lane & 7;
-    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
-    const bf16_t* a_src[AJ];
-    const bf16_t* w_src[4];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + 4 * j) + lrow, M - 1) * lda + sslot * 8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + 4 * j) + lrow, N - 1) * ldw + sslot * 8;
-    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
-
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = K / BK;
-    auto issue = [&](int kt) {
-        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) glds16_asm(a_src[j] + kt * BK, sb + j * 4096);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_asm(w_src[j] + kt * BK, sb + A_BYTES + j * 4096);
-    };
-    // prologue: NS-1 tiles in flight
-#pragma unroll
-    for (int t = 0; t < NS - 1; ++t)
-        if (t < nk) issue(t);
-
-    const int frow = lane & 31, fhalf = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tiles issued so far: min(nk, kt + NS - 1); tile kt must have landed: allow (issued - kt - 1) tiles outstanding
-        const int ahead = min(nk, kt + NS - 1) - kt - 1;
-        if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * LPT>();
-        else if (NS >= 3 && ahead == 1) wait_vmcnt<LPT>();
-        else if (ahead <= 0) wait_vmcnt<0>();
-        else wait_vmcnt<(NS >= 3 ? LPT : 0)>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue(kt + NS - 1);
-        const char* As = smem + (kt % NS) * STAGE;
-        const char* Ws = As + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[MT], fw[2];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(wm * (MT * 32) + i * 32 + frow, kk * 2 + fhalf)));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * 64 + j * 32 + frow, kk * 2 + fhalf)));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
-        }
-        asm volatile("" ::: "memory");  // keep this tile's ds_reads above the next iteration's barrier
-    }
-    gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
-}
-
 
 // ------------------------------------------------------------------------------------------------ v4: rotated pipeline
 // v3 still parks the matrix pipe at every K-step boundary: after the barrier a wave must issue its DMA pieces and wait
@@ -596,82 +428,68 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
 }
 
+
 }  // namespace
 
-static int g_cfg_mt = 0, g_cfg_ns = 0;
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
-        // ACE355_GEMM = v1 (register-staged) | v2 (DMA, compiler-scheduled) | v3 (DMA, counted pipeline; default)
-        // ACE355_GEMM_CFG = "MT,NS" pins v3's tile height (MT*64) and stage count for experiments.
+        // ACE355_GEMM=v1 selects the simple register-staged kernel (A/B + bring-up reference); default = LDS-DMA pipeline
         const char* e = getenv("ACE355_GEMM");
-        v = (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '4') ? (e[1] - '0') : 4;  // v4 = rotated pipeline (default)
-        const char* c = getenv("ACE355_GEMM_CFG");
-        if (c && c[0] >= '2' && c[0] <= '4' && c[1] == ',' && c[2] >= '2' && c[2] <= '4') {
-            g_cfg_mt = c[0] - '0';
-            g_cfg_ns = c[2] - '0';
-        }
+        v = (e && e[0] == 'v' && e[1] == '1') ? 1 : 4;
     }
     return v;
 }
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 template <int MODE>
-static void launch_mode(int variant, int mt, int ns, dim3 grid, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw,
-                        void* C, int ldc, int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
-#define ACE_LAUNCH_T(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg)
-#define ACE_LAUNCH(kern) ACE_LAUNCH_T(kern, 256)
-#define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, sp_grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
-    if (variant == 1) ACE_LAUNCH(gemm_kernel<MODE>);
-    else if (variant == 2) {
-        if (mt == 3) ACE_LAUNCH((gemm_glds_kernel<MODE, 3>));
-        else ACE_LAUNCH((gemm_glds_kernel<MODE, 2>));
-    } else if (variant == 4) {
-        static int abl = -1, group_m = -1, xcd_m_env = -1;
-        if (group_m < 0) { const char* e = getenv("ACE355_GEMM_GROUPM"); group_m = e ? atoi(e) : 4; }
-        if (xcd_m_env < 0) { const char* e = getenv("ACE355_GEMM_XCDM"); xcd_m_env = e ? atoi(e) : 0; }
-        // XCD grid: minimise xcd_n*|A| + xcd_m*|W| = (8/xm) * M + xm * N (same K), over xm in {1,2,4,8}
-        const int tiles_m_ = nwg / tiles_n;
-        int xcd_m = 8;
-        {
-            double best = 1e30;
-            for (int xm = 1; xm <= 8; xm *= 2) {
-                const int xn = 8 / xm;
-                if (xm > tiles_m_ || xn > tiles_n) continue;
-                const double cost = (double)xn * M + (double)xm * N;
-                if (cost < best) { best = cost; xcd_m = xm; }
-            }
-            if (xcd_m_env == 1 || xcd_m_env == 2 || xcd_m_env == 4 || xcd_m_env == 8) xcd_m = xcd_m_env;
-        }
-        const int xcd_n_ = 8 / xcd_m;
-        const int region = ((tiles_m_ + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n_ - 1) / xcd_n_);
-        const dim3 sp_grid(8 * region);
-        if (abl < 0) { const char* e = getenv("ACE355_GEMM_ABL"); abl = e ? atoi(e) : 0; }
-        static int ilv = -1;
-        if (ilv < 0) { const char* e = getenv("ACE355_GEMM_ILV"); ilv = e ? atoi(e) : 1; }  // interleaved schedule (default on)
-        if (ilv && !abl) {
-            if (ns == 8) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
-            else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
-            else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
-        } else if (ns == 8) {  // 192x256 tile, 8 waves
-            if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
-            else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 3>), 512);
-            else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
-        } else if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 1>), 256);
-        else if (abl == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2>), 256);
-        else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 3>), 256);
-        else if (abl == 4) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 4>), 256);
-        else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
-        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2>), 256);
-    } else {
-        if (mt == 2 && ns == 2) ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 2>));
-        else if (mt == 3 && ns == 2) ACE_LAUNCH((gemm_pipe_kernel<MODE, 3, 2>));
-        else if (mt == 2 && ns == 4) ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 4>));
-        else if (mt == 3 && ns == 3) ACE_LAUNCH((gemm_pipe_kernel<MODE, 3, 3>));
-        else if (mt == 4 && ns == 3) ACE_LAUNCH((gemm_pipe_kernel<MODE, 4, 3>));
-        else ACE_LAUNCH((gemm_pipe_kernel<MODE, 2, 2>));
+static void launch_mode(int variant, int mt, bool big, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc,
+                        int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
+    if (variant == 1) {
+        hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+        return;
     }
-#undef ACE_LAUNCH
-#undef ACE_LAUNCH_T
+    static int abl = -1, group_m = -1, xcd_m_env = -1, ilv = -1;
+    if (abl < 0) {
+        abl = env_int("ACE355_GEMM_ABL", 0);          // timing ablations (results garbage)
+        group_m = env_int("ACE355_GEMM_GROUPM", 4);    // rasterisation group height
+        xcd_m_env = env_int("ACE355_GEMM_XCDM", 0);    // pin the XCD grid shape
+        ilv = env_int("ACE355_GEMM_ILV", 1);           // interleaved DMA / fragment-read schedule
+    }
+    // XCD grid: minimise xcd_n*|A| + xcd_m*|W| = (8/xm) * M + xm * N (same K), over xm in {1,2,4,8}
+    const int tiles_m = nwg / tiles_n;
+    int xcd_m = 8;
+    {
+        double best = 1e30;
+        for (int xm = 1; xm <= 8; xm *= 2) {
+            const int xn = 8 / xm;
+            if (xm > tiles_m || xn > tiles_n) continue;
+            const double cost = (double)xn * M + (double)xm * N;
+            if (cost < best) { best = cost; xcd_m = xm; }
+        }
+        if (xcd_m_env == 1 || xcd_m_env == 2 || xcd_m_env == 4 || xcd_m_env == 8) xcd_m = xcd_m_env;
+    }
+    const int xcd_n = 8 / xcd_m;
+    const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
+    const dim3 grid(8 * region);
+#define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
+    if (ilv && !abl) {
+        if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
+        else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
+        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
+    } else if (big) {
+        if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
+        else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 3>), 512);
+        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+    } else if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 1>), 256);
+    else if (abl == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2>), 256);
+    else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 3>), 256);
+    else if (abl == 4) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 4>), 256);
+    else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
+    else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2>), 256);
 #undef ACE_LAUNCH_SP
 }
 
@@ -686,32 +504,28 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     // Tile choice.  The kernel is L2->LDS bandwidth bound (ablation in DESIGN.md), so the biggest tile that still fills
     // the chip wins: 192x256 (8 waves, 110 flop per staged byte) when it yields >= ~0.8 x 256 workgroups, else the
     // 4-wave 128/192 x 128 tiles with the height that minimises (rounds of 512 resident workgroups) x rows.
-    int mt = 2, ns = 2, bn = BN;
-    if (variant >= 2) {
+    int mt = 2, bn = BN;
+    bool big = false;
+    if (variant != 1) {
         const long slots = 512;
         const long tn128 = (N + 127) / 128;
         const long t128 = (long)((M + 127) / 128) * tn128, t192 = (long)((M + 191) / 192) * tn128;
         const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
         if (c192 < c128) mt = 3;
-        if (variant >= 3 && g_cfg_mt) { mt = g_cfg_mt; ns = g_cfg_ns; }
-        if (variant == 4 && mt > 3) mt = 3;
-        if (variant == 4) {
-            static int big = -1;
-            if (big < 0) { const char* e = getenv("ACE355_GEMM_BIG"); big = e ? atoi(e) : 1; }
-            const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
-            if (big == 2 || (big == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; ns = 8; bn = 256; }
-        }
+        static int bigenv = -1;
+        if (bigenv < 0) bigenv = env_int("ACE355_GEMM_BIG", 1);  // 0 never, 1 heuristic, 2 always
+        const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = true; }
     }
     const int tiles_n = (N + bn - 1) / bn;
     const int bm = mt * 64;
     const int tiles_m = (M + bm - 1) / bm;
     const int nwg = tiles_m * tiles_n;
-    dim3 grid(nwg);
     switch (ep.mode) {
-        case 0: launch_mode<0>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 1: launch_mode<1>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 2: launch_mode<2>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
-        case 3: launch_mode<3>(variant, mt, ns, grid, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 0: launch_mode<0>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 1: launch_mode<1>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 2: launch_mode<2>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 3: launch_mode<3>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         default: ACE_CHECK(false, "gemm: bad epilogue mode");
     }
     ACE_LAUNCH_CHECK();

@@ -111,6 +111,9 @@ int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, 
                        const float* sc2, const float* sh1, const float* sh2, int stride, int rows_per_seq, hipStream_t s);
 int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const float* w, float eps,
                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s);
+// one launch for q heads [0,split) with weight w and k heads [split,heads) with weight w2 (contiguous columns)
+int launch_headnorm_rope2(bf16_t* x, int M, int ld, int col0, int heads, const float* w, const float* w2, int split, float eps,
+                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s);
 // vt[n][h][d][s] (ld = s_pad) <- x[(n*S + s)*ld + col0 + h*128 + d]
 int launch_transpose_v(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vt, int s_pad, hipStream_t s);
 int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s);

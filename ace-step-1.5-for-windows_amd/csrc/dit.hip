@@ -292,9 +292,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
         rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
         if (rc) return rc;
-        rc = launch_headnorm_rope(h->qkv, M, QKV, 0, h->HQ, W.qn_s, eps, h->rope_cos, h->rope_sin, S, s);
-        if (rc) return rc;
-        rc = launch_headnorm_rope(h->qkv, M, QKV, QD, h->KVH, W.kn_s, eps, h->rope_cos, h->rope_sin, S, s);
+        rc = launch_headnorm_rope2(h->qkv, M, QKV, 0, h->HQ + h->KVH, W.qn_s, W.kn_s, h->HQ, eps, h->rope_cos, h->rope_sin, S, s);
         if (rc) return rc;
         rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
         if (rc) return rc;

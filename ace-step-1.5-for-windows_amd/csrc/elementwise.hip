@@ -14,6 +14,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // y = bf16( w * (x * rsqrt(mean(x^2) + eps)) * (1 + sc) + sh )     (Qwen3RMSNorm + base.py:499,530,1496)
 // one wave per row; x f32 [M, D]
+template <int NCH>  // NCH = D / 256 float4 chunks per lane held in registers (0: generic two-pass)
 __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           bf16_t* __restrict__ y, int M, int D, float eps,
                                                           const float* __restrict__ sc1, const float* __restrict__ sc2,
@@ -23,17 +24,25 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* xr = x + (long)row * D;
+    float4 xv[NCH > 0 ? NCH : 1];
     float ss = 0.f;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (NCH > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            xv[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+            ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+        }
+    } else {
+        for (int c = lane * 4; c < D; c += 256) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
     }
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)D + eps);
     const long so = sc1 ? (long)(row / rows_per_seq) * stride : 0;
     bf16_t* yr = y + (long)row * D;
-    for (int c = lane * 4; c < D; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    auto emit = [&](int c, const float4 v) {
         const float4 ww = *reinterpret_cast<const float4*>(w + c);
         float o0 = ww.x * (v.x * rstd), o1 = ww.y * (v.y * rstd), o2 = ww.z * (v.z * rstd), o3 = ww.w * (v.w * rstd);
         if (sc1) {
@@ -46,10 +55,13 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
             o2 = o2 * (1.f + (a.z + b.z)) + (e.z + f.z);
             o3 = o3 * (1.f + (a.w + b.w)) + (e.w + f.w);
         }
-        uint2 p;
-        p.x = pack_bf2(o0, o1);
-        p.y = pack_bf2(o2, o3);
-        *reinterpret_cast<uint2*>(yr + c) = p;
+        *reinterpret_cast<uint2*>(yr + c) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+    };
+    if (NCH > 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) emit(i * 256 + lane * 4, xv[i]);
+    } else {
+        for (int c = lane * 4; c < D; c += 256) emit(c, *reinterpret_cast<const float4*>(xr + c));
     }
 }
 
@@ -57,7 +69,8 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
 // In-place per-head RMSNorm(128) (+ RoPE, rotate-half form) on bf16 x[M, ld], heads at col0 + h*128.
 // 16 lanes per head: lane j holds d = 4j..4j+3 and 64+4j..64+4j+3 (the rotate_half partners).
 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, int M, int ld, int col0, int heads,
-                                                            const float* __restrict__ w, float eps,
+                                                            const float* __restrict__ w, const float* __restrict__ w2, int split,
+                                                            float eps,
                                                             const float* __restrict__ cos_tab,
                                                             const float* __restrict__ sin_tab, int S) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
@@ -81,8 +94,9 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float rstd = rsqrtf(ss * (1.f / 128.f) + eps);
-    const float4 wl = *reinterpret_cast<const float4*>(w + j * 4);
-    const float4 wh = *reinterpret_cast<const float4*>(w + 64 + j * 4);
+    const float* wp = (head >= split) ? w2 : w;  // heads [0,split) use w (q_norm), the rest w2 (k_norm)
+    const float4 wl = *reinterpret_cast<const float4*>(wp + j * 4);
+    const float4 wh = *reinterpret_cast<const float4*>(wp + 64 + j * 4);
     a[0] = wl.x * (a[0] * rstd); a[1] = wl.y * (a[1] * rstd); a[2] = wl.z * (a[2] * rstd); a[3] = wl.w * (a[3] * rstd);
     b[0] = wh.x * (b[0] * rstd); b[1] = wh.y * (b[1] * rstd); b[2] = wh.z * (b[2] * rstd); b[3] = wh.w * (b[3] * rstd);
     if (cos_tab) {
@@ -438,16 +452,26 @@ int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, 
                        const float* sc2, const float* sh1, const float* sh2, int stride, int rows_per_seq, hipStream_t s) {
     ACE_CHECK(D % 4 == 0, "rmsnorm: D % 4");
     ACE_CHECK(!sc1 || (sc2 && sh1 && sh2 && rows_per_seq > 0), "rmsnorm: modulation needs all four vectors");
-    hipLaunchKernelGGL(rmsnorm_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride,
-                       rows_per_seq > 0 ? rows_per_seq : 1);
+    const int rps = rows_per_seq > 0 ? rows_per_seq : 1;
+    if (D == 2048) hipLaunchKernelGGL(rmsnorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
+    else if (D == 256) hipLaunchKernelGGL(rmsnorm_mod_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
+    else hipLaunchKernelGGL(rmsnorm_mod_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     ACE_LAUNCH_CHECK();
     return 0;
 }
 
+int launch_headnorm_rope2(bf16_t* x, int M, int ld, int col0, int heads, const float* w, const float* w2, int split, float eps,
+                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s) {
+    const long threads = (long)M * heads * 16;
+    hipLaunchKernelGGL(headnorm_rope_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, x, M, ld, col0, heads, w, w2, split, eps,
+                       cos_tab, sin_tab, S > 0 ? S : 1);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
 int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const float* w, float eps, const float* cos_tab,
                          const float* sin_tab, int S, hipStream_t s) {
     const long threads = (long)M * heads * 16;
-    hipLaunchKernelGGL(headnorm_rope_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, x, M, ld, col0, heads, w, eps,
+    hipLaunchKernelGGL(headnorm_rope_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, x, M, ld, col0, heads, w, w, heads, eps,
                        cos_tab, sin_tab, S > 0 ? S : 1);
     ACE_LAUNCH_CHECK();
     return 0;

@@ -12,18 +12,25 @@
 // V is consumed pre-transposed ([d][key], produced by transpose_v_kernel / the cross-KV cache builder).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace ace355 {
 
 namespace {
 
-constexpr int QB = 128;  // query rows per workgroup
 constexpr int KB = 64;   // keys per tile
 
 __device__ __forceinline__ int k_off(int key, int slot) { return key * 256 + ((slot ^ (key & 15)) << 4); }
 // V^T tile: row d = 128 B (64 keys); 8-byte chunk c8 (4 keys) stored at c8 ^ ((d>>1)&15)
 __device__ __forceinline__ int vt_off8(int d, int c8) { return d * 128 + ((c8 ^ ((d >> 1) & 15)) << 3); }
 
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_log2) {
+// NW = waves per workgroup = 32-query row groups (4: 128 queries, 3: 96 queries - picked by the launcher so that the
+// workgroup count is a whole number of rounds of the 512 resident slots).
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs a, float scale_log2) {
+    constexpr int QB = NW * 32;
+    constexpr int NT = NW * 64;                       // threads
+    constexpr int NI = (1024 + NT - 1) / NT;          // staging passes over the 1024 16-B chunks of a K (or V^T) tile
     __shared__ __attribute__((aligned(16))) char smem[32768];  // K tile 16 KB | V^T tile 16 KB
     char* Ks = smem;
     char* Vs = smem + 16384;
@@ -64,47 +71,43 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
     const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
     const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
 
-    // staging assignment: K chunk c = tid + i*256 -> key = (tid>>4) + 16 i, slot = tid & 15;
-    //                     V^T chunk            -> d = (tid>>3) + 32 i, j = tid & 7
-    const int skey = tid >> 4, sslot = tid & 15, sd = tid >> 3, sj = tid & 7;
-    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
-#define LOAD_KV(key0_)                                                                                          \
-    {                                                                                                           \
-        const bf16_t* kp_ = kbase + sslot * 8;                                                                  \
-        rk0 = ldg16(kp_ + (long)min((key0_) + skey, a.Skv - 1) * a.k_row_stride);      \
-        rk1 = ldg16(kp_ + (long)min((key0_) + skey + 16, a.Skv - 1) * a.k_row_stride); \
-        rk2 = ldg16(kp_ + (long)min((key0_) + skey + 32, a.Skv - 1) * a.k_row_stride); \
-        rk3 = ldg16(kp_ + (long)min((key0_) + skey + 48, a.Skv - 1) * a.k_row_stride); \
-        const bf16_t* vp_ = vbase + (key0_) + sj * 8;                                                           \
-        rv0 = ldg16(vp_ + (long)(sd)*a.vt_ld);                                        \
-        rv1 = ldg16(vp_ + (long)(sd + 32) * a.vt_ld);                                 \
-        rv2 = ldg16(vp_ + (long)(sd + 64) * a.vt_ld);                                 \
-        rv3 = ldg16(vp_ + (long)(sd + 96) * a.vt_ld);                                 \
-    }
-    // (d>>1)&15 for d = sd + 32 i is i-invariant; so is key&15 for key = skey + 16 i
-    const int vx = (sd >> 1) & 15;
-    const int k_st = skey * 256 + ((sslot ^ (skey & 15)) << 4);
-    const int v_st = sd * 128 + ((sj ^ (vx >> 1)) << 4);
-#define SWAPH(v) ((vx & 1) ? make_uint4((v).z, (v).w, (v).x, (v).y) : (v))  /* 8-B halves swap places under the XOR */
-#define STORE_KV()                                                   \
-    {                                                                \
-        *reinterpret_cast<uint4*>(Ks + k_st) = rk0;                  \
-        *reinterpret_cast<uint4*>(Ks + k_st + 4096) = rk1;           \
-        *reinterpret_cast<uint4*>(Ks + k_st + 8192) = rk2;           \
-        *reinterpret_cast<uint4*>(Ks + k_st + 12288) = rk3;          \
-        *reinterpret_cast<uint4*>(Vs + v_st) = SWAPH(rv0);           \
-        *reinterpret_cast<uint4*>(Vs + v_st + 4096) = SWAPH(rv1);    \
-        *reinterpret_cast<uint4*>(Vs + v_st + 8192) = SWAPH(rv2);    \
-        *reinterpret_cast<uint4*>(Vs + v_st + 12288) = SWAPH(rv3);   \
-    }
+    // staging assignment: chunk c = tid + i*NT;  K: key = c>>4, slot = c&15;  V^T: d = c>>3, j = c&7
+    uint4 rk[NI], rv[NI];
+    auto load_kv = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * NT;
+            if (NI * NT == 1024 || c < 1024) {
+                const int key = c >> 4, slot = c & 15;
+                rk[i] = ldg16(kbase + (long)min(key0 + key, a.Skv - 1) * a.k_row_stride + slot * 8);
+                const int d = c >> 3, j = c & 7;
+                rv[i] = ldg16(vbase + (long)d * a.vt_ld + key0 + j * 8);
+            }
+        }
+    };
+    auto store_kv = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = tid + i * NT;
+            if (NI * NT == 1024 || c < 1024) {
+                const int key = c >> 4, slot = c & 15;
+                *reinterpret_cast<uint4*>(Ks + k_off(key, slot)) = rk[i];
+                const int d = c >> 3, j = c & 7;
+                const int x = (d >> 1) & 15;
+                uint4 v = rv[i];
+                if (x & 1) v = make_uint4(v.z, v.w, v.x, v.y);  // the two 8-B halves swap places under the XOR
+                *reinterpret_cast<uint4*>(Vs + d * 128 + ((j ^ (x >> 1)) << 4)) = v;
+            }
+        }
+    };
 
-    if (kt_lo < kt_hi) LOAD_KV(kt_lo * KB)
+    if (kt_lo < kt_hi) load_kv(kt_lo * KB);
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int key0 = kt * KB;
         __syncthreads();  // previous tile fully consumed
-        STORE_KV()
+        store_kv();
         __syncthreads();
-        if (kt + 1 < kt_hi) LOAD_KV(key0 + KB)  // next tile's HBM/L2 latency hides under this tile's MFMAs
+        if (kt + 1 < kt_hi) load_kv(key0 + KB);  // next tile's HBM/L2 latency hides under this tile's MFMAs
 
         // ---- S^T[key][q] = sum_d K[key][d] Q[q][d]
         f32x16 s[2];
@@ -184,9 +187,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnArgs a, float scale_lo
                 }
             }
     }
-#undef LOAD_KV
-#undef STORE_KV
-#undef SWAPH
 
     // ---- finalize: O[q][d] = O^T[d][q] / l ; lane holds d = dt*32 + 8g + 4*half + {0..3} for g = 0..3
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -212,9 +212,24 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     ACE_CHECK(a.Hq % a.Hkv == 0, "attention: Hq % Hkv");
     ACE_CHECK(a.vt_ld % 64 == 0 && a.vt_ld >= ((a.Skv + 63) / 64) * 64, "attention: V^T row stride must be a padded multiple of 64");
     ACE_CHECK(a.q_row_stride % 8 == 0 && a.k_row_stride % 8 == 0 && a.o_row_stride % 4 == 0, "attention: strides");
-    dim3 grid((a.Sq + QB - 1) / QB, a.Hq, a.N), block(256);
     const float scale_log2 = a.scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_kernel, grid, block, 0, s, a, scale_log2);
+    // 2 workgroups per CU are resident (VGPR-bound): pick the block height that wastes fewer resident-slot rounds
+    auto cost = [&](int qb) {
+        const long blocks = (long)((a.Sq + qb - 1) / qb) * a.Hq * a.N;
+        return (double)((blocks + 511) / 512) * qb;
+    };
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ACE355_ATTN_NW"); force = e ? atoi(e) : 0; }
+    // measured (metric config, same box): the 96-query variant is 4% SLOWER than 128 despite the better slot quantisation
+    // (256 VGPRs + spill); it is opt-in via ACE355_ATTN_NW=3 / =-1 (cost model) for other shapes.
+    const bool three = force == 3 || (force == -1 && cost(96) < cost(128));
+    if (three) {
+        dim3 grid((a.Sq + 95) / 96, a.Hq, a.N);
+        hipLaunchKernelGGL(attn_kernel<3>, grid, dim3(192), 0, s, a, scale_log2);
+    } else {
+        dim3 grid((a.Sq + 127) / 128, a.Hq, a.N);
+        hipLaunchKernelGGL(attn_kernel<4>, grid, dim3(256), 0, s, a, scale_log2);
+    }
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -28,22 +28,23 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 // 32x32 accumulator tile.  FULL = the whole block tile is inside [0,M) x [0,N): no per-element predicates.  The fp32
 // residual update (mode 2) issues its 16 loads per accumulator tile back to back, then the FMAs, then the stores - a
 // predicated load/add/store per element serialises ~100 dependent HBM round trips per lane.
-template <int MODE, int MT, bool FULL>
-__device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[MT][2], void* __restrict__ Cv, int ldc, int M, int N,
+template <int MODE, int MT, bool FULL, int NTW>
+__device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
                                                    const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
-    if (MODE == 3) {
+    if (MODE == 3 && NTW == 2) {
         // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up of the same column
         bf16_t* out = reinterpret_cast<bf16_t*>(Cv);
         const int col = ((n0 + wn * 64) >> 1) + frow;
         const bool nok = FULL || (n0 + wn * 64 + 32 + frow) < N;
+        constexpr int J1 = NTW - 1;  // == 1 (keeps acc[i][1] well-formed when this branch is dead code for NTW == 1)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * (MT * 32) + i * 32 + mfma_row(r, lane);
                 if (FULL || (m < M && nok)) {
-                    const float g = acc[i][0][r], u = acc[i][1][r];
+                    const float g = acc[i][0][r], u = acc[i][J1][r];
                     out[(long)m * ldc + col] = f2bf(silu_f(g) * u);
                 }
             }
@@ -51,8 +52,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[MT][2], void* _
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + frow;
+    for (int j = 0; j < NTW; ++j) {
+        const int n = n0 + wn * (NTW * 32) + j * 32 + frow;
         if (!FULL && n >= N) continue;
         float bias = 0.f, g1 = 1.f, cv = 0.f;
         if (MODE == 2 && ep.cvec) cv = ep.cvec[n];
@@ -109,12 +110,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[MT][2], void* _
     }
 }
 
-template <int MODE, int MT>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], void* __restrict__ Cv, int ldc, int M, int N,
+template <int MODE, int MT, int NTW = 2>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
                                               const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane, int bm = MT * 64,
                                               int bn = 128) {
-    if (m0 + bm <= M && n0 + bn <= N) gemm_epilogue_impl<MODE, MT, true>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
-    else gemm_epilogue_impl<MODE, MT, false>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+    if (m0 + bm <= M && n0 + bn <= N) gemm_epilogue_impl<MODE, MT, true, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+    else gemm_epilogue_impl<MODE, MT, false, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
 }
 
 template <int MODE>
@@ -239,13 +240,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Two LDS stages (2 workgroups per CU), one barrier per K-step, >= 8 MFMAs of cover on both sides of every LDS read.
 // WNW = waves along N (2 -> BN 128, 256 threads, 2 workgroups/CU; 4 -> BN 256, 512 threads, 1 workgroup/CU).
 // ABL (timing ablation only, results garbage): 1 no DMA in loop, 2 no LDS fragment reads in loop, 3 both, 4 no barrier
-template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
+// NTW = 32-column accumulator tiles per wave (2: wave tile MT*32 x 64; 1: MT*32 x 32, used for the 8-wave 192x128 tile).
+template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0, int NTW = 2>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
     constexpr int BMv = MT * 64;
     constexpr int A_BYTES = BMv * 128;
-    constexpr int BNv = WNW * 64;
+    constexpr int BNv = WNW * NTW * 32;
+    static_assert(MODE != 3 || NTW == 2, "SwiGLU pairs two column tiles per wave");
     constexpr int NW = 2 * WNW;                 // waves per workgroup
     constexpr int W_BYTES = BNv * 128;
     constexpr int STAGE = A_BYTES + W_BYTES;
@@ -290,11 +293,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     for (int j = 0; j < WJ; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * ldw + sslot * 8;
     const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
 
-    f32x16 acc[MT][2];
+    f32x16 acc[MT][NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -308,33 +311,33 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     };
     const int frow = lane & 31, fhalf = lane >> 5;
     // per-lane fragment byte offsets inside a stage for kk = 0 (the kk term only flips slot bits: see lds_off)
-    int a_off[MT], w_off[2];
+    int a_off[MT], w_off[NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i) a_off[i] = (wm * (MT * 32) + i * 32 + frow) * 128;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w_off[j] = A_BYTES + (wn * 64 + j * 32 + frow) * 128;
+    for (int j = 0; j < NTW; ++j) w_off[j] = A_BYTES + (wn * (NTW * 32) + j * 32 + frow) * 128;
     const int swz = ((wm * (MT * 32) + frow) >> 1) & 7;   // (row>>1)&7 is the same for every 32-row tile of this lane
-    const int swzw = ((wn * 64 + frow) >> 1) & 7;
-    auto load_frags = [&](const char* st, int kk0, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][2]) {
+    const int swzw = ((wn * (NTW * 32) + frow) >> 1) & 7;
+    auto load_frags = [&](const char* st, int kk0, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int slot = (kk0 + h) * 2 + fhalf;
 #pragma unroll
             for (int i = 0; i < MT; ++i) fa[h][i] = as_bf16x8(*reinterpret_cast<const uint4*>(st + a_off[i] + ((slot ^ swz) << 4)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
+            for (int j = 0; j < NTW; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
         }
     };
-    auto mma = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][2]) {
+    auto mma = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[h][i], fw[h][j], acc[i][j]);
+                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma32(fa[h][i], fw[h][j], acc[i][j]);
     };
 
-    bf16x8 pa[2][MT], pw[2][2], qa[2][MT], qw[2][2];
+    bf16x8 pa[2][MT], pw[2][NTW], qa[2][MT], qw[2][NTW];
     issue(0);
     if (nk > 1) issue(1);
     if (nk > 1) wait_vmcnt<AJ + WJ>(); else wait_vmcnt<0>();
@@ -346,15 +349,15 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // back to back right after the barrier stall the in-order wave before its first MFMA.  Here every MFMA is followed
     // by at most one DMA piece or two fragment reads, pinned with sched_barrier.
     if (ILV) {
-        constexpr int NM = 2 * MT * 2;  // MFMAs per half K-step
-        constexpr int NF = 2 * (MT + 2);  // fragment reads per half K-step
+        constexpr int NM = 2 * MT * NTW;  // MFMAs per half K-step
+        constexpr int NF = 2 * (MT + NTW);  // fragment reads per half K-step
         auto frag_ptr = [&](const char* st, int kk0, int f) -> const uint4* {
-            const int h = f / (MT + 2), e = f % (MT + 2);
+            const int h = f / (MT + NTW), e = f % (MT + NTW);
             const int slot = (kk0 + h) * 2 + fhalf;
             return reinterpret_cast<const uint4*>(e < MT ? st + a_off[e] + ((slot ^ swz) << 4) : st + w_off[e - MT] + ((slot ^ swzw) << 4));
         };
-        auto frag_store = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][2], int f, uint4 v) {
-            const int h = f / (MT + 2), e = f % (MT + 2);
+        auto frag_store = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW], int f, uint4 v) {
+            const int h = f / (MT + NTW), e = f % (MT + NTW);
             if (e < MT) fa[h][e] = as_bf16x8(v); else fw[h][e - MT] = as_bf16x8(v);
         };
         for (int kt = 0; kt < nk; ++kt) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int h = m / (MT * 2), i = (m / 2) % MT, j = m % 2;
+                const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
                 acc[i][j] = mfma32(pa[h][i], pw[h][j], acc[i][j]);
 #pragma unroll
                 for (int f = 2 * m; f < 2 * m + 2; ++f)
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             const bool dma = kt + 2 < nk;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int h = m / (MT * 2), i = (m / 2) % MT, j = m % 2;
+                const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
                 acc[i][j] = mfma32(qa[h][i], qw[h][j], acc[i][j]);
                 if (m < AJ + WJ) {
                     if (dma) {
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                         else glds16_asm(w_src[m - AJ] + (kt + 2) * BK, sb + A_BYTES + (m - AJ) * (NW * 1024));
                     }
                 }
+                static_assert(AJ + WJ <= NM, "at most one DMA piece per MFMA slot");
                 if (more) {
                     constexpr int F0 = (AJ + WJ < NM) ? (AJ + WJ) : 0;  // first MFMA slot that carries fragment reads
                     constexpr int PER = (NF + (NM - F0) - 1) / (NM - F0);
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
+        gemm_epilogue<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
         return;
     }
 
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     }
     // (an LDS-transposed 16-byte-store epilogue was tried for modes 0/3 and measured 3-12% SLOWER than these direct
     //  64-byte-segment stores: two extra barriers + 96 ds_write_b16 per lane)
-    gemm_epilogue<MODE, MT>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
+    gemm_epilogue<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
 }
 
 
@@ -446,7 +450,7 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <int MODE>
-static void launch_mode(int variant, int mt, bool big, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc,
+static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc,
                         int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
     if (variant == 1) {
         hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
@@ -477,7 +481,9 @@ static void launch_mode(int variant, int mt, bool big, hipStream_t s, const bf16
     const dim3 grid(8 * region);
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if (ilv && !abl) {
-        if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
+        if (big == 2) {
+            if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
+        } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
         else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
         else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
     } else if (big) {
@@ -505,7 +511,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     // the chip wins: 192x256 (8 waves, 110 flop per staged byte) when it yields >= ~0.8 x 256 workgroups, else the
     // 4-wave 128/192 x 128 tiles with the height that minimises (rounds of 512 resident workgroups) x rows.
     int mt = 2, bn = BN;
-    bool big = false;
+    int big = 0;  // 0: 4-wave 128/192x128 tiles, 1: 8-wave 192x256, 2: 8-wave 192x128
     if (variant != 1) {
         const long slots = 512;
         const long tn128 = (N + 127) / 128;
@@ -515,7 +521,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         static int bigenv = -1;
         if (bigenv < 0) bigenv = env_int("ACE355_GEMM_BIG", 1);  // 0 never, 1 heuristic, 2 always
         const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
-        if (bigenv == 2 || (bigenv == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = true; }
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
+        else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 && t192 <= 320))) { mt = 3; bn = 128; big = 2; }
     }
     const int tiles_n = (N + bn - 1) / bn;
     const int bm = mt * 64;

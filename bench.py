@@ -298,7 +298,7 @@ def main():
         p = dit.get_profile()
         dit.set_profile(False)
         gemm_tf = p["gemm_flops"] / (p["gemm_ms"] * 1e-3) / 1e12 if p["gemm_ms"] > 0 else 0.0
-        result["roofline"] = {"bound": "mfma", "kernel": "gemm_sp_kernel (bf16 MFMA 32x32x16; 192x256x64 8-wave / 128-192x128x64 4-wave tiles, LDS-DMA staging)",
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_sp_kernel (bf16 MFMA 32x32x16; 192x256x64 and 192x128x64 8-wave / 128-192x128x64 4-wave tiles, LDS-DMA staging)",
                               "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
                               "traffic": pmc_traffic_bytes_per_launch(), "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
                               "avg_launch_us": 1000.0 * p["gemm_ms"] / max(p["gemm_launches"], 1),

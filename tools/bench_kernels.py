@@ -40,6 +40,7 @@ def bench_gemm():
     M = 6000
     shapes = [("qkv", M, 4096, 2048, "store"), ("o/q_c (N=2048)", M, 2048, 2048, "store"), ("o_proj resid", M, 2048, 2048, "resid"),
               ("gate_up swiglu", M, 12288, 2048, "swiglu"), ("down resid", M, 2048, 6144, "resid"), ("patchify", M, 2048, 384, "f32"),
+              ("cross q (M=3000)", 3000, 2048, 2048, "store"), ("cross o resid (M=3000)", 3000, 2048, 2048, "resid"),
               ("M=750 qkv", 750, 4096, 2048, "store"), ("M=750 down", 750, 2048, 6144, "resid"), ("M=24000 gate_up", 24000, 12288, 2048, "swiglu")]
     for name, M_, N, K, mode in shapes:
         A = torch.randn(M_, K, device=dev).to(torch.bfloat16)

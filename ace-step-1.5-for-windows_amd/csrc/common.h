@@ -90,6 +90,7 @@ struct GemmEpilogue {
     int rows_per_seq;
     const float* cvec;  // mode 2: rows m >= cvec_row0 additionally get + cvec[n] (constant cross-attention term of broadcast slots)
     int cvec_row0;
+    int wide_ok;  // set by launch_gemm: C / ldc / per-column vectors are 16-byte aligned, so the 16-byte staged epilogue may be used
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);

@@ -24,98 +24,181 @@ constexpr int BM = 128, BN = 128, BK = 64;
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 
-// Epilogue shared by all mainloops.  Lane holds column n = .. + (lane&31) and 16 rows m = .. + mfma_row(r, lane) of each
-// 32x32 accumulator tile.  FULL = the whole block tile is inside [0,M) x [0,N): no per-element predicates.  The fp32
-// residual update (mode 2) issues its 16 loads per accumulator tile back to back, then the FMAs, then the stores - a
-// predicated load/add/store per element serialises ~100 dependent HBM round trips per lane.
-template <int MODE, int MT, bool FULL, int NTW>
-__device__ __forceinline__ void gemm_epilogue_impl(f32x16 (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
-                                                   const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane) {
+// Epilogue shared by all mainloops.  Every mainloop issues its MFMAs with the operands SWAPPED (D = Wfrag x Afrag^T), so in
+// a 32x32 accumulator tile lane l holds ONE output row m = .. + (l&31) and, per register quad g = r>>2, FOUR consecutive
+// columns n = .. + 8g + 4(l>>5) + (r&3).  The stores of an MFMA epilogue are issue-bound (cost per instruction, not per
+// byte: a 2-byte-per-lane store pattern cost 7.5 us per 192x256 tile round, 16 % of the GEMM time), so the tile goes
+// through a wave-private LDS staging image and leaves as full 128-byte lines, 16 bytes per lane:
+//   bf16 modes: pack 4 columns -> ds_write_b64;  fp32 modes: ds_write_b128, one 32-column half (j) at a time;
+//   read back row-major (8 lanes x 16 B = one 128-byte row, XOR-swizzled 16-B slots), then global 16-B loads / stores.
+// The fp32 residual update (mode 2) issues all its loads for a half before the FMAs and stores.
+// Tiles that are partial in N (or a misaligned C) take the scalar path below.
+template <int RB>
+__device__ __forceinline__ int stage_off(int row, int slot) {
+    return RB == 128 ? row * 128 + ((slot ^ (row & 7)) << 4) : row * 64 + ((slot ^ ((row >> 1) & 3)) << 4);
+}
+
+__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int MODE, int MT, int NTW, bool ROWS_FULL>
+__device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
+                                                   int M, const GemmEpilogue& ep, int mw0, int nw0, int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
-    if (MODE == 3 && NTW == 2) {
-        // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up of the same column
-        bf16_t* out = reinterpret_cast<bf16_t*>(Cv);
-        const int col = ((n0 + wn * 64) >> 1) + frow;
-        const bool nok = FULL || (n0 + wn * 64 + 32 + frow) < N;
-        constexpr int J1 = NTW - 1;  // == 1 (keeps acc[i][1] well-formed when this branch is dead code for NTW == 1)
+    if constexpr (MODE == 0 || MODE == 3) {
+        static_assert(MODE != 3 || NTW == 2, "SwiGLU pairs two column tiles per wave");
+        constexpr int NJ = (MODE == 3) ? 1 : NTW;   // 32-column groups in the staged image
+        constexpr int RB = NJ * 64;                 // staged row bytes
+        constexpr int J1 = NTW - 1;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (MT * 32) + i * 32 + mfma_row(r, lane);
-                if (FULL || (m < M && nok)) {
-                    const float g = acc[i][0][r], u = acc[i][J1][r];
-                    out[(long)m * ldc + col] = f2bf(silu_f(g) * u);
-                }
-            }
-        }
-        return;
-    }
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const int n = n0 + wn * (NTW * 32) + j * 32 + frow;
-        if (!FULL && n >= N) continue;
-        float bias = 0.f, g1 = 1.f, cv = 0.f;
-        if (MODE == 2 && ep.cvec) cv = ep.cvec[n];
-        if (MODE <= 1 && ep.bias) bias = ep.bias[n];
-        if (MODE == 2 && ep.g1) g1 = ep.g1[n];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mb = m0 + wm * (MT * 32) + i * 32 + 4 * fhalf;
-            if (MODE == 2) {
-                float* hp = reinterpret_cast<float*>(Cv) + n;
-                const int rps = ep.rows_per_seq;
-                // this lane's 16 rows span 28 consecutive rows: with rps >= 28 they touch at most two sequences
-                float gA = 1.f, gB = 1.f;
-                int seq0 = 0, rem0 = 0;
-                if (ep.g1) {
-                    seq0 = mb / rps;
-                    rem0 = mb - seq0 * rps;
-                    const int last = (M - 1) / rps;
-                    gA = g1 + ep.g2[(long)min(seq0, last) * ep.g2_stride + n];
-                    gB = g1 + ep.g2[(long)min(seq0 + 1, last) * ep.g2_stride + n];
-                }
-                float hv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    const int m = FULL ? (mb + off) : min(mb + off, M - 1);
-                    hv[r] = hp[(long)m * ldc];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int off = (r & 3) + 8 * (r >> 2);
-                    const int m = mb + off;
-                    float gate = (rem0 + off >= rps) ? gB : gA;
-                    if (ep.g1 && rps < 28) {  // short sequences (tiny configs): generic per-row lookup
-                        const int sq = min(m, M - 1) / rps;
-                        gate = g1 + ep.g2[(long)sq * ep.g2_stride + n];
+                for (int g = 0; g < 4; ++g) {
+                    float v0, v1, v2, v3;
+                    if constexpr (MODE == 3) {  // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up
+                        v0 = silu_f(acc[i][0][4 * g + 0]) * acc[i][J1][4 * g + 0];
+                        v1 = silu_f(acc[i][0][4 * g + 1]) * acc[i][J1][4 * g + 1];
+                        v2 = silu_f(acc[i][0][4 * g + 2]) * acc[i][J1][4 * g + 2];
+                        v3 = silu_f(acc[i][0][4 * g + 3]) * acc[i][J1][4 * g + 3];
+                    } else {
+                        v0 = acc[i][j][4 * g + 0]; v1 = acc[i][j][4 * g + 1]; v2 = acc[i][j][4 * g + 2]; v3 = acc[i][j][4 * g + 3];
+                        if (ep.bias) {
+                            const float4 b = ldf4(ep.bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+                            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                        }
                     }
-                    float add = gate * acc[i][j][r];
-                    if (ep.cvec && m >= ep.cvec_row0) add += cv;
-                    if (FULL || m < M) hp[(long)m * ldc] = hv[r] + add;
+                    uint2 pk;
+                    pk.x = pack_bf2(v0, v1);
+                    pk.y = pack_bf2(v2, v3);
+                    *reinterpret_cast<uint2*>(stg + stage_off<RB>(i * 32 + frow, j * 4 + g) + 8 * fhalf) = pk;
                 }
-                __builtin_amdgcn_sched_barrier(0);  // one tile's 16 loads in flight at a time: hoisting all MT*2 tiles spills
-            } else {
+        constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per staged row, rows per store instruction
+        const int rsub = lane / LPR, slot = lane % LPR;
+        bf16_t* out = reinterpret_cast<bf16_t*>(Cv) + (MODE == 3 ? (nw0 >> 1) : nw0) + slot * 8;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2);
-                    if (!FULL && m >= M) continue;
-                    const float v = acc[i][j][r];
-                    if (MODE == 0) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + bias);
-                    else reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + bias;
+        for (int t = 0; t < MT * 32 / RPI; ++t) {
+            const int row = t * RPI + rsub;
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
+            const int m = mw0 + row;
+            if (ROWS_FULL || m < M) *reinterpret_cast<uint4*>(out + (long)m * ldc) = v;
+        }
+    } else {
+        constexpr int NT = MT * 4;  // 8-row groups per 32-column half
+        const int rsub = lane >> 3, slot = lane & 7;
+        const int rps = ep.rows_per_seq;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 a;
+                    a.x = acc[i][j][4 * g + 0]; a.y = acc[i][j][4 * g + 1]; a.z = acc[i][j][4 * g + 2]; a.w = acc[i][j][4 * g + 3];
+                    *reinterpret_cast<float4*>(stg + stage_off<128>(i * 32 + frow, 2 * g + fhalf)) = a;
+                }
+            const int n = nw0 + j * 32 + slot * 4;
+            float* hp = reinterpret_cast<float*>(Cv) + n;
+            if constexpr (MODE == 1) {
+                float4 b = {0.f, 0.f, 0.f, 0.f};
+                if (ep.bias) b = ldf4(ep.bias + n);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int row = t * 8 + rsub;
+                    float4 a = *reinterpret_cast<const float4*>(stg + stage_off<128>(row, slot));
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                    const int m = mw0 + row;
+                    if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = a;
+                }
+            } else {
+                float4 g1 = {1.f, 1.f, 1.f, 1.f}, gA = g1, gB = g1, cv = {0.f, 0.f, 0.f, 0.f};
+                int remA = 0;
+                const bool two_gate = MT * 32 <= rps;  // the wave's rows touch at most two sequences
+                if (ep.cvec) cv = ldf4(ep.cvec + n);
+                if (ep.g1) {
+                    g1 = ldf4(ep.g1 + n);
+                    const int seqA = mw0 / rps, last = (M - 1) / rps;
+                    remA = mw0 - seqA * rps;
+                    const float4 a2 = ldf4(ep.g2 + (long)min(seqA, last) * ep.g2_stride + n);
+                    const float4 b2 = ldf4(ep.g2 + (long)min(seqA + 1, last) * ep.g2_stride + n);
+                    gA = {g1.x + a2.x, g1.y + a2.y, g1.z + a2.z, g1.w + a2.w};
+                    gB = {g1.x + b2.x, g1.y + b2.y, g1.z + b2.z, g1.w + b2.w};
+                }
+                float4 hv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int m = mw0 + t * 8 + rsub;
+                    hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int row = t * 8 + rsub;
+                    const int m = mw0 + row;
+                    const float4 a = *reinterpret_cast<const float4*>(stg + stage_off<128>(row, slot));
+                    float4 gt = (remA + row >= rps) ? gB : gA;
+                    if (ep.g1 && !two_gate) {  // short sequences (tiny configs): per-row lookup
+                        const float4 r2 = ldf4(ep.g2 + (long)(min(m, M - 1) / rps) * ep.g2_stride + n);
+                        gt = {g1.x + r2.x, g1.y + r2.y, g1.z + r2.z, g1.w + r2.w};
+                    }
+                    float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
+                    if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
+                    if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
                 }
             }
         }
     }
 }
 
+// Per-element path for tiles that are partial in N or whose C / vectors are not 16-byte aligned (unit-test shapes, tiny configs).
+template <int MODE, int MT, int NTW>
+__device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
+                                                     const GemmEpilogue& ep, int mw0, int nw0, int lane) {
+    const int frow = lane & 31, fhalf = lane >> 5;
+    constexpr int J1 = NTW - 1;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mw0 + i * 32 + frow;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < (MODE == 3 ? 1 : NTW); ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nl = j * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
+                if (MODE == 3) {
+                    if (nw0 + 32 + nl < N) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + (nw0 >> 1) + nl] = f2bf(silu_f(acc[i][0][r]) * acc[i][J1][r]);
+                    continue;
+                }
+                const int n = nw0 + nl;
+                if (n >= N) continue;
+                const float v = acc[i][j][r];
+                if (MODE == 0) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + (ep.bias ? ep.bias[n] : 0.f));
+                else if (MODE == 1) reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + (ep.bias ? ep.bias[n] : 0.f);
+                else {
+                    float gate = 1.f;
+                    if (ep.g1) gate = ep.g1[n] + ep.g2[(long)(m / ep.rows_per_seq) * ep.g2_stride + n];
+                    float add = gate * v;
+                    if (ep.cvec && m >= ep.cvec_row0) add += ep.cvec[n];
+                    reinterpret_cast<float*>(Cv)[(long)m * ldc + n] += add;
+                }
+            }
+    }
+}
+
+// smem: the workgroup's LDS (dead after the K loop; every wave stages MT*32 rows x 128 B in its own slice of it).
 template <int MODE, int MT, int NTW = 2>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
-                                              const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int lane, int bm = MT * 64,
-                                              int bn = 128) {
-    if (m0 + bm <= M && n0 + bn <= N) gemm_epilogue_impl<MODE, MT, true, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
-    else gemm_epilogue_impl<MODE, MT, false, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem, void* __restrict__ Cv, int ldc, int M, int N,
+                                              const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int wave, int lane,
+                                              int bm = MT * 64, int bn = 128) {
+    const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NTW * 32);
+    if (ep.wide_ok && n0 + bn <= N) {  // workgroup-uniform
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();  // every wave is done reading operand fragments: the stages may be overwritten
+        char* stg = smem + wave * (MT * 32 * 128);
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane);
+        else gemm_epilogue_wide<MODE, MT, NTW, false>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane);
+    } else {
+        gemm_epilogue_scalar<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
+    }
 }
 
 template <int MODE>
@@ -197,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);
         }
         if (more) {
             char* Ad = smem + ((kt + 1) & 1) * 32768;
@@ -206,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
         __syncthreads();
     }
 
-    gemm_epilogue<MODE, 2>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane);
+    gemm_epilogue<MODE, 2>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane);
 }
 
 
@@ -255,7 +338,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     constexpr int AJ = BMv / (8 * NW);          // A DMA pieces per wave per tile (8 rows each)
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int EPI_BYTES = NW * MT * 32 * 128;  // epilogue staging: MT*32 rows x 128 B per wave
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
 
     // Workgroup -> tile map.  Block b runs on XCD b % 8 (observed, speed only).  The 8 XCDs (private L2s) form an
     // xcd_m x xcd_n grid of rectangular tile regions, chosen per GEMM to minimise the bytes each L2 must pull from
@@ -334,7 +418,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma32(fa[h][i], fw[h][j], acc[i][j]);
+                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma32(fw[h][j], fa[h][i], acc[i][j]);
     };
 
     bf16x8 pa[2][MT], pw[2][NTW], qa[2][MT], qw[2][NTW];
@@ -366,7 +450,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
-                acc[i][j] = mfma32(pa[h][i], pw[h][j], acc[i][j]);
+                acc[i][j] = mfma32(pw[h][j], pa[h][i], acc[i][j]);
 #pragma unroll
                 for (int f = 2 * m; f < 2 * m + 2; ++f)
                     if (f < NF) frag_store(qa, qw, f, *frag_ptr(st, 2, f));
@@ -384,7 +468,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
-                acc[i][j] = mfma32(qa[h][i], qw[h][j], acc[i][j]);
+                acc[i][j] = mfma32(qw[h][j], qa[h][i], acc[i][j]);
                 if (m < AJ + WJ) {
                     if (dma) {
                         if (m < AJ) glds16_asm(a_src[m] + (kt + 2) * BK, sb + m * (NW * 1024));
@@ -404,7 +488,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        gemm_epilogue<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
+        gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
         return;
     }
 
@@ -429,7 +513,141 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     }
     // (an LDS-transposed 16-byte-store epilogue was tried for modes 0/3 and measured 3-12% SLOWER than these direct
     //  64-byte-segment stores: two extra barriers + 96 ds_write_b16 per lane)
-    gemm_epilogue<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, m0, n0, wm, wn, lane, BMv, BNv);
+    gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+}
+
+// ------------------------------------------------------------------------------------------------ v5: ping-pong wave groups
+// Same 192x256x64 tile, LDS image and DMA as v4, different schedule.  The 8 waves form two groups of four (group = wave>>2,
+// one wave of each group per SIMD).  Every half K-step is split into a MEM section (fragment ds_reads, DMA issue, waits)
+// and an MFMA section (12 back-to-back MFMAs at raised priority), each closed by a workgroup barrier; group 1 executes one
+// extra barrier up front, so it runs exactly one section behind group 0:
+//        barrier clock   |  4T        4T+1       4T+2       4T+3      |
+//        group 0         |  MEM(T,0)  MFMA(T,0)  MEM(T,1)   MFMA(T,1) |
+//        group 1         |  MFMA(T-1,1) MEM(T,0) MFMA(T,0)  MEM(T,1)  |
+// On each SIMD one wave feeds the matrix pipe while its partner issues memory instructions: a DMA piece's 60-185 cycle
+// issue stall never sits in front of an MFMA.
+//   WAR: tile T+1 is DMA'd into stage (T+1)&1 from MEM(T,0) on; the last reads of tile T-1 (group 1, MEM(T-1,1)) were
+//        retired (lgkmcnt(0)) before barrier 4T.
+//   RAW: every wave waits for its own pieces of tile T+1 (vmcnt(0)) at the end of MEM(T,1), before barrier 4T+3 (group 0)
+//        / 4T+4 (group 1); the first read of tile T+1 (group 0, MEM(T+1,0)) comes after barrier 4T+4.
+template <int MODE, int ABL = 0>  // ABL (timing only, results garbage): 1 DMA always re-reads K-tile 0, 2 no DMA in loop, 3 no fragment reads
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
+                                                         void* __restrict__ Cv, int ldc, int M, int N, int K, GemmEpilogue ep,
+                                                         int tiles_n, int nwg, int group_m, int xcd_m) {
+    constexpr int MT = 3, NTW = 2, WNW = 4, NW = 8;
+    constexpr int BMv = MT * 64, BNv = WNW * NTW * 32;
+    constexpr int A_BYTES = BMv * 128, W_BYTES = BNv * 128, STAGE = A_BYTES + W_BYTES;
+    constexpr int AJ = BMv / (8 * NW), WJ = BNv / (8 * NW);
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    int tm, tn;
+    {
+        const int tiles_m = nwg / tiles_n;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd_n = 8 / xcd_m;
+        const int rm = (tiles_m + xcd_m - 1) / xcd_m, rn = (tiles_n + xcd_n - 1) / xcd_n;
+        const int xi = xcd / xcd_n, xj = xcd - xi * xcd_n;
+        const int m_lo = xi * rm, n_lo = xj * rn;
+        const int hm = min(rm, tiles_m - m_lo), hn = min(rn, tiles_n - n_lo);
+        if (hm <= 0 || hn <= 0 || idx >= hm * hn) return;
+        const int gsz = group_m * hn;
+        const int grp = idx / gsz, rem = idx - grp * gsz;
+        const int first_m = grp * group_m;
+        const int gm = min(hm - first_m, group_m);
+        tm = m_lo + first_m + rem % gm;
+        tn = n_lo + rem / gm;
+    }
+    const int m0 = tm * BMv, n0 = tn * BNv;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+
+    const int lrow = lane >> 3, pslot = lane & 7;
+    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
+    const bf16_t* a_src[AJ];
+    const bf16_t* w_src[WJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + NW * j) + lrow, M - 1) * lda + sslot * 8;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * ldw + sslot * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
+
+    f32x16 acc[MT][NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    auto issue = [&](int kt) {
+        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
+        const int ks = (ABL == 1) ? 0 : kt;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) glds16_asm(a_src[j] + ks * BK, sb + j * (NW * 1024));
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) glds16_asm(w_src[j] + ks * BK, sb + A_BYTES + j * (NW * 1024));
+    };
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int a_off[MT], w_off[NTW];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_off[i] = (wm * (MT * 32) + i * 32 + frow) * 128;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) w_off[j] = A_BYTES + (wn * (NTW * 32) + j * 32 + frow) * 128;
+    const int swz = ((wm * (MT * 32) + frow) >> 1) & 7;
+    const int swzw = ((wn * (NTW * 32) + frow) >> 1) & 7;
+    bf16x8 fa[2][MT], fw[2][NTW];
+    auto load_frags = [&](const char* st, int kk0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int slot = (kk0 + h) * 2 + fhalf;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[h][i] = as_bf16x8(*reinterpret_cast<const uint4*>(st + a_off[i] + ((slot ^ swz) << 4)));
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
+        }
+    };
+    auto mma = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma32(fw[h][j], fa[h][i], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define ACE_PP_BARRIER()                    \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);
+
+    issue(0);
+    wait_vmcnt<0>();
+    ACE_PP_BARRIER()
+    if (wm == 1) { ACE_PP_BARRIER() }  // group 1 runs one section behind group 0
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + (kt & 1) * STAGE;
+        // MEM(kt, 0): fragments of kk = 0,1; DMA of the next tile into the other stage
+        if (ABL != 3 || kt == 0) load_frags(st, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk && ABL != 2) issue(kt + 1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        ACE_PP_BARRIER()
+        mma();
+        ACE_PP_BARRIER()
+        // MEM(kt, 1): fragments of kk = 2,3; this wave's pieces of the next tile must have landed before the barrier
+        if (ABL != 3) load_frags(st, 2);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        wait_vmcnt<0>();
+        ACE_PP_BARRIER()
+        mma();
+        ACE_PP_BARRIER()
+    }
+    if (wm == 0) { ACE_PP_BARRIER() }  // balance group 1's extra barrier
+#undef ACE_PP_BARRIER
+    gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
 }
 
 
@@ -456,8 +674,9 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
         return;
     }
-    static int abl = -1, group_m = -1, xcd_m_env = -1, ilv = -1;
+    static int abl = -1, group_m = -1, xcd_m_env = -1, ilv = -1, pp = 0;
     if (abl < 0) {
+        pp = env_int("ACE355_GEMM_PP", 0);             // ping-pong wave-group schedule for the 192x256 tile
         abl = env_int("ACE355_GEMM_ABL", 0);          // timing ablations (results garbage)
         group_m = env_int("ACE355_GEMM_GROUPM", 4);    // rasterisation group height
         xcd_m_env = env_int("ACE355_GEMM_XCDM", 0);    // pin the XCD grid shape
@@ -483,7 +702,11 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     if (ilv && !abl) {
         if (big == 2) {
             if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
-        } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
+        } else if (big && pp == 1) ACE_LAUNCH_SP((gemm_pp_kernel<MODE>), 512);
+        else if (big && pp == 11) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 1>), 512);
+        else if (big && pp == 12) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 2>), 512);
+        else if (big && pp == 13) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 3>), 512);
+        else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
         else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
         else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
     } else if (big) {
@@ -500,7 +723,15 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
 }
 
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
-                const GemmEpilogue& ep, hipStream_t s) {
+                const GemmEpilogue& ep_in, hipStream_t s) {
+    GemmEpilogue ep = ep_in;
+    {
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const int per16 = (ep.mode == 0 || ep.mode == 3) ? 8 : 4;  // elements of C per 16 bytes
+        ep.wide_ok = al16(C) && (ldc % per16) == 0 && al16(ep.bias) && al16(ep.g1) && al16(ep.g2) && al16(ep.cvec) &&
+                     (ep.g2_stride % 4) == 0;
+        if (env_int("ACE355_GEMM_SCALAR_EPI", 0)) ep.wide_ok = 0;  // A/B + test hook
+    }
     ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");
     ACE_CHECK((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-B rows)");

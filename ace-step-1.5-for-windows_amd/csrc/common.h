@@ -90,6 +90,7 @@ struct GemmEpilogue {
     int rows_per_seq;
     const float* cvec;  // mode 2: rows m >= cvec_row0 additionally get + cvec[n] (constant cross-attention term of broadcast slots)
     int cvec_row0;
+    int clk_probe;  // set by launch_gemm (ACE355_GEMM_CLK diagnostic)
     int wide_ok;  // set by launch_gemm: C / ldc / per-column vectors are 16-byte aligned, so the 16-byte staged epilogue may be used
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
@@ -105,6 +106,7 @@ struct AttnArgs {
     bf16_t* out; long o_seq_stride; int o_row_stride;
     int N, Sq, Skv, Hq, Hkv, window;
     float scale;
+    int clk_probe;  // set by launch_attention (ACE355_ATTN_CLK diagnostic)
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 

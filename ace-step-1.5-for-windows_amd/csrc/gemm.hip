@@ -13,6 +13,7 @@
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace ace355 {
@@ -20,6 +21,10 @@ namespace ace355 {
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
+
+// ACE355_GEMM_CLK=1 (diagnostic): workgroup 0 records shader-clock and 100 MHz wall-clock deltas around its K loop;
+// launch_gemm then prints the effective shader clock (DVFS) and the cycles per K-step to stderr.
+__device__ unsigned long long g_clk_probe[4];
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
@@ -324,7 +329,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // WNW = waves along N (2 -> BN 128, 256 threads, 2 workgroups/CU; 4 -> BN 256, 512 threads, 1 workgroup/CU).
 // ABL (timing ablation only, results garbage): 1 no DMA in loop, 2 no LDS fragment reads in loop, 3 both, 4 no barrier
 // NTW = 32-column accumulator tiles per wave (2: wave tile MT*32 x 64; 1: MT*32 x 32, used for the 8-wave 192x128 tile).
-template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0, int NTW = 2>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
+// PERS 1: persistent workgroups - the grid is one workgroup per CU slot and each walks its XCD region's tiles with stride
+// gridDim/8: no s_endpgm store drain, no workgroup re-dispatch and no kernarg reload between the tiles of a multi-round GEMM.
+template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0, int NTW = 2, int PERS = 0>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
@@ -345,10 +352,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // xcd_m x xcd_n grid of rectangular tile regions, chosen per GEMM to minimise the bytes each L2 must pull from
     // HBM/MALL (xcd_n * |A| + xcd_m * |W|); inside a region tiles are walked in groups of `group_m` rows so the ~32
     // workgroups resident on one XCD share both A row-panels and W column-panels.
+    for (int idx = blockIdx.x >> 3;; idx += (int)(gridDim.x >> 3)) {
     int tm, tn;
     {
         const int tiles_m = nwg / tiles_n;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = blockIdx.x & 7;
         const int xcd_n = 8 / xcd_m;
         const int rm = (tiles_m + xcd_m - 1) / xcd_m, rn = (tiles_n + xcd_n - 1) / xcd_n;  // region size in tiles
         const int xi = xcd / xcd_n, xj = xcd - xi * xcd_n;
@@ -444,6 +452,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             const int h = f / (MT + NTW), e = f % (MT + NTW);
             if (e < MT) fa[h][e] = as_bf16x8(v); else fw[h][e - MT] = as_bf16x8(v);
         };
+        unsigned long long c0 = 0, w0 = 0;
+        const bool probe = ep.clk_probe && blockIdx.x == 0 && tid == 0;
+        if (probe) { c0 = clock64(); w0 = wall_clock64(); }
         for (int kt = 0; kt < nk; ++kt) {
             const char* st = smem + (kt & 1) * STAGE;
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
@@ -488,8 +499,16 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (probe) {
+            g_clk_probe[0] = clock64() - c0;
+            g_clk_probe[1] = wall_clock64() - w0;
+            g_clk_probe[2] = (unsigned long long)nk;
+        }
         gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
-        return;
+        if (!PERS) return;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();  // every wave has read back its staging slice: the next tile's DMA may overwrite it
+        continue;
     }
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -514,6 +533,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // (an LDS-transposed 16-byte-store epilogue was tried for modes 0/3 and measured 3-12% SLOWER than these direct
     //  64-byte-segment stores: two extra barriers + 96 ds_write_b16 per lane)
     gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+    return;  // (the non-interleaved schedules are single-tile only)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ v5: ping-pong wave groups
@@ -674,8 +695,9 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
         return;
     }
-    static int abl = -1, group_m = -1, xcd_m_env = -1, ilv = -1, pp = 0;
+    static int abl = -1, group_m = -1, xcd_m_env = -1, ilv = -1, pp = 0, pers = 0;
     if (abl < 0) {
+        pers = env_int("ACE355_GEMM_PERS", 1);         // persistent workgroups for multi-round launches
         pp = env_int("ACE355_GEMM_PP", 0);             // ping-pong wave-group schedule for the 192x256 tile
         abl = env_int("ACE355_GEMM_ABL", 0);          // timing ablations (results garbage)
         group_m = env_int("ACE355_GEMM_GROUPM", 4);    // rasterisation group height
@@ -706,7 +728,11 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         else if (big && pp == 11) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 1>), 512);
         else if (big && pp == 12) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 2>), 512);
         else if (big && pp == 13) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 3>), 512);
-        else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
+        else if (big && pers && region > 32) {
+            const dim3 pgrid(8 * 32);
+            hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 0, 1, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg,
+                               group_m, xcd_m);
+        } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
         else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
         else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
     } else if (big) {
@@ -731,6 +757,9 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         ep.wide_ok = al16(C) && (ldc % per16) == 0 && al16(ep.bias) && al16(ep.g1) && al16(ep.g2) && al16(ep.cvec) &&
                      (ep.g2_stride % 4) == 0;
         if (env_int("ACE355_GEMM_SCALAR_EPI", 0)) ep.wide_ok = 0;  // A/B + test hook
+        static int clk = -1;
+        if (clk < 0) clk = env_int("ACE355_GEMM_CLK", 0);
+        ep.clk_probe = clk;
     }
     ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");
@@ -767,6 +796,13 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         default: ACE_CHECK(false, "gemm: bad epilogue mode");
     }
     ACE_LAUNCH_CHECK();
+    if (ep.clk_probe) {
+        unsigned long long h[4] = {0, 0, 0, 0};
+        ACE_HIP(hipStreamSynchronize(s));
+        ACE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), sizeof(h)));
+        if (h[1]) fprintf(stderr, "[ace355 gemm clk] M=%d N=%d K=%d mode=%d: %.3f GHz shader clock, %.0f cycles / K-step (%.3f us)\n", M, N, K,
+                          ep.mode, (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2]);
+    }
     return 0;
 }
 

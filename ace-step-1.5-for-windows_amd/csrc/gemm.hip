@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace ace355 {
@@ -313,6 +314,15 @@ __device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_addr) 
                  : "v"(gsrc), "s"(lds_addr)
                  : "memory");
 }
+// same, address = uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: the per-lane part is loop invariant, so a
+// K step costs scalar adds only (the flat form needs a 64-bit VALU add per piece)
+__device__ __forceinline__ void glds16_sv(unsigned voff, const void* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -377,12 +387,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 
     const int lrow = lane >> 3, pslot = lane & 7;
     const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
-    const bf16_t* a_src[AJ];
-    const bf16_t* w_src[WJ];
+    unsigned a_voff[AJ], w_voff[WJ];  // per-lane byte offsets from A / W (launch_gemm checks both matrices are < 4 GB)
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + NW * j) + lrow, M - 1) * lda + sslot * 8;
+    for (int j = 0; j < AJ; ++j) a_voff[j] = ((unsigned)min(m0 + 8 * (wave + NW * j) + lrow, M - 1) * (unsigned)lda + sslot * 8) * 2u;
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * ldw + sslot * 8;
+    for (int j = 0; j < WJ; ++j) w_voff[j] = ((unsigned)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * (unsigned)ldw + sslot * 8) * 2u;
     const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
 
     f32x16 acc[MT][NTW];
@@ -397,9 +406,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     auto issue = [&](int kt) {
         const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) glds16_asm(a_src[j] + kt * BK, sb + j * (NW * 1024));
+        for (int j = 0; j < AJ; ++j) glds16_sv(a_voff[j], A + kt * BK, sb + j * (NW * 1024));
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) glds16_asm(w_src[j] + kt * BK, sb + A_BYTES + j * (NW * 1024));
+        for (int j = 0; j < WJ; ++j) glds16_sv(w_voff[j], W + kt * BK, sb + A_BYTES + j * (NW * 1024));
     };
     const int frow = lane & 31, fhalf = lane >> 5;
     // per-lane fragment byte offsets inside a stage for kk = 0 (the kk term only flips slot bits: see lds_off)
@@ -455,7 +464,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         unsigned long long c0 = 0, w0 = 0;
         const bool probe = ep.clk_probe && blockIdx.x == 0 && tid == 0;
         if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-        for (int kt = 0; kt < nk; ++kt) {
+        auto kstep = [&](int kt, auto more_c, auto dma_c) {
+            constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
             const char* st = smem + (kt & 1) * STAGE;
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
 #pragma unroll
@@ -468,22 +478,22 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
-            const bool more = kt + 1 < nk;
             if (more) {
                 wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
             }
             const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
             const char* stn = smem + ((kt + 1) & 1) * STAGE;
-            const bool dma = kt + 2 < nk;
+            const bf16_t* a_k2 = A + (kt + 2) * BK;  // uniform
+            const bf16_t* w_k2 = W + (kt + 2) * BK;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
                 acc[i][j] = mfma32(qw[h][j], qa[h][i], acc[i][j]);
                 if (m < AJ + WJ) {
                     if (dma) {
-                        if (m < AJ) glds16_asm(a_src[m] + (kt + 2) * BK, sb + m * (NW * 1024));
-                        else glds16_asm(w_src[m - AJ] + (kt + 2) * BK, sb + A_BYTES + (m - AJ) * (NW * 1024));
+                        if (m < AJ) glds16_sv(a_voff[m], a_k2, sb + m * (NW * 1024));
+                        else glds16_sv(w_voff[m - AJ], w_k2, sb + A_BYTES + (m - AJ) * (NW * 1024));
                     }
                 }
                 static_assert(AJ + WJ <= NM, "at most one DMA piece per MFMA slot");
@@ -498,6 +508,14 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        {
+            using T = std::integral_constant<bool, true>;
+            using F = std::integral_constant<bool, false>;
+            int kt = 0;
+            for (; kt + 2 < nk; ++kt) kstep(kt, T{}, T{});      // steady state: branch-free
+            if (kt + 1 < nk) { kstep(kt, T{}, F{}); ++kt; }      // last-but-one K step: nothing left to prefetch
+            kstep(kt, F{}, F{});                                 // last K step
         }
         if (probe) {
             g_clk_probe[0] = clock64() - c0;
@@ -763,6 +781,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     }
     ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");
+    ACE_CHECK((long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31), "gemm: A and W must each be smaller than 4 GB (32-bit DMA offsets)");
     ACE_CHECK((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-B rows)");
     ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");

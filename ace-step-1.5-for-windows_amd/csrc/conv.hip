@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fa[i], fw[j], acc[i][j]);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);  // swapped: lane = one output row, 4 consecutive channels per register quad
             }
             if (more) {
                 char* Wd = Wbase + ((tap + 1) & 1) * (BN * 128);
@@ -133,42 +133,70 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue
-    // lane holds output column n and 16 rows per accumulator tile.  Interior tiles (no row/column/crop predicate) take a
-    // branch-free path whose residual loads are issued 16 at a time before the adds (a predicated load->add->store per
-    // element serialises one memory round trip per element and made the k=1 convs slower than the k=7 ones).
+    // Operands are swapped in the MFMAs, so lane l holds output ROW (position) lq of each 32x32 tile and, per register quad
+    // g = r>>2, four consecutive channels n = .. + 8g + 4*half + (r&3).  Stores (and the residual loads) of an MFMA epilogue
+    // are issue-bound per instruction: interior bf16 tiles go through a wave-private fp32 LDS staging image, one 32-channel
+    // half at a time, and leave as 16-byte row-major accesses (8 loads + 8 stores per lane instead of 64 + 64 two-byte ones).
     const bool full = (m0 + 128 <= a.M) && (n0 + BN <= a.N) &&
                       ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + 127) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
+    const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NT * 32);
+    if (BN == 128 && a.out_mode == 0 && full && a.wide_ok) {  // workgroup-uniform
+        __syncthreads();  // every wave is done with the operand tiles: the LDS may be overwritten
+        char* stg = smem + wave * 8192;  // 64 rows x 128 B (32 floats)
+        const int row_l = lane >> 2, c4 = lane & 3;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * (NT * 32) + j * 32 + lq;
-        if (n >= a.N) continue;
-        const float bias = a.bias ? a.bias[n] : 0.f;
+        for (int j = 0; j < NT; ++j) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mb = m0 + wm * (MT * 32) + i * 32 + 4 * half;
-            if (a.out_mode == 0 && full) {
-                const long base = (long)b * a.y_batch_stride + (long)mb * a.N + n + a.y_shift;
-                bf16_t* yp = reinterpret_cast<bf16_t*>(a.y) + base;
-                float rv[16];
-                if (a.res) {
-                    const bf16_t* rp = a.res + (long)b * a.res_batch_stride + (long)mb * a.N + n + a.y_shift;
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) rv[r] = bf2f(rp[(long)((r & 3) + 8 * (r >> 2)) * a.N]);
+                for (int g = 0; g < 4; ++g) {
+                    float4 v;
+                    v.x = acc[i][j][4 * g + 0]; v.y = acc[i][j][4 * g + 1]; v.z = acc[i][j][4 * g + 2]; v.w = acc[i][j][4 * g + 3];
+                    const int row = i * 32 + lq, slot = 2 * g + half;
+                    *reinterpret_cast<float4*>(stg + row * 128 + ((slot ^ (row & 7)) << 4)) = v;
                 }
+            const int n = nw0 + j * 32 + c4 * 8;
+            float bias[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + bias;
-                    if (a.res) v += rv[r];
-                    yp[(long)((r & 3) + 8 * (r >> 2)) * a.N] = f2bf(v);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                continue;
+            for (int e = 0; e < 8; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
+            const long col = (long)b * a.y_batch_stride + n + a.y_shift;
+            const long rcol = (long)b * a.res_batch_stride + n + a.y_shift;
+            uint4 rv[MT * 2];
+            if (a.res) {
+#pragma unroll
+                for (int t = 0; t < MT * 2; ++t) rv[t] = *reinterpret_cast<const uint4*>(a.res + rcol + (long)(mw0 + t * 16 + row_l) * a.N);
             }
 #pragma unroll
+            for (int t = 0; t < MT * 2; ++t) {
+                const int row = t * 16 + row_l;
+                const float4 lo = *reinterpret_cast<const float4*>(stg + row * 128 + (((2 * c4) ^ (row & 7)) << 4));
+                const float4 hi = *reinterpret_cast<const float4*>(stg + row * 128 + (((2 * c4 + 1) ^ (row & 7)) << 4));
+                float v[8] = {lo.x + bias[0], lo.y + bias[1], lo.z + bias[2], lo.w + bias[3],
+                              hi.x + bias[4], hi.y + bias[5], hi.z + bias[6], hi.w + bias[7]};
+                if (a.res) {
+                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(&rv[t]);
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) { v[2 * e2] += bf_lo(rp[e2]); v[2 * e2 + 1] += bf_hi(rp[e2]); }
+                }
+                uint4 pk;
+                pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]); pk.z = pack_bf2(v[4], v[5]); pk.w = pack_bf2(v[6], v[7]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.y) + col + (long)(mw0 + row) * a.N) = pk;
+            }
+        }
+        return;
+    }
+    // generic per-element path (edge tiles, cropped transposed-conv spans, the fp32 NCL output of the last conv)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mw0 + i * 32 + lq;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bias;
+                const int n = nw0 + j * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (n >= a.N) continue;
+                float v = acc[i][j][r] + (a.bias ? a.bias[n] : 0.f);
                 if (a.out_mode == 0) {
                     const long flat = (long)m * a.N + n + a.y_shift;
                     if (flat < 0 || flat >= a.y_valid) continue;
@@ -178,7 +206,6 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
                     if (n < a.n_real) reinterpret_cast<float*>(a.y)[(long)b * a.y_batch_stride + (long)n * a.M + m] = v;
                 }
             }
-        }
     }
 }
 
@@ -199,12 +226,18 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     ACE_CHECK(a.Cin % 64 == 0, "conv: Cin must be a multiple of 64");
     ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil + 128 <= WIN_MAX && a.dil >= 1, "conv: window too large");
     ACE_CHECK(a.B > 0 && a.M > 0 && a.N > 0, "conv: empty problem");
+    ConvArgs aw = a;
+    {
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
+                     (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
+    }
     if (a.N >= 128 || a.N % 128 == 0) {
         dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.B);
-        hipLaunchKernelGGL(conv_kernel<128>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(conv_kernel<128>, grid, dim3(256), 0, s, aw);
     } else {
         dim3 grid((a.M + 127) / 128, (a.N + 31) / 32, a.B);
-        hipLaunchKernelGGL(conv_kernel<32>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(conv_kernel<32>, grid, dim3(256), 0, s, aw);
     }
     ACE_LAUNCH_CHECK();
     return 0;

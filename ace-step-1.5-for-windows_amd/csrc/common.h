@@ -69,7 +69,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / rcp (1 ulp; results are rounded to bf16 afterwards).  A plain `x / (1 + expf(-x))`
+// compiles to the IEEE division sequence (~10 VALU ops per element): 5 % of the SwiGLU GEMM at 96 elements per lane.
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 
 // MFMA 32x32x16 bf16: D[i][j] += sum_k A[i][k] B[k][j].
 //   A operand: lane l holds A[i = l&31][k = (l>>5)*8 + e], e = 0..7

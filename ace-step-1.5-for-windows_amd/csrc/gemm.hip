@@ -25,7 +25,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 
 // ACE355_GEMM_CLK=1 (diagnostic): workgroup 0 records shader-clock and 100 MHz wall-clock deltas around its K loop;
 // launch_gemm then prints the effective shader clock (DVFS) and the cycles per K-step to stderr.
-__device__ unsigned long long g_clk_probe[4];
+__device__ unsigned long long g_clk_probe[8];
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
@@ -363,6 +363,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // HBM/MALL (xcd_n * |A| + xcd_m * |W|); inside a region tiles are walked in groups of `group_m` rows so the ~32
     // workgroups resident on one XCD share both A row-panels and W column-panels.
     for (int idx = blockIdx.x >> 3;; idx += (int)(gridDim.x >> 3)) {
+    const unsigned long long t_entry = ep.clk_probe ? clock64() : 0ull;
     int tm, tn;
     {
         const int tiles_m = nwg / tiles_n;
@@ -522,7 +523,15 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             g_clk_probe[1] = wall_clock64() - w0;
             g_clk_probe[2] = (unsigned long long)nk;
         }
+        unsigned long long e0 = 0;
+        if (probe) e0 = clock64();
         gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+        if (probe) {
+            g_clk_probe[3] = clock64() - e0;            // epilogue until the last store is ISSUED
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            g_clk_probe[4] = clock64() - e0;            // ... until the stores are acknowledged
+            g_clk_probe[5] = c0 - t_entry;              // tile map + prologue (first two K tiles landed, first fragments read)
+        }
         if (!PERS) return;
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();  // every wave has read back its staging slice: the next tile's DMA may overwrite it
@@ -816,11 +825,13 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     }
     ACE_LAUNCH_CHECK();
     if (ep.clk_probe) {
-        unsigned long long h[4] = {0, 0, 0, 0};
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         ACE_HIP(hipStreamSynchronize(s));
         ACE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), sizeof(h)));
-        if (h[1]) fprintf(stderr, "[ace355 gemm clk] M=%d N=%d K=%d mode=%d: %.3f GHz shader clock, %.0f cycles / K-step (%.3f us)\n", M, N, K,
-                          ep.mode, (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2]);
+        if (h[1]) fprintf(stderr, "[ace355 gemm clk] M=%d N=%d K=%d mode=%d: %.3f GHz shader clock, %.0f cycles / K-step (%.3f us); prologue %.0f, "
+                          "epilogue issue %.0f / acked %.0f cycles (last tile of workgroup 0)\n", M, N, K, ep.mode,
+                          (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2],
+                          (double)h[5], (double)h[3], (double)h[4]);
     }
     return 0;
 }

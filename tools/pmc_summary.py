@@ -7,7 +7,7 @@ launches = collections.defaultdict(set)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        fam = "gemm" if "gemm_" in k else "attn" if "attn_kernel" in k else "conv" if "conv_kernel" in k else "rmsnorm" if "rmsnorm" in k else "other"
+        fam = "gemm" if "gemm_" in k else "attn" if "attn" in k else "conv" if "conv_kernel" in k else "rmsnorm" if "rmsnorm" in k else "other"
         agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[(fam, r["Counter_Name"])].add(r["Dispatch_Id"])
 res = {}

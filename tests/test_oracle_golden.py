@@ -10,6 +10,7 @@ import torch
 
 from ace355 import weightgen
 from oracle import apg as o_apg
+from oracle import cond as o_cond
 from oracle import dit as o_dit
 from oracle import sampler as o_sampler
 from oracle import tiling as o_tiling
@@ -122,6 +123,27 @@ def test_g6_tiling(golden_dir):
         assert out.shape[-1] == Tn * HOP and torch.equal(out[0, 0, ::HOP], torch.arange(Tn, dtype=torch.float32))
     assert G["calls_750_512_64"].tolist() == [448, 430]  # two windows for a 30 s song
     assert torch.equal(o_tiling.peak_normalize(T(G["peak_in"])), T(G["peak_out"]))
+
+
+def tiny_cond_config(window):
+    return o_cond.CondConfig(**TINY_COND, sliding_window=window)
+
+
+TINY_COND = dict(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128,
+                 text_hidden_dim=64, timbre_hidden_dim=64, num_lyric_encoder_hidden_layers=2, num_timbre_encoder_hidden_layers=2)
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_g7_condition_encoder(golden_dir, case):
+    """lyric / timbre encoders + pack_sequences vs the imported reference (incl. padding rows)."""
+    G = np.load(f"{golden_dir}/g7_cond_encoder.npz")
+    cfg = tiny_cond_config(int(G[f"{case}_window"]))
+    w = weightgen.make_dit_weights(o_cond.cond_weight_shapes(cfg), cfg.hidden_size, seed=int(G["seed"]), mode="test")
+    assert weightgen.checksum(w) == float(G[f"{case}_wsum"])
+    h, m = o_cond.condition_encoder(cfg, w, T(G[f"{case}_text"]), T(G[f"{case}_tmask"]), T(G[f"{case}_lyric"]), T(G[f"{case}_lmask"]),
+                                    T(G[f"{case}_refer"]), T(G[f"{case}_order"]))
+    assert torch.equal(m.long(), T(G[f"{case}_m"]))
+    assert float((h - T(G[f"{case}_h"])).abs().max()) < 2e-5
 
 
 def test_latent_guards():

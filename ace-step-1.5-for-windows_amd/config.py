@@ -85,6 +85,68 @@ class DitConfig:
 
 
 @dataclass
+class CondConfig:
+    """Fields of ``AceStepConfig`` used by ``AceStepConditionEncoder`` (modeling_acestep_v15_base.py:1509-1554)."""
+
+    hidden_size: int = 2048
+    intermediate_size: int = 6144
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    sliding_window: int = 128
+    text_hidden_dim: int = 1024
+    timbre_hidden_dim: int = 64
+    num_lyric_encoder_hidden_layers: int = 8
+    num_timbre_encoder_hidden_layers: int = 4
+    layer_types: Optional[List[str]] = None
+
+    def __post_init__(self):
+        if self.layer_types is None:
+            n = max(self.num_lyric_encoder_hidden_layers, self.num_timbre_encoder_hidden_layers)
+            self.layer_types = ["sliding_attention" if (i + 1) % 2 else "full_attention" for i in range(n)]
+
+    @classmethod
+    def from_reference(cls, cfg) -> "CondConfig":
+        return cls(
+            hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+            num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps,
+            rope_theta=float(getattr(cfg, "rope_theta", 1e6)), sliding_window=cfg.sliding_window or 0,
+            text_hidden_dim=cfg.text_hidden_dim, timbre_hidden_dim=cfg.timbre_hidden_dim,
+            num_lyric_encoder_hidden_layers=cfg.num_lyric_encoder_hidden_layers,
+            num_timbre_encoder_hidden_layers=cfg.num_timbre_encoder_hidden_layers, layer_types=list(cfg.layer_types),
+        )
+
+    def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Names/shapes of ``AceStepConditionEncoder.state_dict()`` (608 M parameters at the default config)."""
+        D, Fh, hd = self.hidden_size, self.intermediate_size, self.head_dim
+        q, kv = self.num_attention_heads * hd, self.num_key_value_heads * hd
+        s: Dict[str, Tuple[int, ...]] = {"text_projector.weight": (D, self.text_hidden_dim)}
+        for p, n, din in (("lyric_encoder.", self.num_lyric_encoder_hidden_layers, self.text_hidden_dim),
+                          ("timbre_encoder.", self.num_timbre_encoder_hidden_layers, self.timbre_hidden_dim)):
+            s[p + "embed_tokens.weight"] = (D, din)
+            s[p + "embed_tokens.bias"] = (D,)
+            s[p + "norm.weight"] = (D,)
+            if p == "timbre_encoder.":
+                s[p + "special_token"] = (1, 1, D)
+            for li in range(n):
+                r = f"{p}layers.{li}."
+                s[r + "self_attn.q_proj.weight"] = (q, D)
+                s[r + "self_attn.k_proj.weight"] = (kv, D)
+                s[r + "self_attn.v_proj.weight"] = (kv, D)
+                s[r + "self_attn.o_proj.weight"] = (D, q)
+                s[r + "self_attn.q_norm.weight"] = (hd,)
+                s[r + "self_attn.k_norm.weight"] = (hd,)
+                s[r + "input_layernorm.weight"] = (D,)
+                s[r + "post_attention_layernorm.weight"] = (D,)
+                s[r + "mlp.gate_proj.weight"] = (Fh, D)
+                s[r + "mlp.up_proj.weight"] = (Fh, D)
+                s[r + "mlp.down_proj.weight"] = (D, Fh)
+        return s
+
+
+@dataclass
 class VaeConfig:
     """Decoder half of AutoencoderOobleck.  Strides are run-time data (checkpoints/vae/config.json);
     the synthetic default has hop 1920 (handler/conditioning_target.py:47,53)."""

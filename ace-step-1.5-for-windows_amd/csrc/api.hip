@@ -115,10 +115,35 @@ int ace355_headnorm_rope(void* x, int M, int ld, int col0, int heads, const floa
     return rc;
 }
 
+static int attention_hook(const void* q, const void* k, const void* v, void* out, int N, int Sq, int Skv, int Hq, int Hkv, int window,
+                          float scale, const int32_t* kv_len_host, void* stream);
+
 int ace355_attention(const void* q, const void* k, const void* v, void* out, int N, int Sq, int Skv, int Hq, int Hkv, int window,
                      float scale, void* stream) {
+    return attention_hook(q, k, v, out, N, Sq, Skv, Hq, Hkv, window, scale, nullptr, stream);
+}
+
+int ace355_attention_masked(const void* q, const void* k, const void* v, void* out, int N, int Sq, int Skv, int Hq, int Hkv,
+                            int window, float scale, const int32_t* kv_len_host, void* stream) {
+    ACE_CHECK(kv_len_host, "attention_masked: null kv_len");
+    ACE_CHECK(Sq == Skv, "attention_masked: self-attention only");
+    return attention_hook(q, k, v, out, N, Sq, Skv, Hq, Hkv, window, scale, kv_len_host, stream);
+}
+
+static int attention_hook(const void* q, const void* k, const void* v, void* out, int N, int Sq, int Skv, int Hq, int Hkv, int window,
+                          float scale, const int32_t* kv_len_host, void* stream) {
     ACE_CHECK(q && k && v && out, "attention: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    int* kvl = nullptr;
+    bf16_t* vmean = nullptr;
+    if (kv_len_host) {
+        for (int i = 0; i < N; ++i) ACE_CHECK(kv_len_host[i] >= 0 && kv_len_host[i] <= Skv, "attention_masked: kv_len out of range");
+        ACE_HIP(hipMalloc((void**)&kvl, sizeof(int) * N));
+        ACE_HIP(hipMalloc((void**)&vmean, (size_t)N * Hkv * 128 * 2));
+        ACE_HIP(hipMemcpy(kvl, kv_len_host, sizeof(int) * N, hipMemcpyHostToDevice));
+        int rcm = launch_vmean((const bf16_t*)v, Hkv * 128, 0, N, Skv, Hkv, vmean, s);
+        if (rcm) return rcm;
+    }
     const int Sp = ((Skv + 63) / 64) * 64;
     bf16_t* vt = nullptr;
     ACE_HIP(hipMalloc((void**)&vt, (size_t)N * Hkv * 128 * Sp * 2));
@@ -131,10 +156,13 @@ int ace355_attention(const void* q, const void* k, const void* v, void* out, int
         a.use_tab = 0;
         a.out = (bf16_t*)out; a.o_seq_stride = (long)Sq * Hq * 128; a.o_row_stride = Hq * 128;
         a.N = N; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv; a.window = window; a.scale = scale;
+        a.kv_len = kvl; a.vmean = vmean;
         rc = launch_attention(a, s);
     }
     hipError_t e = hipStreamSynchronize(s);
     hipFree(vt);
+    if (kvl) hipFree(kvl);
+    if (vmean) hipFree(vmean);
     if (e != hipSuccess) return hip_fail(e, "attention sync", __FILE__, __LINE__);
     return rc;
 }

@@ -247,11 +247,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
     const int qrow_c = min(qrow, a.Sq - 1);
     const int win = a.window < 0 ? (1 << 28) : a.window;
     const bool wave_live = qw0 < a.Sq;         // waves past the end of the sequence only help with the DMA
+    const int skv = a.kv_len ? a.kv_len[n] : a.Skv;  // valid (un-padded) keys of this sequence
 
-    int kt_lo = 0, kt_hi = (a.Skv + KB - 1) / KB;
+    int kt_lo = 0, kt_hi = (skv + KB - 1) / KB;
     if (a.window >= 0) {
         kt_lo = max(0, q0 - a.window) / KB;
-        kt_hi = min(kt_hi, (min(a.Skv - 1, q0 + QB - 1 + a.window)) / KB + 1);
+        kt_hi = min(kt_hi, (min(skv - 1, q0 + QB - 1 + a.window)) / KB + 1);
     }
     const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
     const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
                     fr[(t2 * 2 + t) * 4 + dt] =
                         as_bf16x8(*reinterpret_cast<const uint4*>(Vs + dt * 4096 + v_row_off + (((t2 * 4 + 2 * t + half) ^ v_swz) << 4)));
         // lane owns query qrow; register r of s[t2] is key key0 + t2*32 + 16*(r>>3) + 8*half + (r&7)
-        const bool interior = (key0 + KB <= a.Skv) && (qw0 + 31 - key0 <= win) && (key0 + KB - 1 - qw0 <= win);
+        const bool interior = (key0 + KB <= skv) && (qw0 + 31 - key0 <= win) && (key0 + KB - 1 - qw0 <= win);
         if (!interior) {
             const int kb = key0 + 8 * half;
 #pragma unroll
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb + t2 * 32 + 16 * (r >> 3) + (r & 7);
-                    const bool ok = (key < a.Skv) & ((unsigned)(qrow - key + win) <= (unsigned)(2 * win));
+                    const bool ok = (key < skv) & ((unsigned)(qrow - key + win) <= (unsigned)(2 * win));
                     s[t2][r] = ok ? s[t2][r] : -INFINITY;
                 }
         }
@@ -432,7 +433,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
     // O[q][d] = O^T[d][q] / l; register r of o[dt] is d = dt*32 + 16*(r>>3) + 8*half + (r&7)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
-    if (qrow < a.Sq) {
+    if (qrow < a.Sq && l_tot == 0.f) {
+        // no valid key at all (only possible with kv_len): the reference's finfo.min mask makes this row uniform over ALL keys
+        bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 8 * half;
+        const bf16_t* vm = a.vmean + ((long)n * a.Hkv + hkv) * 128 + 8 * half;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(op + c * 16) = *reinterpret_cast<const uint4*>(vm + c * 16);
+    } else if (qrow < a.Sq) {
         bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 8 * half;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -469,7 +476,9 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     // (256 VGPRs + spill); it is opt-in via ACE355_ATTN_NW=3 / =-1 (cost model) for other shapes.
     static int ver = -1;
     if (ver < 0) { const char* e = getenv("ACE355_ATTN"); ver = (e && e[0] == 'v' && e[1] == '2') ? 2 : 3; }
-    if (ver == 3 && (a.o_row_stride % 8) == 0) {
+    ACE_CHECK(!a.kv_len || a.vmean, "attention: kv_len needs vmean");
+    ACE_CHECK(!a.kv_len || (a.o_row_stride % 8) == 0, "attention: key-padding masks need 16-byte aligned output rows");
+    if ((ver == 3 || a.kv_len) && (a.o_row_stride % 8) == 0) {
         // 2 waves per SIMD (256-VGPR budget): 4-wave blocks (128 queries, two workgroups per CU) by default; 8-wave blocks
         // (256 queries, K/V staged once per 256 rows) when the sequence is long enough to fill the chip with them
         static int nw_env = -1;

@@ -111,6 +111,11 @@ struct AttnArgs {
     int N, Sq, Skv, Hq, Hkv, window;
     float scale;
     int clk_probe;  // set by launch_attention (ACE355_ATTN_CLK diagnostic)
+    // key-padding mask of the condition encoders (create_4d_mask with attention_mask, base.py:117-124), prefix form:
+    // keys j >= kv_len[n] are masked.  A query row with NO valid key (padding query outside the band of the valid prefix)
+    // softmaxes to uniform over ALL Skv keys in the reference (the mask is finfo.min, not -inf): it gets vmean[n][hkv][:].
+    const int* kv_len;      // device [N] or null
+    const bf16_t* vmean;    // device [N][Hkv][128], required when kv_len is set
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -124,6 +129,11 @@ int launch_headnorm_rope2(bf16_t* x, int M, int ld, int col0, int heads, const f
 // vt[n][h][d][s] (ld = s_pad) <- x[(n*S + s)*ld + col0 + h*128 + d]
 int launch_transpose_v(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vt, int s_pad, hipStream_t s);
 int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s);
+// vmean[n][h][d] = mean over s in [0,S) of x[(n*S + s)*ld + col0 + h*128 + d]
+int launch_vmean(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vmean, hipStream_t s);
+// dst[r][c] (f32, row stride dst_ld) = src[r][c] (bf16, row stride src_ld) for `rows` rows taken through a per-row source index
+// table (row_src[r] == -1: zero row, < -1: leave dst row r untouched)
+int launch_gather_rows_bf16_f32(const bf16_t* src, long src_ld, const int* row_src, float* dst, long dst_ld, long rows, int cols, hipStream_t s);
 
 struct TVals { float t[64]; };
 int launch_sinusoid(const TVals& tv, int n, float* out /*[n,256]*/, hipStream_t s);

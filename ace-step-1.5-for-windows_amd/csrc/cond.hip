@@ -1,0 +1,427 @@
+// cond.hip - the condition-encoder handle behind ace355.h: weight ingestion/packing and
+// AceStepConditionEncoder.forward (base.py:1509-1554) = text projector + AceStepLyricEncoder (base.py:577-731) +
+// AceStepTimbreEncoder (base.py:997-1178) + two pack_sequences (base.py:138-169).  Host-side orchestration only: every
+// contraction / norm / attention runs on the DiT's kernels (gemm.hip, attn.hip, elementwise.hip).
+//
+// Differences from the DiT layer that matter here: plain residuals (no gates), un-modulated RMSNorm, and REAL key-padding
+// masks on the lyric encoder.  Padding rows are not dead data: the DiT ignores encoder_attention_mask (base.py:1384-1385),
+// so the encoder outputs at padded positions flow into the DiT's cross-attention and must match the reference too -
+// including query rows with no valid key on sliding layers (AttnArgs::vmean).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/ace355.h"
+#include "common.h"
+
+using namespace ace355;
+
+namespace {
+
+struct EncLayerW {
+    bf16_t *wqkv, *wo, *wgu, *wdown;
+    float *n_in, *n_post, *qn, *kn;
+};
+struct EncoderW {
+    int n_layers = 0, in_dim = 0;
+    bf16_t* w_embed = nullptr;
+    float *b_embed = nullptr, *norm = nullptr;
+    std::vector<EncLayerW> layers;
+};
+
+}  // namespace
+
+struct ace355_cond {
+    ace355_cond_config cfg;
+    int D, F, QD, KVD, HQ, KVH;
+    EncoderW lyric, timbre;
+    bf16_t* w_text = nullptr;
+    std::set<std::string> loaded;
+    size_t expected_tensors = 0;
+    bool finalized = false;
+    std::vector<void*> allocs;
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+
+    // workspace (sized for the largest M = rows of one encoder call seen so far)
+    long ws_rows = 0, ws_in = 0;
+    int ws_seqs = 0;
+    std::vector<void*> ws_allocs;
+    bf16_t *in_bf = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr, *vmean = nullptr;
+    bf16_t *lyric_out = nullptr, *timbre_out = nullptr, *text_out = nullptr;
+    float* h = nullptr;
+    int *kvlen_dev = nullptr, *rowsrc_dev = nullptr;
+    long rowsrc_cap = 0;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    int rope_S = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(std::vector<void*>& bag, T** p, size_t n) {
+    void* q = nullptr;
+    ACE_HIP(hipMalloc(&q, n * sizeof(T) + 256));
+    bag.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+#define ALLOC(bag, ptr, n)                     \
+    do {                                       \
+        int _rc = dev_alloc(bag, &(ptr), (n)); \
+        if (_rc) return _rc;                   \
+    } while (0)
+
+struct Dest {
+    void* dst;
+    int is_bf16, mode;
+    long rows, cols, dst_ld, dst_row0;
+    int p0;
+    bool ignore;
+};
+
+// Map a key of AceStepConditionEncoder.state_dict() to its packed destination.
+bool resolve(ace355_cond* h, const std::string& name, Dest* d) {
+    const long D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+    auto rows = [&](void* dst, int bf, long r, long c, long ld, long row0) {
+        *d = Dest{dst, bf, PACK_ROWS, r, c, ld, row0, 0, false};
+        return true;
+    };
+    if (name == "text_projector.weight") return rows(h->w_text, 1, D, h->cfg.text_hidden_dim, h->cfg.text_hidden_dim, 0);
+    for (int e = 0; e < 2; ++e) {
+        const std::string p = e == 0 ? "lyric_encoder." : "timbre_encoder.";
+        if (name.rfind(p, 0) != 0) continue;
+        EncoderW& E = e == 0 ? h->lyric : h->timbre;
+        const std::string r = name.substr(p.size());
+        if (r == "embed_tokens.weight") return rows(E.w_embed, 1, D, E.in_dim, E.in_dim, 0);
+        if (r == "embed_tokens.bias") return rows(E.b_embed, 0, 1, D, D, 0);
+        if (r == "norm.weight") return rows(E.norm, 0, 1, D, D, 0);
+        if (r == "special_token") {  // parameter of the reference module that its forward never reads (base.py:1015)
+            *d = Dest{nullptr, 0, PACK_ROWS, 1, D, D, 0, 0, true};
+            return true;
+        }
+        if (r.rfind("layers.", 0) != 0) return false;
+        const size_t dot = r.find('.', 7);
+        if (dot == std::string::npos) return false;
+        const int li = atoi(r.substr(7, dot - 7).c_str());
+        if (li < 0 || li >= E.n_layers) return false;
+        EncLayerW& L = E.layers[li];
+        const std::string q = r.substr(dot + 1);
+        if (q == "input_layernorm.weight") return rows(L.n_in, 0, 1, D, D, 0);
+        if (q == "post_attention_layernorm.weight") return rows(L.n_post, 0, 1, D, D, 0);
+        if (q == "self_attn.q_proj.weight") return rows(L.wqkv, 1, QD, D, D, 0);
+        if (q == "self_attn.k_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD);
+        if (q == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
+        if (q == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
+        if (q == "self_attn.q_norm.weight") return rows(L.qn, 0, 1, 128, 128, 0);
+        if (q == "self_attn.k_norm.weight") return rows(L.kn, 0, 1, 128, 128, 0);
+        if (q == "mlp.gate_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 0, false}; return true; }
+        if (q == "mlp.up_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 1, false}; return true; }
+        if (q == "mlp.down_proj.weight") return rows(L.wdown, 1, D, F, F, 0);
+        return false;
+    }
+    return false;
+}
+
+int ensure_rope(ace355_cond* h, int S, hipStream_t s) {
+    if (S <= h->rope_S) return 0;
+    int cap = 512;
+    while (cap < S) cap *= 2;
+    ALLOC(h->allocs, h->rope_cos, (size_t)cap * 64);
+    ALLOC(h->allocs, h->rope_sin, (size_t)cap * 64);
+    int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->cfg.rope_theta, s);
+    if (rc) return rc;
+    h->rope_S = cap;
+    return 0;
+}
+
+int ensure_workspace(ace355_cond* h, long rows, long in_elems, int seqs, long s_pad_total, hipStream_t s) {
+    if (rows <= h->ws_rows && in_elems <= h->ws_in && seqs <= h->ws_seqs) return 0;
+    ACE_HIP(hipStreamSynchronize(s));
+    for (void* p : h->ws_allocs) hipFree(p);
+    h->ws_allocs.clear();
+    const long R = std::max(rows, h->ws_rows), I = std::max(in_elems, h->ws_in);
+    const int Q = std::max(seqs, h->ws_seqs);
+    const long D = h->D, QKV = h->QD + 2 * h->KVD;
+    ALLOC(h->ws_allocs, h->in_bf, (size_t)I);
+    ALLOC(h->ws_allocs, h->h, (size_t)R * D);
+    ALLOC(h->ws_allocs, h->xn, (size_t)R * D);
+    ALLOC(h->ws_allocs, h->qkv, (size_t)(R + 64) * QKV);  // +64 rows: the last K tile's DMA rows are clamped, not skipped
+    ALLOC(h->ws_allocs, h->ao, (size_t)R * h->QD);
+    ALLOC(h->ws_allocs, h->act, (size_t)R * h->F);
+    ALLOC(h->ws_allocs, h->vt, (size_t)(R + 64 * Q) * h->KVD);
+    ALLOC(h->ws_allocs, h->vmean, (size_t)Q * h->KVD);
+    ALLOC(h->ws_allocs, h->kvlen_dev, (size_t)Q);
+    ALLOC(h->ws_allocs, h->lyric_out, (size_t)R * D);
+    ALLOC(h->ws_allocs, h->timbre_out, (size_t)R * D);
+    ALLOC(h->ws_allocs, h->text_out, (size_t)R * D);
+    (void)s_pad_total;
+    h->ws_rows = R;
+    h->ws_in = I;
+    h->ws_seqs = Q;
+    return 0;
+}
+
+// embed (Linear with bias) + n_layers x AceStepEncoderLayer + final RMSNorm over N sequences of S tokens.
+// in_bf: [N*S, in_dim] bf16; kv_len_dev: per-sequence valid key count or null; out: [N*S, D] bf16.
+int encoder_stack(ace355_cond* h, const EncoderW& E, const bf16_t* in_bf, int N, int S, const int* kv_len_dev, bf16_t* out, hipStream_t s) {
+    const int M = N * S, D = h->D, F = h->F, QD = h->QD, KVD = h->KVD, QKV = QD + 2 * KVD;
+    const int Sp = ((S + 63) / 64) * 64;
+    const float eps = h->cfg.rms_norm_eps;
+    const float scale = 1.0f / sqrtf((float)h->cfg.head_dim);
+    int rc = ensure_rope(h, S, s);
+    if (rc) return rc;
+    GemmEpilogue ep{1, E.b_embed, nullptr, nullptr, 0, 0};
+    rc = launch_gemm(in_bf, E.in_dim, E.w_embed, E.in_dim, h->h, D, M, D, E.in_dim, ep, s);  // base.py:623 / :1070
+    if (rc) return rc;
+    for (int li = 0; li < E.n_layers; ++li) {
+        const EncLayerW& W = E.layers[li];
+        const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
+        // self attention (base.py:414-427)
+        rc = launch_rmsnorm_mod(h->h, W.n_in, h->xn, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        rc = launch_gemm(h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
+        if (rc) return rc;
+        rc = launch_headnorm_rope2(h->qkv, M, QKV, 0, h->HQ + h->KVH, W.qn, W.kn, h->HQ, eps, h->rope_cos, h->rope_sin, S, s);
+        if (rc) return rc;
+        rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
+        if (rc) return rc;
+        if (kv_len_dev) {
+            rc = launch_vmean(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vmean, s);
+            if (rc) return rc;
+        }
+        AttnArgs a{};
+        a.q = h->qkv; a.q_seq_stride = (long)S * QKV; a.q_row_stride = QKV;
+        a.k = h->qkv + QD; a.k_seq_stride = (long)S * QKV; a.k_head_stride = 128; a.k_row_stride = QKV;
+        a.vt = h->vt; a.vt_seq_stride = (long)h->KVH * 128 * Sp; a.vt_head_stride = 128L * Sp; a.vt_ld = Sp;
+        a.use_tab = 0;
+        a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
+        a.N = N; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
+        a.window = sliding ? h->cfg.sliding_window : -1;
+        a.scale = scale;
+        a.kv_len = kv_len_dev;
+        a.vmean = kv_len_dev ? h->vmean : nullptr;
+        rc = launch_attention(a, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};  // h += o_proj(attn)
+        rc = launch_gemm(h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
+        if (rc) return rc;
+        // SwiGLU MLP (base.py:430-433)
+        rc = launch_rmsnorm_mod(h->h, W.n_post, h->xn, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{3, nullptr, nullptr, nullptr, 0, 0};
+        rc = launch_gemm(h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
+        if (rc) return rc;
+        ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};
+        rc = launch_gemm(h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
+        if (rc) return rc;
+    }
+    return launch_rmsnorm_mod(h->h, E.norm, out, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
+}
+
+int alloc_encoder(ace355_cond* h, EncoderW& E, int n_layers, int in_dim) {
+    const size_t D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+    E.n_layers = n_layers;
+    E.in_dim = in_dim;
+    ALLOC(h->allocs, E.w_embed, D * in_dim);
+    ALLOC(h->allocs, E.b_embed, D);
+    ALLOC(h->allocs, E.norm, D);
+    E.layers.resize(n_layers);
+    for (EncLayerW& L : E.layers) {
+        ALLOC(h->allocs, L.wqkv, (QD + 2 * KVD) * D);
+        ALLOC(h->allocs, L.wo, D * QD);
+        ALLOC(h->allocs, L.wgu, 2 * F * D);
+        ALLOC(h->allocs, L.wdown, D * F);
+        ALLOC(h->allocs, L.n_in, D);
+        ALLOC(h->allocs, L.n_post, D);
+        ALLOC(h->allocs, L.qn, 128);
+        ALLOC(h->allocs, L.kn, 128);
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ace355_cond_create(const ace355_cond_config* cfg, ace355_cond** out) {
+    ACE_CHECK(cfg && out, "cond_create: null argument");
+    ACE_CHECK(cfg->head_dim == 128, "cond_create: head_dim must be 128");
+    ACE_CHECK(cfg->hidden_size % 256 == 0 && cfg->intermediate_size % 64 == 0, "cond_create: hidden/intermediate size");
+    ACE_CHECK(cfg->text_hidden_dim % 64 == 0 && cfg->timbre_hidden_dim % 64 == 0, "cond_create: input dims must be multiples of 64");
+    ACE_CHECK(cfg->num_heads % cfg->num_kv_heads == 0, "cond_create: heads % kv_heads");
+    ACE_CHECK(cfg->num_lyric_layers >= 0 && cfg->num_lyric_layers <= 64 && cfg->num_timbre_layers >= 0 && cfg->num_timbre_layers <= 64,
+              "cond_create: layer counts");
+    ace355_cond* h = new ace355_cond();
+    h->cfg = *cfg;
+    h->D = cfg->hidden_size; h->F = cfg->intermediate_size; h->HQ = cfg->num_heads; h->KVH = cfg->num_kv_heads;
+    h->QD = cfg->num_heads * 128; h->KVD = cfg->num_kv_heads * 128;
+    int rc = dev_alloc(h->allocs, &h->w_text, (size_t)h->D * cfg->text_hidden_dim);
+    if (!rc) rc = alloc_encoder(h, h->lyric, cfg->num_lyric_layers, cfg->text_hidden_dim);
+    if (!rc) rc = alloc_encoder(h, h->timbre, cfg->num_timbre_layers, cfg->timbre_hidden_dim);
+    if (rc) { ace355_cond_destroy(h); return rc; }
+    h->expected_tensors = 1 + (3 + (size_t)cfg->num_lyric_layers * 11) + (3 + (size_t)cfg->num_timbre_layers * 11);
+    *out = h;
+    return ACE355_OK;
+}
+
+void ace355_cond_destroy(ace355_cond* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    for (void* p : h->ws_allocs) hipFree(p);
+    if (h->stage) hipFree(h->stage);
+    if (h->rowsrc_dev) hipFree(h->rowsrc_dev);
+    delete h;
+}
+
+int ace355_cond_load_tensor(ace355_cond* h, const char* name, const void* data, int dtype, int64_t numel, int is_device) {
+    ACE_CHECK(h && name && data, "cond_load_tensor: null argument");
+    ACE_CHECK(dtype == ACE355_DTYPE_F32 || dtype == ACE355_DTYPE_BF16, "cond_load_tensor: dtype");
+    Dest d;
+    if (!resolve(h, name, &d)) {
+        set_error(std::string("cond_load_tensor: unknown tensor name '") + name + "'");
+        return ACE355_ERR_INVALID;
+    }
+    if (numel != d.rows * d.cols) {
+        set_error(std::string("cond_load_tensor: wrong element count for '") + name + "': got " + std::to_string(numel) +
+                  ", expected " + std::to_string(d.rows * d.cols));
+        return ACE355_ERR_INVALID;
+    }
+    if (d.ignore) return ACE355_OK;
+    const size_t esz = dtype == ACE355_DTYPE_F32 ? 4 : 2;
+    const void* src = data;
+    if (!is_device) {
+        const size_t bytes = (size_t)numel * esz;
+        if (bytes > h->stage_bytes) {
+            if (h->stage) ACE_HIP(hipFree(h->stage));
+            h->stage = nullptr;
+            ACE_HIP(hipMalloc(&h->stage, bytes));
+            h->stage_bytes = bytes;
+        }
+        ACE_HIP(hipMemcpy(h->stage, data, bytes, hipMemcpyHostToDevice));
+        src = h->stage;
+    }
+    int rc = launch_pack(src, dtype, d.dst, d.is_bf16, d.mode, d.rows, d.cols, d.dst_ld, d.dst_row0, d.p0, 0, nullptr);
+    if (rc) return rc;
+    ACE_HIP(hipDeviceSynchronize());
+    h->loaded.insert(name);
+    h->finalized = false;
+    return ACE355_OK;
+}
+
+int ace355_cond_finalize(ace355_cond* h) {
+    ACE_CHECK(h, "cond_finalize: null handle");
+    if (h->loaded.size() != h->expected_tensors) {
+        set_error("cond_finalize: " + std::to_string(h->loaded.size()) + " of " + std::to_string(h->expected_tensors) + " tensors loaded");
+        return ACE355_ERR_STATE;
+    }
+    if (h->stage) { hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+    h->finalized = true;
+    return ACE355_OK;
+}
+
+int ace355_cond_out_len(int Ll, int Lt, const int32_t* refer_item, int Nref, int B) {
+    if (Ll < 0 || Lt < 0 || Nref < 0 || B <= 0 || (Nref > 0 && !refer_item)) return -1;
+    std::vector<int> cnt(B, 0);
+    int mx = 0;
+    for (int i = 0; i < Nref; ++i) {
+        if (refer_item[i] < 0 || refer_item[i] >= B) return -1;
+        mx = std::max(mx, ++cnt[refer_item[i]]);
+    }
+    return Ll + mx + Lt;
+}
+
+int ace355_cond_encode(ace355_cond* h, const float* text_dev, const int32_t* text_len, int Lt, const float* lyric_dev,
+                       const int32_t* lyric_len, int Ll, const float* refer_dev, const int32_t* refer_item, int Nref, int Tref, int B,
+                       float* enc_out_dev, int32_t* enc_len_out, void* stream) {
+    ACE_CHECK(h && text_dev && text_len && lyric_dev && lyric_len && refer_dev && refer_item && enc_out_dev && enc_len_out,
+              "cond_encode: null argument");
+    if (!h->finalized) { set_error("cond_encode: call ace355_cond_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && B <= 64 && Lt > 0 && Ll > 0 && Nref > 0 && Nref <= 256 && Tref > 0, "cond_encode: sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->D, TD = h->cfg.text_hidden_dim, AD = h->cfg.timbre_hidden_dim;
+    for (int b = 0; b < B; ++b) {
+        ACE_CHECK(text_len[b] >= 0 && text_len[b] <= Lt && lyric_len[b] >= 0 && lyric_len[b] <= Ll, "cond_encode: lengths out of range");
+    }
+    std::vector<int> cnt(B, 0), slot(Nref, 0);
+    int max_cnt = 0;
+    for (int i = 0; i < Nref; ++i) {
+        ACE_CHECK(refer_item[i] >= 0 && refer_item[i] < B, "cond_encode: refer_item out of range");
+        slot[i] = cnt[refer_item[i]]++;  // order of appearance inside its batch item (unpack_timbre_embeddings, base.py:1019-1061)
+        max_cnt = std::max(max_cnt, cnt[refer_item[i]]);
+    }
+    const int Lout = Ll + max_cnt + Lt;
+    const long rows = std::max<long>({(long)B * Ll, (long)Nref * Tref, (long)B * Lt});
+    const long in_elems = std::max<long>({(long)B * Ll * TD, (long)Nref * Tref * AD, (long)B * Lt * TD});
+    int rc = ensure_workspace(h, rows, in_elems, std::max(B, Nref), 0, s);
+    if (rc) return rc;
+
+    // text: Linear(text_dim -> D, no bias) (base.py:1541)
+    rc = launch_f32_to_bf16(text_dev, h->in_bf, (long)B * Lt * TD, s);
+    if (rc) return rc;
+    GemmEpilogue ep{0, nullptr, nullptr, nullptr, 0, 0};
+    rc = launch_gemm(h->in_bf, TD, h->w_text, TD, h->text_out, D, B * Lt, D, TD, ep, s);
+    if (rc) return rc;
+
+    // lyric encoder with its key-padding mask (base.py:1543-1547)
+    rc = launch_f32_to_bf16(lyric_dev, h->in_bf, (long)B * Ll * TD, s);
+    if (rc) return rc;
+    ACE_HIP(hipMemcpyAsync(h->kvlen_dev, lyric_len, sizeof(int) * B, hipMemcpyHostToDevice, s));
+    ACE_HIP(hipStreamSynchronize(s));  // lyric_len is caller memory
+    rc = encoder_stack(h, h->lyric, h->in_bf, B, Ll, h->kvlen_dev, h->lyric_out, s);
+    if (rc) return rc;
+
+    // timbre encoder: no padding mask, token 0 of every reference clip (base.py:1549, :1175)
+    rc = launch_f32_to_bf16(refer_dev, h->in_bf, (long)Nref * Tref * AD, s);
+    if (rc) return rc;
+    rc = encoder_stack(h, h->timbre, h->in_bf, Nref, Tref, nullptr, h->timbre_out, s);
+    if (rc) return rc;
+
+    // pack_sequences twice (base.py:1553-1554) with prefix masks = a segmented row gather per batch item:
+    //   [lyric valid | timbre valid | text valid | lyric padding | timbre zero rows | text padding]
+    // The three sources live in one virtual row space: lyric rows [0, B*Ll), timbre rows (token 0 of clip i) B*Ll + i,
+    // text rows B*Ll + Nref + r; they are gathered from three buffers, so build three index tables and gather three times.
+    const long total = (long)B * Lout;
+    if (total * 3 > h->rowsrc_cap) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->rowsrc_dev) hipFree(h->rowsrc_dev);
+        ACE_HIP(hipMalloc((void**)&h->rowsrc_dev, sizeof(int) * total * 3 + 256));
+        h->rowsrc_cap = total * 3;
+    }
+    std::vector<int> src_l(total, -2), src_t(total, -2), src_x(total, -2);  // -2: row not owned by this source
+    std::vector<std::vector<int>> clips(B);
+    for (int i = 0; i < Nref; ++i) clips[refer_item[i]].push_back(i);
+    for (int b = 0; b < B; ++b) {
+        long o = (long)b * Lout;
+        const int ll = lyric_len[b], tl = text_len[b], c = cnt[b];
+        for (int j = 0; j < ll; ++j) src_l[o++] = b * Ll + j;
+        for (int j = 0; j < c; ++j) src_t[o++] = clips[b][j] * Tref;  // token 0 of the clip
+        for (int j = 0; j < tl; ++j) src_x[o++] = b * Lt + j;
+        for (int j = ll; j < Ll; ++j) src_l[o++] = b * Ll + j;
+        for (int j = c; j < max_cnt; ++j) src_t[o++] = -1;              // zero rows of the one-hot unpack
+        for (int j = tl; j < Lt; ++j) src_x[o++] = b * Lt + j;
+        enc_len_out[b] = ll + c + tl;
+    }
+    // compact each table to (dst row, src row) pairs handled by one gather over the owned rows only
+    std::vector<int> table(total * 3);
+    const std::vector<int>* tabs[3] = {&src_l, &src_t, &src_x};
+    const bf16_t* bufs[3] = {h->lyric_out, h->timbre_out, h->text_out};
+    (void)slot;
+    for (int t = 0; t < 3; ++t) memcpy(table.data() + total * t, tabs[t]->data(), sizeof(int) * total);
+    ACE_HIP(hipMemcpyAsync(h->rowsrc_dev, table.data(), sizeof(int) * total * 3, hipMemcpyHostToDevice, s));
+    for (int t = 0; t < 3; ++t) {
+        rc = launch_gather_rows_bf16_f32(bufs[t], D, h->rowsrc_dev + total * t, enc_out_dev, D, total, D, s);
+        if (rc) return rc;
+    }
+    ACE_HIP(hipStreamSynchronize(s));  // `table` is host memory
+    return ACE355_OK;
+}
+
+}  // extern "C"

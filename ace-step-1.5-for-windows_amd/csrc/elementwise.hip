@@ -444,6 +444,32 @@ __global__ void pack_kernel(const SRC* __restrict__ src, void* __restrict__ dst,
     else reinterpret_cast<float*>(dst)[di] = v;
 }
 
+// mean over the sequence of every V head channel (fully-masked attention rows of the condition encoders, see AttnArgs::vmean)
+__global__ void vmean_kernel(const bf16_t* __restrict__ x, int ld, int col0, int S, bf16_t* __restrict__ out, int heads) {
+    const int h = blockIdx.x, n = blockIdx.y, d = threadIdx.x;
+    const bf16_t* p = x + (long)n * S * ld + col0 + h * 128 + d;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += bf2f(p[(long)s * ld]);
+    out[((long)n * heads + h) * 128 + d] = f2bf(acc / (float)S);
+}
+
+__global__ void gather_rows_bf16_f32_kernel(const bf16_t* __restrict__ src, long src_ld, const int* __restrict__ row_src,
+                                            float* __restrict__ dst, long dst_ld, long rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = cols / 4;
+    if (i >= rows * c4) return;
+    const long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const int sr = row_src[r];
+    if (sr < -1) return;  // row owned by another source buffer
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sr >= 0) {
+        const uint2 u = *reinterpret_cast<const uint2*>(src + (long)sr * src_ld + c);
+        v = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+    }
+    *reinterpret_cast<float4*>(dst + r * dst_ld + c) = v;
+}
+
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
@@ -456,6 +482,21 @@ int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, 
     if (D == 2048) hipLaunchKernelGGL(rmsnorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     else if (D == 256) hipLaunchKernelGGL(rmsnorm_mod_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     else hipLaunchKernelGGL(rmsnorm_mod_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_vmean(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vmean, hipStream_t s) {
+    hipLaunchKernelGGL(vmean_kernel, dim3(heads, N), dim3(128), 0, s, x, ld, col0, S, vmean, heads);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gather_rows_bf16_f32(const bf16_t* src, long src_ld, const int* row_src, float* dst, long dst_ld, long rows, int cols,
+                                hipStream_t s) {
+    ACE_CHECK(cols % 4 == 0, "gather_rows: cols must be a multiple of 4");
+    const long n = rows * (cols / 4);
+    hipLaunchKernelGGL(gather_rows_bf16_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, src_ld, row_src, dst, dst_ld, rows, cols);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -38,6 +38,15 @@ class SampleParamsC(C.Structure):
     ]
 
 
+class CondConfigC(C.Structure):
+    _fields_ = [
+        ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("text_hidden_dim", C.c_int32), ("timbre_hidden_dim", C.c_int32),
+        ("num_lyric_layers", C.c_int32), ("num_timbre_layers", C.c_int32), ("sliding_window", C.c_int32),
+        ("sliding_layer_mask", C.c_uint64), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
+    ]
+
+
 class VaeConfigC(C.Structure):
     _fields_ = [
         ("decoder_channels", C.c_int32), ("decoder_input_channels", C.c_int32), ("audio_channels", C.c_int32),
@@ -70,6 +79,14 @@ SIGNATURES = {
     "ace355_vae_hop": (C.c_int, [C.c_void_p]),
     "ace355_vae_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_vae_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ace355_cond_create": (C.c_int, [C.POINTER(CondConfigC), C.POINTER(C.c_void_p)]),
+    "ace355_cond_destroy": (None, [C.c_void_p]),
+    "ace355_cond_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),
+    "ace355_cond_finalize": (C.c_int, [C.c_void_p]),
+    "ace355_cond_out_len": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int]),
+    "ace355_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int,
+                                     C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32),
+                                     C.c_void_p]),
     "ace355_peak_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "ace355_latent_check": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_void_p]),
     "ace355_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -81,6 +98,8 @@ SIGNATURES = {
                                        C.c_float, C.c_void_p]),
     "ace355_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_float, C.c_void_p]),
+    "ace355_attention_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_float, C.POINTER(C.c_int32), C.c_void_p]),
     "ace355_apg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                         C.c_int, C.c_void_p]),
     "ace355_conv1d_nlc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

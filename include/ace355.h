@@ -159,6 +159,49 @@ int ace355_vae_hop(const ace355_vae* h);
 int ace355_vae_set_profile(ace355_vae* h, int enable);
 int ace355_vae_get_profile(ace355_vae* h, double* conv_ms, double* conv_flops, int64_t* conv_launches);
 
+/* ------------------------------------------------------------------------------------------
+ * Condition encoder: AceStepConditionEncoder.forward, base.py:1509-1554
+ * = text_projector + AceStepLyricEncoder (base.py:577-731) + AceStepTimbreEncoder (base.py:997-1178)
+ * + pack_sequences x2 (base.py:138-169).  Replaces the call `self.encoder(...)` of prepare_condition
+ * (base.py:1626-1633); its output is what ace355_dit_set_condition takes.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ace355_cond ace355_cond;
+
+typedef struct ace355_cond_config {
+    int32_t hidden_size;        /* 2048 */
+    int32_t intermediate_size;  /* 6144 */
+    int32_t num_heads;          /* 16 */
+    int32_t num_kv_heads;       /* 8 */
+    int32_t head_dim;           /* 128 (only value supported) */
+    int32_t text_hidden_dim;    /* 1024: text and lyric embedding width */
+    int32_t timbre_hidden_dim;  /* 64: reference-audio latent width */
+    int32_t num_lyric_layers;   /* 8 */
+    int32_t num_timbre_layers;  /* 4 */
+    int32_t sliding_window;     /* 128 */
+    uint64_t sliding_layer_mask; /* bit i set: encoder layer i is "sliding_attention" (config.layer_types[i]) */
+    float rms_norm_eps;         /* 1e-6 */
+    float rope_theta;           /* 1e6 */
+} ace355_cond_config;
+
+int ace355_cond_create(const ace355_cond_config* cfg, ace355_cond** out);
+void ace355_cond_destroy(ace355_cond* h);
+/* name = a key of AceStepConditionEncoder.state_dict() (`model.encoder` of the reference checkpoint), e.g.
+ * "lyric_encoder.layers.3.self_attn.q_proj.weight"; "timbre_encoder.special_token" is accepted and ignored
+ * (the reference's forward never reads it).  Same contract as ace355_dit_load_tensor. */
+int ace355_cond_load_tensor(ace355_cond* h, const char* name, const void* data, int dtype, int64_t numel, int is_device);
+int ace355_cond_finalize(ace355_cond* h);
+/* Rows per item of the packed output: Ll + (max number of reference clips of one item) + Lt; < 0 on bad arguments. */
+int ace355_cond_out_len(int Ll, int Lt, const int32_t* refer_item_host, int Nref, int B);
+/* One encoder forward.  text dev f32 [B,Lt,text_dim], lyric dev f32 [B,Ll,text_dim], refer dev f32
+ * [Nref,Tref,timbre_dim] (refer_audio_acoustic_hidden_states_packed); text_len / lyric_len host int32 [B]: the
+ * attention masks in prefix form (mask[b][j] = j < len[b]; anything else must take the PyTorch path);
+ * refer_item host int32 [Nref] = refer_audio_order_mask.  Writes enc_out dev f32 [B, out_len, hidden]
+ * (encoder_hidden_states, valid tokens first exactly as pack_sequences orders them, padding rows included because the
+ * DiT attends them: base.py:1384-1385) and enc_len_out host int32 [B] (encoder_attention_mask in prefix form). */
+int ace355_cond_encode(ace355_cond* h, const float* text_dev, const int32_t* text_len_host, int Lt, const float* lyric_dev,
+                       const int32_t* lyric_len_host, int Ll, const float* refer_dev, const int32_t* refer_item_host,
+                       int Nref, int Tref, int B, float* enc_out_dev, int32_t* enc_len_out_host, void* stream);
+
 /* Post-decode peak clip, H/generate_music_decode.py:191-195: per item, if any peak > 1 divide
  * every item by clamp(peak, min=1).  wav dev f32 [B, per_item]. */
 int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream);
@@ -186,6 +229,11 @@ int ace355_headnorm_rope(void* x_bf16_dev, int M, int ld, int col0, int heads, c
  * window < 0 = full, else |i-j| <= window.  out bf16 [N,Sq,Hq*128]. */
 int ace355_attention(const void* q_dev, const void* k_dev, const void* v_dev, void* out_dev, int N, int Sq, int Skv,
                      int Hq, int Hkv, int window, float scale, void* stream);
+/* Same with the key-padding mask of the condition encoders (create_4d_mask, base.py:117-124, prefix form): keys
+ * j >= kv_len_host[n] are masked; a query with no valid key attends uniformly to ALL keys, as the reference's
+ * finfo.min additive mask does. */
+int ace355_attention_masked(const void* q_dev, const void* k_dev, const void* v_dev, void* out_dev, int N, int Sq, int Skv,
+                            int Hq, int Hkv, int window, float scale, const int32_t* kv_len_host, void* stream);
 /* One guidance + Euler step (base.py:1946-1979): v dev f32 [2B,T,64] (cond | uncond), avg dev f32 [B,T,64]
  * momentum state (updated), xt dev f32 [B,T,64] (updated in place). first != 0: momentum buffer is empty. */
 int ace355_apg_euler_step(const float* v_dev, float* avg_dev, float* xt_dev, int B, int T, float guidance, float dt,

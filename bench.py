@@ -209,12 +209,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the native HIP path has no CPU fallback")
-    device = torch.device(f"cuda:{local_rank}")
+    # ACE355_BENCH_BACKEND=gloo: functional check of the multi-rank flow on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin; RCCL refuses two ranks on one GPU).  The driver's runs use the default: one GPU per rank over RCCL.
+    backend = os.environ.get("ACE355_BENCH_BACKEND", "nccl")
+    device = torch.device(f"cuda:{local_rank % torch.cuda.device_count() if backend != 'nccl' else local_rank}")
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import ace355  # noqa: F401
     from ace355 import dist as a_dist
@@ -241,9 +247,18 @@ def main():
     seeds = [1000 + rank * B + i for i in range(B)]
     noise = prepare_noise((B, T, 64), seeds).to(device)  # CPU generator (reference CPU stream), uploaded once
 
-    def one_pass():
-        bundle = a_dist.broadcast_conditioning({"enc": enc, "null": null, "ctx": ctx_shared}, src=0) if world > 1 else \
-            {"enc": enc, "null": null, "ctx": ctx_shared}
+    last_bundle = {}
+
+    def one_pass(collective=True):
+        # collective=False (the rank-0-only profiled pass after the timed region) must not enter a broadcast the other
+        # ranks never join: it reuses the bundle of the last timed pass
+        if world > 1 and collective:
+            bundle = a_dist.broadcast_conditioning({"enc": enc, "null": null, "ctx": ctx_shared}, src=0)
+            last_bundle.update(bundle)
+        elif world > 1:
+            bundle = last_bundle
+        else:
+            bundle = {"enc": enc, "null": null, "ctx": ctx_shared}
         ctx = bundle["ctx"][None].expand(B, -1, -1).contiguous()
         dit.set_condition(SLOT_COND, bundle["enc"])
         dit.set_condition(SLOT_NULL, bundle["null"].reshape(1, -1), L=L)
@@ -293,7 +308,7 @@ def main():
         dit.set_profile(True)
         if vae is not None:
             vae.set_profile(True)
-        one_pass()
+        one_pass(collective=False)
         torch.cuda.synchronize()
         p = dit.get_profile()
         dit.set_profile(False)
@@ -314,7 +329,7 @@ def main():
         result["algorithmic_tflop_per_step"] = alg / 1e12
         result["achieved_tflops_whole_path"] = alg / 1e12 / (elapsed / args.steps)
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(args, dcfg, vcfg, sd, vsd, enc.cpu(), null.cpu(), ctx_shared.cpu()[None], T, L)
 
     if rank == 0:

@@ -6,10 +6,11 @@ Layout:
   dit.py       NativeDit: weight packing, condition slots, forward, sampler
   vae.py       NativeVae: weight-norm fusion, decode
   cond.py      NativeCondEncoder: lyric / timbre encoders + sequence packing
+  lmhints.py   audio-code parsing, FSQ index decode, NativeDetokenizer
   backend.py   NativeDitMixin / NativeVaeMixin / NativeHandler: the reference's handler seam
   dist.py      one-process-per-GPU data-parallel runner (RCCL broadcast of conditioning)
   weightgen.py deterministic synthetic weights (no checkpoints exist on the boxes)
 """
-from .config import CondConfig, DitConfig, VaeConfig  # noqa: F401
+from .config import CondConfig, DetokConfig, DitConfig, VaeConfig  # noqa: F401
 
-__all__ = ["CondConfig", "DitConfig", "VaeConfig"]
+__all__ = ["CondConfig", "DetokConfig", "DitConfig", "VaeConfig"]

@@ -147,6 +147,63 @@ class CondConfig:
 
 
 @dataclass
+class DetokConfig:
+    """Fields of ``AceStepConfig`` used by ``AudioTokenDetokenizer`` (modeling_acestep_v15_base.py:862-994)."""
+
+    hidden_size: int = 2048
+    intermediate_size: int = 6144
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    sliding_window: int = 128
+    pool_window_size: int = 5
+    num_attention_pooler_hidden_layers: int = 2
+    audio_acoustic_hidden_dim: int = 64
+    layer_types: Optional[List[str]] = None
+
+    def __post_init__(self):
+        if self.layer_types is None:
+            self.layer_types = ["sliding_attention" if (i + 1) % 2 else "full_attention"
+                                for i in range(self.num_attention_pooler_hidden_layers)]
+
+    @classmethod
+    def from_reference(cls, cfg) -> "DetokConfig":
+        return cls(
+            hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_attention_heads=cfg.num_attention_heads,
+            num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, rms_norm_eps=cfg.rms_norm_eps,
+            rope_theta=float(getattr(cfg, "rope_theta", 1e6)), sliding_window=cfg.sliding_window or 0,
+            pool_window_size=cfg.pool_window_size, num_attention_pooler_hidden_layers=cfg.num_attention_pooler_hidden_layers,
+            audio_acoustic_hidden_dim=cfg.audio_acoustic_hidden_dim,
+            layer_types=list(cfg.layer_types)[: cfg.num_attention_pooler_hidden_layers],
+        )
+
+    def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """Names/shapes of ``AudioTokenDetokenizer.state_dict()``."""
+        D, Fh, hd = self.hidden_size, self.intermediate_size, self.head_dim
+        q, kv = self.num_attention_heads * hd, self.num_key_value_heads * hd
+        s: Dict[str, Tuple[int, ...]] = {
+            "embed_tokens.weight": (D, D), "embed_tokens.bias": (D,), "norm.weight": (D,),
+            "special_tokens": (1, self.pool_window_size, D), "proj_out.weight": (self.audio_acoustic_hidden_dim, D),
+            "proj_out.bias": (self.audio_acoustic_hidden_dim,)}
+        for li in range(self.num_attention_pooler_hidden_layers):
+            r = f"layers.{li}."
+            s[r + "self_attn.q_proj.weight"] = (q, D)
+            s[r + "self_attn.k_proj.weight"] = (kv, D)
+            s[r + "self_attn.v_proj.weight"] = (kv, D)
+            s[r + "self_attn.o_proj.weight"] = (D, q)
+            s[r + "self_attn.q_norm.weight"] = (hd,)
+            s[r + "self_attn.k_norm.weight"] = (hd,)
+            s[r + "input_layernorm.weight"] = (D,)
+            s[r + "post_attention_layernorm.weight"] = (D,)
+            s[r + "mlp.gate_proj.weight"] = (Fh, D)
+            s[r + "mlp.up_proj.weight"] = (Fh, D)
+            s[r + "mlp.down_proj.weight"] = (D, Fh)
+        return s
+
+
+@dataclass
 class VaeConfig:
     """Decoder half of AutoencoderOobleck.  Strides are run-time data (checkpoints/vae/config.json);
     the synthetic default has hop 1920 (handler/conditioning_target.py:47,53)."""

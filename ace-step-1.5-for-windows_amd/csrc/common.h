@@ -133,6 +133,8 @@ int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStr
 int launch_vmean(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vmean, hipStream_t s);
 // dst[r][c] (f32, row stride dst_ld) = src[r][c] (bf16, row stride src_ld) for `rows` rows taken through a per-row source index
 // table (row_src[r] == -1: zero row, < -1: leave dst row r untouched)
+// out[(r*P + p)][c] = emb[r][c] + special[p][c]   (f32)
+int launch_expand_add(const float* emb, const float* special, float* out, long rows, int P, int D, hipStream_t s);
 int launch_gather_rows_bf16_f32(const bf16_t* src, long src_ld, const int* row_src, float* dst, long dst_ld, long rows, int cols, hipStream_t s);
 
 struct TVals { float t[64]; };

@@ -1,4 +1,5 @@
-// cond.hip - the condition-encoder handle behind ace355.h: weight ingestion/packing and
+// cond.hip - the encoder-stack handles behind ace355.h: the condition encoder and the audio-token
+// detokenizer of the LM-hint path (row N2, AudioTokenDetokenizer, base.py:862-994, at the end of this file).  N1: weight ingestion/packing and
 // AceStepConditionEncoder.forward (base.py:1509-1554) = text projector + AceStepLyricEncoder (base.py:577-731) +
 // AceStepTimbreEncoder (base.py:997-1178) + two pack_sequences (base.py:138-169).  Host-side orchestration only: every
 // contraction / norm / attention runs on the DiT's kernels (gemm.hip, attn.hip, elementwise.hip).
@@ -36,11 +37,11 @@ struct EncoderW {
 
 }  // namespace
 
-struct ace355_cond {
-    ace355_cond_config cfg;
-    int D, F, QD, KVD, HQ, KVH;
-    EncoderW lyric, timbre;
-    bf16_t* w_text = nullptr;
+// state shared by every encoder-stack handle: dimensions, weight bag, workspace
+struct EncBase {
+    int D = 0, F = 0, QD = 0, KVD = 0, HQ = 0, KVH = 0, sliding_window = 0;
+    unsigned long long sliding_layer_mask = 0;
+    float eps = 1e-6f, theta = 1e6f;
     std::set<std::string> loaded;
     size_t expected_tensors = 0;
     bool finalized = false;
@@ -49,16 +50,30 @@ struct ace355_cond {
     size_t stage_bytes = 0;
 
     // workspace (sized for the largest M = rows of one encoder call seen so far)
-    long ws_rows = 0, ws_in = 0;
+    long ws_rows = 0, ws_in = 0, ws_vt = 0;
     int ws_seqs = 0;
     std::vector<void*> ws_allocs;
     bf16_t *in_bf = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr, *vmean = nullptr;
     bf16_t *lyric_out = nullptr, *timbre_out = nullptr, *text_out = nullptr;
-    float* h = nullptr;
+    float *h = nullptr, *emb = nullptr;
     int *kvlen_dev = nullptr, *rowsrc_dev = nullptr;
     long rowsrc_cap = 0;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_S = 0;
+};
+
+struct ace355_cond : EncBase {
+    ace355_cond_config cfg;
+    EncoderW lyric, timbre;
+    bf16_t* w_text = nullptr;
+};
+
+struct ace355_detok : EncBase {
+    ace355_detok_config cfg;
+    EncoderW enc;            // embed_tokens / layers / norm
+    float* special = nullptr;  // [pool][D]
+    bf16_t* w_out = nullptr;   // [out_dim][D]
+    float* b_out = nullptr;
 };
 
 namespace {
@@ -128,24 +143,25 @@ bool resolve(ace355_cond* h, const std::string& name, Dest* d) {
     return false;
 }
 
-int ensure_rope(ace355_cond* h, int S, hipStream_t s) {
+int ensure_rope(EncBase* h, int S, hipStream_t s) {
     if (S <= h->rope_S) return 0;
     int cap = 512;
     while (cap < S) cap *= 2;
     ALLOC(h->allocs, h->rope_cos, (size_t)cap * 64);
     ALLOC(h->allocs, h->rope_sin, (size_t)cap * 64);
-    int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->cfg.rope_theta, s);
+    int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->theta, s);
     if (rc) return rc;
     h->rope_S = cap;
     return 0;
 }
 
-int ensure_workspace(ace355_cond* h, long rows, long in_elems, int seqs, long s_pad_total, hipStream_t s) {
-    if (rows <= h->ws_rows && in_elems <= h->ws_in && seqs <= h->ws_seqs) return 0;
+// vt_elems: V^T buffer = seqs x KVD x (S rounded up to 64)
+int ensure_workspace(EncBase* h, long rows, long in_elems, int seqs, long vt_elems, hipStream_t s) {
+    if (rows <= h->ws_rows && in_elems <= h->ws_in && seqs <= h->ws_seqs && vt_elems <= h->ws_vt) return 0;
     ACE_HIP(hipStreamSynchronize(s));
     for (void* p : h->ws_allocs) hipFree(p);
     h->ws_allocs.clear();
-    const long R = std::max(rows, h->ws_rows), I = std::max(in_elems, h->ws_in);
+    const long R = std::max(rows, h->ws_rows), I = std::max(in_elems, h->ws_in), V = std::max(vt_elems, h->ws_vt);
     const int Q = std::max(seqs, h->ws_seqs);
     const long D = h->D, QKV = h->QD + 2 * h->KVD;
     ALLOC(h->ws_allocs, h->in_bf, (size_t)I);
@@ -154,34 +170,33 @@ int ensure_workspace(ace355_cond* h, long rows, long in_elems, int seqs, long s_
     ALLOC(h->ws_allocs, h->qkv, (size_t)(R + 64) * QKV);  // +64 rows: the last K tile's DMA rows are clamped, not skipped
     ALLOC(h->ws_allocs, h->ao, (size_t)R * h->QD);
     ALLOC(h->ws_allocs, h->act, (size_t)R * h->F);
-    ALLOC(h->ws_allocs, h->vt, (size_t)(R + 64 * Q) * h->KVD);
+    ALLOC(h->ws_allocs, h->vt, (size_t)V);
+    ALLOC(h->ws_allocs, h->emb, (size_t)R * D);
     ALLOC(h->ws_allocs, h->vmean, (size_t)Q * h->KVD);
     ALLOC(h->ws_allocs, h->kvlen_dev, (size_t)Q);
     ALLOC(h->ws_allocs, h->lyric_out, (size_t)R * D);
     ALLOC(h->ws_allocs, h->timbre_out, (size_t)R * D);
     ALLOC(h->ws_allocs, h->text_out, (size_t)R * D);
-    (void)s_pad_total;
     h->ws_rows = R;
     h->ws_in = I;
     h->ws_seqs = Q;
+    h->ws_vt = V;
     return 0;
 }
 
-// embed (Linear with bias) + n_layers x AceStepEncoderLayer + final RMSNorm over N sequences of S tokens.
-// in_bf: [N*S, in_dim] bf16; kv_len_dev: per-sequence valid key count or null; out: [N*S, D] bf16.
-int encoder_stack(ace355_cond* h, const EncoderW& E, const bf16_t* in_bf, int N, int S, const int* kv_len_dev, bf16_t* out, hipStream_t s) {
+// n_layers x AceStepEncoderLayer + final RMSNorm over N sequences of S tokens, on the fp32 stream h->h ([N*S, D], already
+// embedded).  kv_len_dev: per-sequence valid key count or null; out: [N*S, D] bf16.
+int encoder_layers(EncBase* h, const EncoderW& E, int N, int S, const int* kv_len_dev, bf16_t* out, hipStream_t s) {
     const int M = N * S, D = h->D, F = h->F, QD = h->QD, KVD = h->KVD, QKV = QD + 2 * KVD;
     const int Sp = ((S + 63) / 64) * 64;
-    const float eps = h->cfg.rms_norm_eps;
-    const float scale = 1.0f / sqrtf((float)h->cfg.head_dim);
+    const float eps = h->eps;
+    const float scale = 1.0f / sqrtf(128.0f);
     int rc = ensure_rope(h, S, s);
     if (rc) return rc;
-    GemmEpilogue ep{1, E.b_embed, nullptr, nullptr, 0, 0};
-    rc = launch_gemm(in_bf, E.in_dim, E.w_embed, E.in_dim, h->h, D, M, D, E.in_dim, ep, s);  // base.py:623 / :1070
-    if (rc) return rc;
+    GemmEpilogue ep{};
     for (int li = 0; li < E.n_layers; ++li) {
         const EncLayerW& W = E.layers[li];
-        const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
+        const bool sliding = (h->sliding_layer_mask >> li) & 1ull;
         // self attention (base.py:414-427)
         rc = launch_rmsnorm_mod(h->h, W.n_in, h->xn, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
         if (rc) return rc;
@@ -203,7 +218,7 @@ int encoder_stack(ace355_cond* h, const EncoderW& E, const bf16_t* in_bf, int N,
         a.use_tab = 0;
         a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
         a.N = N; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
-        a.window = sliding ? h->cfg.sliding_window : -1;
+        a.window = sliding ? h->sliding_window : -1;
         a.scale = scale;
         a.kv_len = kv_len_dev;
         a.vmean = kv_len_dev ? h->vmean : nullptr;
@@ -225,7 +240,15 @@ int encoder_stack(ace355_cond* h, const EncoderW& E, const bf16_t* in_bf, int N,
     return launch_rmsnorm_mod(h->h, E.norm, out, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
 }
 
-int alloc_encoder(ace355_cond* h, EncoderW& E, int n_layers, int in_dim) {
+// embed (Linear with bias, base.py:623 / :1070) then the layers.  in_bf: [N*S, in_dim] bf16.
+int encoder_stack(EncBase* h, const EncoderW& E, const bf16_t* in_bf, int N, int S, const int* kv_len_dev, bf16_t* out, hipStream_t s) {
+    GemmEpilogue ep{1, E.b_embed, nullptr, nullptr, 0, 0};
+    int rc = launch_gemm(in_bf, E.in_dim, E.w_embed, E.in_dim, h->h, h->D, N * S, h->D, E.in_dim, ep, s);
+    if (rc) return rc;
+    return encoder_layers(h, E, N, S, kv_len_dev, out, s);
+}
+
+int alloc_encoder(EncBase* h, EncoderW& E, int n_layers, int in_dim) {
     const size_t D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
     E.n_layers = n_layers;
     E.in_dim = in_dim;
@@ -262,6 +285,8 @@ int ace355_cond_create(const ace355_cond_config* cfg, ace355_cond** out) {
     h->cfg = *cfg;
     h->D = cfg->hidden_size; h->F = cfg->intermediate_size; h->HQ = cfg->num_heads; h->KVH = cfg->num_kv_heads;
     h->QD = cfg->num_heads * 128; h->KVD = cfg->num_kv_heads * 128;
+    h->sliding_window = cfg->sliding_window; h->sliding_layer_mask = cfg->sliding_layer_mask;
+    h->eps = cfg->rms_norm_eps; h->theta = cfg->rope_theta;
     int rc = dev_alloc(h->allocs, &h->w_text, (size_t)h->D * cfg->text_hidden_dim);
     if (!rc) rc = alloc_encoder(h, h->lyric, cfg->num_lyric_layers, cfg->text_hidden_dim);
     if (!rc) rc = alloc_encoder(h, h->timbre, cfg->num_timbre_layers, cfg->timbre_hidden_dim);
@@ -360,7 +385,8 @@ int ace355_cond_encode(ace355_cond* h, const float* text_dev, const int32_t* tex
     const int Lout = Ll + max_cnt + Lt;
     const long rows = std::max<long>({(long)B * Ll, (long)Nref * Tref, (long)B * Lt});
     const long in_elems = std::max<long>({(long)B * Ll * TD, (long)Nref * Tref * AD, (long)B * Lt * TD});
-    int rc = ensure_workspace(h, rows, in_elems, std::max(B, Nref), 0, s);
+    const long vt_elems = std::max<long>((long)B * (((Ll + 63) / 64) * 64), (long)Nref * (((Tref + 63) / 64) * 64)) * h->KVD;
+    int rc = ensure_workspace(h, rows, in_elems, std::max(B, Nref), vt_elems, s);
     if (rc) return rc;
 
     // text: Linear(text_dim -> D, no bias) (base.py:1541)
@@ -422,6 +448,157 @@ int ace355_cond_encode(ace355_cond* h, const float* text_dev, const int32_t* tex
     }
     ACE_HIP(hipStreamSynchronize(s));  // `table` is host memory
     return ACE355_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ detokenizer (N2)
+namespace {
+
+bool resolve_detok(ace355_detok* h, const std::string& name, Dest* d) {
+    const long D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+    auto rows = [&](void* dst, int bf, long r, long c, long ld, long row0) {
+        *d = Dest{dst, bf, PACK_ROWS, r, c, ld, row0, 0, false};
+        return true;
+    };
+    EncoderW& E = h->enc;
+    if (name == "embed_tokens.weight") return rows(E.w_embed, 1, D, D, D, 0);
+    if (name == "embed_tokens.bias") return rows(E.b_embed, 0, 1, D, D, 0);
+    if (name == "norm.weight") return rows(E.norm, 0, 1, D, D, 0);
+    if (name == "special_tokens") return rows(h->special, 0, h->cfg.pool_window_size, D, D, 0);
+    if (name == "proj_out.weight") return rows(h->w_out, 1, h->cfg.out_dim, D, D, 0);
+    if (name == "proj_out.bias") return rows(h->b_out, 0, 1, h->cfg.out_dim, h->cfg.out_dim, 0);
+    if (name.rfind("layers.", 0) != 0) return false;
+    const size_t dot = name.find('.', 7);
+    if (dot == std::string::npos) return false;
+    const int li = atoi(name.substr(7, dot - 7).c_str());
+    if (li < 0 || li >= E.n_layers) return false;
+    EncLayerW& L = E.layers[li];
+    const std::string q = name.substr(dot + 1);
+    if (q == "input_layernorm.weight") return rows(L.n_in, 0, 1, D, D, 0);
+    if (q == "post_attention_layernorm.weight") return rows(L.n_post, 0, 1, D, D, 0);
+    if (q == "self_attn.q_proj.weight") return rows(L.wqkv, 1, QD, D, D, 0);
+    if (q == "self_attn.k_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD);
+    if (q == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
+    if (q == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
+    if (q == "self_attn.q_norm.weight") return rows(L.qn, 0, 1, 128, 128, 0);
+    if (q == "self_attn.k_norm.weight") return rows(L.kn, 0, 1, 128, 128, 0);
+    if (q == "mlp.gate_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 0, false}; return true; }
+    if (q == "mlp.up_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 1, false}; return true; }
+    if (q == "mlp.down_proj.weight") return rows(L.wdown, 1, D, F, F, 0);
+    return false;
+}
+
+// shared body of the two load_tensor entry points
+int load_packed(EncBase* h, const Dest& d, const char* name, const void* data, int dtype, int64_t numel, int is_device, const char* who) {
+    if (numel != d.rows * d.cols) {
+        set_error(std::string(who) + ": wrong element count for '" + name + "': got " + std::to_string(numel) + ", expected " +
+                  std::to_string(d.rows * d.cols));
+        return ACE355_ERR_INVALID;
+    }
+    if (d.ignore) return ACE355_OK;
+    const size_t esz = dtype == ACE355_DTYPE_F32 ? 4 : 2;
+    const void* src = data;
+    if (!is_device) {
+        const size_t bytes = (size_t)numel * esz;
+        if (bytes > h->stage_bytes) {
+            if (h->stage) ACE_HIP(hipFree(h->stage));
+            h->stage = nullptr;
+            ACE_HIP(hipMalloc(&h->stage, bytes));
+            h->stage_bytes = bytes;
+        }
+        ACE_HIP(hipMemcpy(h->stage, data, bytes, hipMemcpyHostToDevice));
+        src = h->stage;
+    }
+    int rc = launch_pack(src, dtype, d.dst, d.is_bf16, d.mode, d.rows, d.cols, d.dst_ld, d.dst_row0, d.p0, 0, nullptr);
+    if (rc) return rc;
+    ACE_HIP(hipDeviceSynchronize());
+    h->loaded.insert(name);
+    h->finalized = false;
+    return ACE355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ace355_detok_create(const ace355_detok_config* cfg, ace355_detok** out) {
+    ACE_CHECK(cfg && out, "detok_create: null argument");
+    ACE_CHECK(cfg->head_dim == 128, "detok_create: head_dim must be 128");
+    ACE_CHECK(cfg->hidden_size % 256 == 0 && cfg->intermediate_size % 64 == 0, "detok_create: hidden/intermediate size");
+    ACE_CHECK(cfg->num_heads % cfg->num_kv_heads == 0, "detok_create: heads % kv_heads");
+    ACE_CHECK(cfg->num_layers >= 0 && cfg->num_layers <= 64 && cfg->pool_window_size >= 1 && cfg->pool_window_size <= 64 &&
+                  cfg->out_dim >= 1, "detok_create: layer count / pool window / out_dim");
+    ace355_detok* h = new ace355_detok();
+    h->cfg = *cfg;
+    h->D = cfg->hidden_size; h->F = cfg->intermediate_size; h->HQ = cfg->num_heads; h->KVH = cfg->num_kv_heads;
+    h->QD = cfg->num_heads * 128; h->KVD = cfg->num_kv_heads * 128;
+    h->sliding_window = cfg->sliding_window; h->sliding_layer_mask = cfg->sliding_layer_mask;
+    h->eps = cfg->rms_norm_eps; h->theta = cfg->rope_theta;
+    int rc = alloc_encoder(h, h->enc, cfg->num_layers, cfg->hidden_size);
+    if (!rc) rc = dev_alloc(h->allocs, &h->special, (size_t)cfg->pool_window_size * h->D);
+    if (!rc) rc = dev_alloc(h->allocs, &h->w_out, (size_t)cfg->out_dim * h->D);
+    if (!rc) rc = dev_alloc(h->allocs, &h->b_out, (size_t)cfg->out_dim);
+    if (rc) { ace355_detok_destroy(h); return rc; }
+    h->expected_tensors = 6 + (size_t)cfg->num_layers * 11;
+    *out = h;
+    return ACE355_OK;
+}
+
+void ace355_detok_destroy(ace355_detok* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    for (void* p : h->ws_allocs) hipFree(p);
+    if (h->stage) hipFree(h->stage);
+    delete h;
+}
+
+int ace355_detok_load_tensor(ace355_detok* h, const char* name, const void* data, int dtype, int64_t numel, int is_device) {
+    ACE_CHECK(h && name && data, "detok_load_tensor: null argument");
+    ACE_CHECK(dtype == ACE355_DTYPE_F32 || dtype == ACE355_DTYPE_BF16, "detok_load_tensor: dtype");
+    Dest d;
+    if (!resolve_detok(h, name, &d)) {
+        set_error(std::string("detok_load_tensor: unknown tensor name '") + name + "'");
+        return ACE355_ERR_INVALID;
+    }
+    return load_packed(h, d, name, data, dtype, numel, is_device, "detok_load_tensor");
+}
+
+int ace355_detok_finalize(ace355_detok* h) {
+    ACE_CHECK(h, "detok_finalize: null handle");
+    if (h->loaded.size() != h->expected_tensors) {
+        set_error("detok_finalize: " + std::to_string(h->loaded.size()) + " of " + std::to_string(h->expected_tensors) + " tensors loaded");
+        return ACE355_ERR_STATE;
+    }
+    if (h->stage) { hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+    h->finalized = true;
+    return ACE355_OK;
+}
+
+int ace355_detok_run(ace355_detok* h, const float* x_dev, int B, int T5, float* out_dev, void* stream) {
+    ACE_CHECK(h && x_dev && out_dev, "detok_run: null argument");
+    if (!h->finalized) { set_error("detok_run: call ace355_detok_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && T5 > 0 && (long)B * T5 <= (1L << 20), "detok_run: sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->D, P = h->cfg.pool_window_size, OD = h->cfg.out_dim;
+    const long R5 = (long)B * T5, R = R5 * P;  // 5 Hz tokens, 25 Hz rows: R5 sequences of P tokens
+    const long vt_elems = R5 * h->KVD * (((P + 63) / 64) * 64);
+    int rc = ensure_workspace(h, R, R5 * D, (int)R5, vt_elems, s);
+    if (rc) return rc;
+    // embed_tokens (base.py:888), then one copy per frame of the window + its special token (:889-894)
+    rc = launch_f32_to_bf16(x_dev, h->in_bf, R5 * D, s);
+    if (rc) return rc;
+    GemmEpilogue ep{1, h->enc.b_embed, nullptr, nullptr, 0, 0};
+    rc = launch_gemm(h->in_bf, D, h->enc.w_embed, D, h->emb, D, (int)R5, D, D, ep, s);
+    if (rc) return rc;
+    rc = launch_expand_add(h->emb, h->special, h->h, R5, P, D, s);
+    if (rc) return rc;
+    // (b t) sequences of P tokens through the encoder layers + norm (:896-987), proj_out (:989), unfold (:991) is a view
+    rc = encoder_layers(h, h->enc, (int)R5, P, nullptr, h->xn, s);
+    if (rc) return rc;
+    ep = GemmEpilogue{1, h->b_out, nullptr, nullptr, 0, 0};
+    return launch_gemm(h->xn, D, h->w_out, D, out_dev, OD, (int)R, OD, D, ep, s);
 }
 
 }  // extern "C"

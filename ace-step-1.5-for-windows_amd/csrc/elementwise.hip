@@ -470,6 +470,21 @@ __global__ void gather_rows_bf16_f32_kernel(const bf16_t* __restrict__ src, long
     *reinterpret_cast<float4*>(dst + r * dst_ld + c) = v;
 }
 
+// AudioTokenDetokenizer (base.py:889-894): h[(r*P + p)][c] = emb[r][c] + special[p][c]
+__global__ void expand_add_kernel(const float* __restrict__ emb, const float* __restrict__ special, float* __restrict__ out, long rows,
+                                  int P, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4 = D / 4;
+    if (i >= rows * P * d4) return;
+    const long rp = i / d4;
+    const int c = (int)(i - rp * d4) * 4;
+    const long r = rp / P;
+    const int p = (int)(rp - r * P);
+    const float4 a = *reinterpret_cast<const float4*>(emb + r * D + c);
+    const float4 b = *reinterpret_cast<const float4*>(special + (long)p * D + c);
+    *reinterpret_cast<float4*>(out + rp * D + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
@@ -497,6 +512,14 @@ int launch_gather_rows_bf16_f32(const bf16_t* src, long src_ld, const int* row_s
     ACE_CHECK(cols % 4 == 0, "gather_rows: cols must be a multiple of 4");
     const long n = rows * (cols / 4);
     hipLaunchKernelGGL(gather_rows_bf16_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, src, src_ld, row_src, dst, dst_ld, rows, cols);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_expand_add(const float* emb, const float* special, float* out, long rows, int P, int D, hipStream_t s) {
+    ACE_CHECK(D % 4 == 0, "expand_add: D must be a multiple of 4");
+    const long n = rows * P * (D / 4);
+    hipLaunchKernelGGL(expand_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, emb, special, out, rows, P, D);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,121 @@
+"""LM-hint path: ``<|audio_code_N|>`` text -> code indices -> FSQ output -> detokenizer ->
+``lm_hints_25Hz`` (what replaces ``src_latents`` where ``is_covers``; modeling_acestep_v15_base.py:1638-1649).
+
+Mirror of ``AudioCodesMixin._parse_audio_code_string`` / ``_decode_audio_codes_to_latents``
+(acestep/core/generation/handler/audio_codes.py:20-66).  ``NativeDetokenizer`` is call-compatible with the reference's
+``AudioTokenDetokenizer`` module (``model.detokenizer``).  The FSQ index decode is a [n, 6] x [6, 2048] product and stays in
+torch on the caller's device; its arithmetic belongs to ``vector_quantize_pytorch`` (absent here): the restatement in
+``fsq_output_from_indices`` is parity-unpinned.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import Dict, List, Optional, Sequence, Union
+
+import torch
+import torch.nn.functional as F
+
+from . import native
+from .config import DetokConfig
+
+MAX_AUDIO_CODE = 63999
+FSQ_LEVELS = (8, 8, 8, 5, 5, 5)
+
+
+def parse_audio_code_string(code_str: str) -> List[int]:
+    """Every ``<|audio_code_N|>`` of the string, clamped to [0, 63999] (audio_codes.py:20-47)."""
+    if not code_str:
+        return []
+    return [max(0, min(int(x), MAX_AUDIO_CODE)) for x in re.findall(r"<\|audio_code_(\d+)\|>", code_str)]
+
+
+def fsq_output_from_indices(indices: torch.Tensor, project_out_weight: torch.Tensor, project_out_bias: Optional[torch.Tensor] = None,
+                            levels: Sequence[int] = FSQ_LEVELS) -> torch.Tensor:
+    """ResidualFSQ(num_quantizers=1).get_output_from_indices restated: indices [B, T, 1] (or [B, T]) -> [B, T, dim]."""
+    idx = indices[..., 0] if indices.dim() == 3 else indices
+    lv = torch.tensor(list(levels), dtype=torch.int64, device=idx.device)
+    basis = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.int64, device=idx.device), lv[:-1]]), dim=0)
+    digits = (idx.to(torch.int64).unsqueeze(-1) // basis) % lv
+    half = (lv // 2).to(torch.float32)
+    codes = (digits.to(torch.float32) - half) / half
+    return F.linear(codes, project_out_weight.float(), None if project_out_bias is None else project_out_bias.float())
+
+
+class NativeDetokenizer:
+    def __init__(self, cfg: DetokConfig, device: Union[str, torch.device] = "cuda:0", out_dtype: torch.dtype = torch.float32):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.out_dtype = out_dtype
+        self._lib = native.lib()
+        mask = 0
+        for i in range(cfg.num_attention_pooler_hidden_layers):
+            if cfg.layer_types[i] == "sliding_attention":
+                mask |= 1 << i
+        c = native.DetokConfigC(cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim,
+                                cfg.num_attention_pooler_hidden_layers, cfg.pool_window_size, cfg.audio_acoustic_hidden_dim,
+                                cfg.sliding_window, mask, cfg.rms_norm_eps, cfg.rope_theta)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_detok_create(C.byref(c), C.byref(h)), "detok_create")
+        self._h = h
+
+    @classmethod
+    def from_reference(cls, module, device: Union[str, torch.device], out_dtype: torch.dtype = torch.float32) -> "NativeDetokenizer":
+        """Build from the loaded reference module (``handler.model.detokenizer``)."""
+        self = cls(DetokConfig.from_reference(module.config), device, out_dtype)
+        self.load_state_dict(module.state_dict())
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            with torch.cuda.device(self.device):
+                self._lib.ace355_detok_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        with torch.cuda.device(self.device):
+            for name, t in sd.items():
+                if "rotary_emb" in name:
+                    continue
+                t = t.detach()
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                t = t.contiguous()
+                dt = native.DTYPE_F32 if t.dtype == torch.float32 else native.DTYPE_BF16
+                native.check(self._lib.ace355_detok_load_tensor(self._h, name.encode(), native.ptr(t), dt, t.numel(),
+                                                                1 if t.is_cuda else 0), f"detok_load_tensor({name})")
+            native.check(self._lib.ace355_detok_finalize(self._h), "detok_finalize")
+
+    def __call__(self, x: torch.Tensor, attention_mask=None) -> torch.Tensor:
+        """x [B, T5, hidden] -> [B, T5 * pool_window_size, 64] (``AudioTokenDetokenizer.forward``; the reference never
+        passes a mask here: audio_codes.py:65, base.py:1647)."""
+        if attention_mask is not None:
+            raise ValueError("ace355: the detokenizer takes no attention mask (the reference never passes one)")
+        B, T5, D = x.shape
+        if D != self.cfg.hidden_size:
+            raise ValueError("ace355: detokenizer input width does not match the configuration")
+        x = x.detach().to(self.device, torch.float32).contiguous()
+        out = torch.empty(B, T5 * self.cfg.pool_window_size, self.cfg.audio_acoustic_hidden_dim, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_detok_run(self._h, native.ptr(x), B, T5, native.ptr(out), native.current_stream_ptr()), "detok_run")
+        return out if self.out_dtype == torch.float32 else out.to(self.out_dtype)
+
+    forward = __call__
+
+
+def decode_audio_codes_to_latents(code_str: str, detokenizer, project_out_weight: torch.Tensor,
+                                  project_out_bias: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """``_decode_audio_codes_to_latents`` (audio_codes.py:49-66): None when the string holds no codes."""
+    ids = parse_audio_code_string(code_str)
+    if not ids:
+        return None
+    dev = project_out_weight.device
+    idx = torch.tensor(ids, dtype=torch.long, device=dev).unsqueeze(0).unsqueeze(-1)
+    return detokenizer(fsq_output_from_indices(idx, project_out_weight, project_out_bias))

@@ -47,6 +47,14 @@ class CondConfigC(C.Structure):
     ]
 
 
+class DetokConfigC(C.Structure):
+    _fields_ = [
+        ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("num_layers", C.c_int32), ("pool_window_size", C.c_int32), ("out_dim", C.c_int32),
+        ("sliding_window", C.c_int32), ("sliding_layer_mask", C.c_uint64), ("rms_norm_eps", C.c_float), ("rope_theta", C.c_float),
+    ]
+
+
 class VaeConfigC(C.Structure):
     _fields_ = [
         ("decoder_channels", C.c_int32), ("decoder_input_channels", C.c_int32), ("audio_channels", C.c_int32),
@@ -87,6 +95,11 @@ SIGNATURES = {
     "ace355_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int,
                                      C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32),
                                      C.c_void_p]),
+    "ace355_detok_create": (C.c_int, [C.POINTER(DetokConfigC), C.POINTER(C.c_void_p)]),
+    "ace355_detok_destroy": (None, [C.c_void_p]),
+    "ace355_detok_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),
+    "ace355_detok_finalize": (C.c_int, [C.c_void_p]),
+    "ace355_detok_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_peak_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "ace355_latent_check": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_void_p]),
     "ace355_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -202,6 +202,37 @@ int ace355_cond_encode(ace355_cond* h, const float* text_dev, const int32_t* tex
                        const int32_t* lyric_len_host, int Ll, const float* refer_dev, const int32_t* refer_item_host,
                        int Nref, int Tref, int B, float* enc_out_dev, int32_t* enc_len_out_host, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Audio-token detokenizer of the LM-hint path: AudioTokenDetokenizer.forward,
+ * base.py:886-994, as called by _decode_audio_codes_to_latents (handler/audio_codes.py:49-66) and by
+ * prepare_condition (base.py:1646-1647).  Input = the quantizer's output for the 5 Hz audio codes, output =
+ * lm_hints_25Hz.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ace355_detok ace355_detok;
+
+typedef struct ace355_detok_config {
+    int32_t hidden_size;        /* 2048 */
+    int32_t intermediate_size;  /* 6144 */
+    int32_t num_heads;          /* 16 */
+    int32_t num_kv_heads;       /* 8 */
+    int32_t head_dim;           /* 128 (only value supported) */
+    int32_t num_layers;         /* 2 (num_attention_pooler_hidden_layers) */
+    int32_t pool_window_size;   /* 5: 25 Hz frames per 5 Hz token */
+    int32_t out_dim;            /* 64 (audio_acoustic_hidden_dim) */
+    int32_t sliding_window;     /* 128 */
+    uint64_t sliding_layer_mask;
+    float rms_norm_eps;
+    float rope_theta;
+} ace355_detok_config;
+
+int ace355_detok_create(const ace355_detok_config* cfg, ace355_detok** out);
+void ace355_detok_destroy(ace355_detok* h);
+/* name = a key of AudioTokenDetokenizer.state_dict() (`model.detokenizer` of the reference checkpoint). */
+int ace355_detok_load_tensor(ace355_detok* h, const char* name, const void* data, int dtype, int64_t numel, int is_device);
+int ace355_detok_finalize(ace355_detok* h);
+/* x dev f32 [B, T5, hidden] -> out dev f32 [B, T5 * pool_window_size, out_dim]. */
+int ace355_detok_run(ace355_detok* h, const float* x_dev, int B, int T5, float* out_dev, void* stream);
+
 /* Post-decode peak clip, H/generate_music_decode.py:191-195: per item, if any peak > 1 divide
  * every item by clamp(peak, min=1).  wav dev f32 [B, per_item]. */
 int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream);

@@ -37,6 +37,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(native.VaeConfigC) == 4 * 4 + 2 * 8 * 4
     assert ctypes.sizeof(native.SampleParamsC) == 72
     assert ctypes.sizeof(native.CondConfigC) == 10 * 4 + 8 + 2 * 4
+    assert ctypes.sizeof(native.DetokConfigC) == 9 * 4 + 4 + 8 + 2 * 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -11,6 +11,7 @@ import torch
 from ace355 import weightgen
 from oracle import apg as o_apg
 from oracle import cond as o_cond
+from oracle import detok as o_detok
 from oracle import dit as o_dit
 from oracle import sampler as o_sampler
 from oracle import tiling as o_tiling
@@ -144,6 +145,24 @@ def test_g7_condition_encoder(golden_dir, case):
                                     T(G[f"{case}_refer"]), T(G[f"{case}_order"]))
     assert torch.equal(m.long(), T(G[f"{case}_m"]))
     assert float((h - T(G[f"{case}_h"])).abs().max()) < 2e-5
+
+
+def test_g8_detokenizer_and_code_parser(golden_dir):
+    """AudioTokenDetokenizer + the audio-code string parser vs the imported reference."""
+    G = np.load(f"{golden_dir}/g8_detokenizer.npz")
+    cfg = o_detok.DetokConfig(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
+    w = weightgen.make_dit_weights(o_detok.detok_weight_shapes(cfg), cfg.hidden_size, seed=int(G["seed"]), mode="test")
+    assert weightgen.checksum(w) == float(G["wsum"])
+    y = o_detok.detokenizer(cfg, w, T(G["x"]))
+    assert float((y - T(G["y"])).abs().max()) < 2e-5
+    for i, c in enumerate(G["parse_cases"].tolist()):
+        assert o_detok.parse_audio_code_string(c) == G[f"parse_{i}"].tolist()
+    # FSQ index decode (parity unpinned: vector_quantize_pytorch is absent) - structural checks of the restatement
+    codes = o_detok.fsq_codes_from_indices(torch.tensor([0, 63999, 1, 8, 64 * 8]), (8, 8, 8, 5, 5, 5))
+    assert torch.allclose(codes[0], torch.tensor([-1.0, -1, -1, -1, -1, -1])) and torch.allclose(codes[1], torch.tensor([0.75, 0.75, 0.75, 1, 1, 1]))
+    assert torch.allclose(codes[2], torch.tensor([-0.75, -1, -1, -1, -1, -1])) and torch.allclose(codes[3], torch.tensor([-1, -0.75, -1, -1, -1, -1]))
+    assert torch.allclose(codes[4], torch.tensor([-1, -1, -1, -0.5, -1, -1]))
+    assert len({tuple(r.tolist()) for r in o_detok.fsq_codes_from_indices(torch.arange(64000), (8, 8, 8, 5, 5, 5))}) == 64000
 
 
 def test_latent_guards():

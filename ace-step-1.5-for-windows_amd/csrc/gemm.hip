@@ -7,8 +7,11 @@
 //   gemm_kernel     (v1)  register-staged 128x128x64 tile: the simple bring-up / A-B reference (ACE355_GEMM=v1).
 //   gemm_sp_kernel  (v4)  the product kernel: A/W tiles HBM -> LDS by DMA (global_load_lds, issued from asm so hipcc does
 //                         not drain it), two LDS stages, K loop rotated by half a step, DMA pieces / fragment reads
-//                         interleaved one per MFMA, 192x256 (8 waves) or 128/192x128 (4 waves) block tiles,
-//                         grouped XCD-local rasterisation.  DESIGN.md section 5 has the measured ladder and the ablation.
+//                         interleaved one per MFMA, 192x256 / 192x128 (8 waves) or 128/192x128 (4 waves) block tiles,
+//                         grouped XCD-local rasterisation, persistent workgroups for multi-round launches.  DESIGN.md
+//                         section 5 has the measured ladder; the ablation variants (no-DMA / no-fragment-read / no-barrier),
+//                         the non-interleaved schedule and the ping-pong wave-group kernel that produced its numbers were
+//                         removed from the source once measured (git history: "ping-pong wave-group kernel", "GEMM v4").
 // Common: MFMA 32x32x16 bf16, K-contiguous operands, LDS image XOR-swizzled at 16-B granularity (slot ^= (row>>1)&7:
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
@@ -337,11 +340,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 //     DMA tile kt+2 -> stage kt&1;  ds_read frags(kt+1, kk=0,1) -> P  |  MFMA(kt, kk=2,3) from Q
 // Two LDS stages (2 workgroups per CU), one barrier per K-step, >= 8 MFMAs of cover on both sides of every LDS read.
 // WNW = waves along N (2 -> BN 128, 256 threads, 2 workgroups/CU; 4 -> BN 256, 512 threads, 1 workgroup/CU).
-// ABL (timing ablation only, results garbage): 1 no DMA in loop, 2 no LDS fragment reads in loop, 3 both, 4 no barrier
 // NTW = 32-column accumulator tiles per wave (2: wave tile MT*32 x 64; 1: MT*32 x 32, used for the 8-wave 192x128 tile).
 // PERS 1: persistent workgroups - the grid is one workgroup per CU slot and each walks its XCD region's tiles with stride
 // gridDim/8: no s_endpgm store drain, no workgroup re-dispatch and no kernarg reload between the tiles of a multi-round GEMM.
-template <int MODE, int MT, int WNW, int ABL = 0, int ILV = 0, int NTW = 2, int PERS = 0>  // ILV 1: DMA pieces / fragment reads interleaved between MFMAs
+template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0>
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
@@ -446,11 +448,10 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, pa, pw);
 
-    if (ABL & 2) load_frags(smem, 2, qa, qw);
     // ---- ILV: explicit instruction interleave.  An LDS-DMA piece costs 60-185 cycles to ISSUE (TA queue); seven of them
     // back to back right after the barrier stall the in-order wave before its first MFMA.  Here every MFMA is followed
     // by at most one DMA piece or two fragment reads, pinned with sched_barrier.
-    if (ILV) {
+    {
         constexpr int NM = 2 * MT * NTW;  // MFMAs per half K-step
         constexpr int NF = 2 * (MT + NTW);  // fragment reads per half K-step
         auto frag_ptr = [&](const char* st, int kk0, int f) -> const uint4* {
@@ -538,164 +539,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         continue;
     }
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* st = smem + (kt & 1) * STAGE;
-        if (!(ABL & 2)) load_frags(st, 2, qa, qw);
-        else { _Pragma("unroll") for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(qa[0][i]), "+v"(qa[1][i])); } }
-        mma(pa, pw);
-        __builtin_amdgcn_sched_barrier(0);
-        // lgkmcnt(0) in the builtin form (simm16 0xC07F: vmcnt 63, expcnt 7, lgkmcnt 0) so hipcc's own scoreboard knows the Q
-        // fragments have landed; an asm wait is invisible to it and it would make MFMA(Q) wait on the NEW P loads instead.
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (kt + 1 < nk) {
-            wait_vmcnt<0>();  // only tile kt+1 is in flight here
-            if (ABL != 4) __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk && !(ABL & 1)) issue(kt + 2);
-            if (!(ABL & 2)) load_frags(smem + ((kt + 1) & 1) * STAGE, 0, pa, pw);
-            else { _Pragma("unroll") for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(pa[0][i]), "+v"(pa[1][i])); } }
-        }
-        mma(qa, qw);
-        __builtin_amdgcn_sched_barrier(0);
     }
-    // (an LDS-transposed 16-byte-store epilogue was tried for modes 0/3 and measured 3-12% SLOWER than these direct
-    //  64-byte-segment stores: two extra barriers + 96 ds_write_b16 per lane)
-    gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
-    return;  // (the non-interleaved schedules are single-tile only)
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ v5: ping-pong wave groups
-// Same 192x256x64 tile, LDS image and DMA as v4, different schedule.  The 8 waves form two groups of four (group = wave>>2,
-// one wave of each group per SIMD).  Every half K-step is split into a MEM section (fragment ds_reads, DMA issue, waits)
-// and an MFMA section (12 back-to-back MFMAs at raised priority), each closed by a workgroup barrier; group 1 executes one
-// extra barrier up front, so it runs exactly one section behind group 0:
-//        barrier clock   |  4T        4T+1       4T+2       4T+3      |
-//        group 0         |  MEM(T,0)  MFMA(T,0)  MEM(T,1)   MFMA(T,1) |
-//        group 1         |  MFMA(T-1,1) MEM(T,0) MFMA(T,0)  MEM(T,1)  |
-// On each SIMD one wave feeds the matrix pipe while its partner issues memory instructions: a DMA piece's 60-185 cycle
-// issue stall never sits in front of an MFMA.
-//   WAR: tile T+1 is DMA'd into stage (T+1)&1 from MEM(T,0) on; the last reads of tile T-1 (group 1, MEM(T-1,1)) were
-//        retired (lgkmcnt(0)) before barrier 4T.
-//   RAW: every wave waits for its own pieces of tile T+1 (vmcnt(0)) at the end of MEM(T,1), before barrier 4T+3 (group 0)
-//        / 4T+4 (group 1); the first read of tile T+1 (group 0, MEM(T+1,0)) comes after barrier 4T+4.
-template <int MODE, int ABL = 0>  // ABL (timing only, results garbage): 1 DMA always re-reads K-tile 0, 2 no DMA in loop, 3 no fragment reads
-__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int ldw,
-                                                         void* __restrict__ Cv, int ldc, int M, int N, int K, GemmEpilogue ep,
-                                                         int tiles_n, int nwg, int group_m, int xcd_m) {
-    constexpr int MT = 3, NTW = 2, WNW = 4, NW = 8;
-    constexpr int BMv = MT * 64, BNv = WNW * NTW * 32;
-    constexpr int A_BYTES = BMv * 128, W_BYTES = BNv * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int AJ = BMv / (8 * NW), WJ = BNv / (8 * NW);
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-
-    int tm, tn;
-    {
-        const int tiles_m = nwg / tiles_n;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int xcd_n = 8 / xcd_m;
-        const int rm = (tiles_m + xcd_m - 1) / xcd_m, rn = (tiles_n + xcd_n - 1) / xcd_n;
-        const int xi = xcd / xcd_n, xj = xcd - xi * xcd_n;
-        const int m_lo = xi * rm, n_lo = xj * rn;
-        const int hm = min(rm, tiles_m - m_lo), hn = min(rn, tiles_n - n_lo);
-        if (hm <= 0 || hn <= 0 || idx >= hm * hn) return;
-        const int gsz = group_m * hn;
-        const int grp = idx / gsz, rem = idx - grp * gsz;
-        const int first_m = grp * group_m;
-        const int gm = min(hm - first_m, group_m);
-        tm = m_lo + first_m + rem % gm;
-        tn = n_lo + rem / gm;
-    }
-    const int m0 = tm * BMv, n0 = tn * BNv;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WNW, wn = wave % WNW;
-
-    const int lrow = lane >> 3, pslot = lane & 7;
-    const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
-    const bf16_t* a_src[AJ];
-    const bf16_t* w_src[WJ];
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) a_src[j] = A + (long)min(m0 + 8 * (wave + NW * j) + lrow, M - 1) * lda + sslot * 8;
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) w_src[j] = W + (long)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * ldw + sslot * 8;
-    const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
-
-    f32x16 acc[MT][NTW];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = K / BK;
-    auto issue = [&](int kt) {
-        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
-        const int ks = (ABL == 1) ? 0 : kt;
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) glds16_asm(a_src[j] + ks * BK, sb + j * (NW * 1024));
-#pragma unroll
-        for (int j = 0; j < WJ; ++j) glds16_asm(w_src[j] + ks * BK, sb + A_BYTES + j * (NW * 1024));
-    };
-    const int frow = lane & 31, fhalf = lane >> 5;
-    int a_off[MT], w_off[NTW];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) a_off[i] = (wm * (MT * 32) + i * 32 + frow) * 128;
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) w_off[j] = A_BYTES + (wn * (NTW * 32) + j * 32 + frow) * 128;
-    const int swz = ((wm * (MT * 32) + frow) >> 1) & 7;
-    const int swzw = ((wn * (NTW * 32) + frow) >> 1) & 7;
-    bf16x8 fa[2][MT], fw[2][NTW];
-    auto load_frags = [&](const char* st, int kk0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int slot = (kk0 + h) * 2 + fhalf;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[h][i] = as_bf16x8(*reinterpret_cast<const uint4*>(st + a_off[i] + ((slot ^ swz) << 4)));
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
-        }
-    };
-    auto mma = [&]() {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma32(fw[h][j], fa[h][i], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-#define ACE_PP_BARRIER()                    \
-    __builtin_amdgcn_sched_barrier(0);      \
-    __builtin_amdgcn_s_barrier();           \
-    __builtin_amdgcn_sched_barrier(0);
-
-    issue(0);
-    wait_vmcnt<0>();
-    ACE_PP_BARRIER()
-    if (wm == 1) { ACE_PP_BARRIER() }  // group 1 runs one section behind group 0
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* st = smem + (kt & 1) * STAGE;
-        // MEM(kt, 0): fragments of kk = 0,1; DMA of the next tile into the other stage
-        if (ABL != 3 || kt == 0) load_frags(st, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk && ABL != 2) issue(kt + 1);
-        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-        ACE_PP_BARRIER()
-        mma();
-        ACE_PP_BARRIER()
-        // MEM(kt, 1): fragments of kk = 2,3; this wave's pieces of the next tile must have landed before the barrier
-        if (ABL != 3) load_frags(st, 2);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        wait_vmcnt<0>();
-        ACE_PP_BARRIER()
-        mma();
-        ACE_PP_BARRIER()
-    }
-    if (wm == 0) { ACE_PP_BARRIER() }  // balance group 1's extra barrier
-#undef ACE_PP_BARRIER
-    gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
 }
 
 
@@ -722,14 +566,11 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
         return;
     }
-    static int abl = -1, group_m = -1, xcd_m_env = -1, ilv = -1, pp = 0, pers = 0;
-    if (abl < 0) {
+    static int group_m = -1, xcd_m_env = -1, pers = 0;
+    if (group_m < 0) {
         pers = env_int("ACE355_GEMM_PERS", 1);         // persistent workgroups for multi-round launches
-        pp = env_int("ACE355_GEMM_PP", 0);             // ping-pong wave-group schedule for the 192x256 tile
-        abl = env_int("ACE355_GEMM_ABL", 0);          // timing ablations (results garbage)
         group_m = env_int("ACE355_GEMM_GROUPM", 4);    // rasterisation group height
         xcd_m_env = env_int("ACE355_GEMM_XCDM", 0);    // pin the XCD grid shape
-        ilv = env_int("ACE355_GEMM_ILV", 1);           // interleaved DMA / fragment-read schedule
     }
     // XCD grid: minimise xcd_n*|A| + xcd_m*|W| = (8/xm) * M + xm * N (same K), over xm in {1,2,4,8}
     const int tiles_m = nwg / tiles_n;
@@ -748,28 +589,13 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
     const dim3 grid(8 * region);
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
-    if (ilv && !abl) {
-        if (big == 2) {
-            if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
-        } else if (big && pp == 1) ACE_LAUNCH_SP((gemm_pp_kernel<MODE>), 512);
-        else if (big && pp == 11) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 1>), 512);
-        else if (big && pp == 12) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 2>), 512);
-        else if (big && pp == 13) ACE_LAUNCH_SP((gemm_pp_kernel<MODE, 3>), 512);
-        else if (big && pers && region > 32) {
-            const dim3 pgrid(8 * 32);
-            hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 0, 1, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg,
-                               group_m, xcd_m);
-        } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 0, 1>), 512);
-        else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 0, 1>), 256);
-        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 0, 1>), 256);
-    } else if (big) {
-        if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
-        else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 3>), 512);
-        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
-    } else if (abl == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 1>), 256);
-    else if (abl == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2>), 256);
-    else if (abl == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 3>), 256);
-    else if (abl == 4) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 4>), 256);
+    if (big == 2) {
+        if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
+    } else if (big && pers && region > 32) {
+        const dim3 pgrid(8 * 32);
+        hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
+                           xcd_m);
+    } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
     else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
     else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2>), 256);
 #undef ACE_LAUNCH_SP

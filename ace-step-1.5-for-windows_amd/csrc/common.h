@@ -95,6 +95,7 @@ struct GemmEpilogue {
     const float* cvec;  // mode 2: rows m >= cvec_row0 additionally get + cvec[n] (constant cross-attention term of broadcast slots)
     int cvec_row0;
     int clk_probe;  // set by launch_gemm (ACE355_GEMM_CLK diagnostic)
+    int ksplit;     // set by launch_gemm: > 1 = split-K (mode 2 only): blockIdx.y owns a K range and ADDS into H with fp32 atomics
     int wide_ok;  // set by launch_gemm: C / ldc / per-column vectors are 16-byte aligned, so the 16-byte staged epilogue may be used
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,

@@ -133,6 +133,35 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     gA = {g1.x + a2.x, g1.y + a2.y, g1.z + a2.z, g1.w + a2.w};
                     gB = {g1.x + b2.x, g1.y + b2.y, g1.z + b2.z, g1.w + b2.w};
                 }
+                if (ep.ksplit > 1) {
+                    // split-K: this workgroup holds a partial sum over its K range; gate * partial is added with fp32 atomics
+                    // (no workspace, no reduction pass), 64 consecutive-lane floats = two full 128-byte rows per instruction.
+                    // The constant term is added by the first K range only.
+                    const bool add_cv = ep.cvec && blockIdx.y == 0;
+                    const int col = lane & 31, rhalf = lane >> 5;
+                    const int nn = nw0 + j * 32 + col;
+                    float g1s = 1.f, gAs = 1.f, gBs = 1.f, cvs = 0.f;
+                    if (ep.cvec) cvs = ep.cvec[nn];
+                    if (ep.g1) {
+                        g1s = ep.g1[nn];
+                        const int seqA = mw0 / rps, last = (M - 1) / rps;
+                        gAs = g1s + ep.g2[(long)min(seqA, last) * ep.g2_stride + nn];
+                        gBs = g1s + ep.g2[(long)min(seqA + 1, last) * ep.g2_stride + nn];
+                    }
+                    float* hq = reinterpret_cast<float*>(Cv) + nn;
+#pragma unroll
+                    for (int t = 0; t < MT * 16; ++t) {
+                        const int row = t * 2 + rhalf;
+                        const int m = mw0 + row;
+                        const float a = *reinterpret_cast<const float*>(stg + stage_off<128>(row, col >> 2) + (col & 3) * 4);
+                        float gt = (remA + row >= rps) ? gBs : gAs;
+                        if (ep.g1 && !two_gate) gt = g1s + ep.g2[(long)(min(m, M - 1) / rps) * ep.g2_stride + nn];
+                        float o = gt * a;
+                        if (add_cv && m >= ep.cvec_row0) o += cvs;
+                        if (ROWS_FULL || m < M) unsafeAtomicAdd(hq + (long)m * ldc, o);
+                    }
+                    continue;
+                }
                 float4 hv[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -186,8 +215,9 @@ __device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], voi
                     float gate = 1.f;
                     if (ep.g1) gate = ep.g1[n] + ep.g2[(long)(m / ep.rows_per_seq) * ep.g2_stride + n];
                     float add = gate * v;
-                    if (ep.cvec && m >= ep.cvec_row0) add += ep.cvec[n];
-                    reinterpret_cast<float*>(Cv)[(long)m * ldc + n] += add;
+                    if (ep.cvec && m >= ep.cvec_row0 && (ep.ksplit <= 1 || blockIdx.y == 0)) add += ep.cvec[n];
+                    if (ep.ksplit > 1) unsafeAtomicAdd(reinterpret_cast<float*>(Cv) + (long)m * ldc + n, add);
+                    else reinterpret_cast<float*>(Cv)[(long)m * ldc + n] += add;
                 }
             }
     }
@@ -344,7 +374,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // PERS 1: persistent workgroups - the grid is one workgroup per CU slot and each walks its XCD region's tiles with stride
 // gridDim/8: no s_endpgm store drain, no workgroup re-dispatch and no kernarg reload between the tiles of a multi-round GEMM.
 template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0>
-__global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W,
+__global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A0, int lda, const bf16_t* __restrict__ W0,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
     constexpr int BMv = MT * 64;
@@ -405,7 +435,14 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = K / BK;
+    // split-K (ep.ksplit > 1, mode 2): blockIdx.y owns K steps [kt0, kt0 + nk)
+    const int nk_all = K / BK;
+    const int kchunk = (nk_all + ep.ksplit - 1) / ep.ksplit;
+    const int kt0 = (ep.ksplit > 1) ? (int)blockIdx.y * kchunk : 0;
+    const int nk = (ep.ksplit > 1) ? min(kchunk, nk_all - kt0) : nk_all;
+    if (nk <= 0) return;
+    const bf16_t* A = A0 + kt0 * BK;
+    const bf16_t* W = W0 + kt0 * BK;
     auto issue = [&](int kt) {
         const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
 #pragma unroll
@@ -587,7 +624,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     }
     const int xcd_n = 8 / xcd_m;
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
-    const dim3 grid(8 * region);
+    const dim3 grid(8 * region, ep.ksplit > 1 ? ep.ksplit : 1);
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if (big == 2) {
         if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
@@ -642,6 +679,22 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     const int bm = mt * 64;
     const int tiles_m = (M + bm - 1) / bm;
     const int nwg = tiles_m * tiles_n;
+    // Small-M residual GEMMs (batch-1 requests: M = 750 rows -> 96 workgroups, each alone with a 32-96 step K loop) are
+    // latency bound: split K over blockIdx.y and let every part add gate * partial into H with fp32 atomics.  Only mode 2
+    // (its epilogue is an accumulation already); results then depend on the atomic arrival order in the last bits, so the
+    // split is limited to launches that fill less than a quarter of the chip's workgroup slots (ACE355_GEMM_KSPLIT=1 disables).
+    ep.ksplit = 1;
+    if (variant != 1 && ep.mode == 2 && big == 0) {
+        static int ks_env = -1;
+        if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
+        const int nk = K / BK;
+        int ks = 1;
+        if (nwg < 128) {
+            while (ks < 8 && nwg * ks * 2 <= 512 && nk / (ks * 2) >= 4) ks *= 2;
+        }
+        if (ks_env >= 1) ks = ks_env;
+        ep.ksplit = ks;
+    }
     switch (ep.mode) {
         case 0: launch_mode<0>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         case 1: launch_mode<1>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;

@@ -373,7 +373,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // NTW = 32-column accumulator tiles per wave (2: wave tile MT*32 x 64; 1: MT*32 x 32, used for the 8-wave 192x128 tile).
 // PERS 1: persistent workgroups - the grid is one workgroup per CU slot and each walks its XCD region's tiles with stride
 // gridDim/8: no s_endpgm store drain, no workgroup re-dispatch and no kernarg reload between the tiles of a multi-round GEMM.
-template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0>
+// NS = LDS stages (2: product default, one K step of DMA cover; 3-4: small-M launches with one workgroup per CU, where
+// nothing else hides the HBM latency of the weight stream: NS-1 tiles stay in flight behind a counted vmcnt).
+template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0, int NS = 2>
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A0, int lda, const bf16_t* __restrict__ W0,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
     constexpr int EPI_BYTES = NW * MT * 32 * 128;  // epilogue staging: MT*32 rows x 128 B per wave
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES];
 
     // Workgroup -> tile map.  Block b runs on XCD b % 8 (observed, speed only).  The 8 XCDs (private L2s) form an
     // xcd_m x xcd_n grid of rectangular tile regions, chosen per GEMM to minimise the bytes each L2 must pull from
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     const bf16_t* A = A0 + kt0 * BK;
     const bf16_t* W = W0 + kt0 * BK;
     auto issue = [&](int kt) {
-        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
+        const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
 #pragma unroll
         for (int j = 0; j < AJ; ++j) glds16_sv(a_voff[j], A + kt * BK, sb + j * (NW * 1024));
 #pragma unroll
@@ -480,8 +482,20 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 
     bf16x8 pa[2][MT], pw[2][NTW], qa[2][MT], qw[2][NTW];
     issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 1) wait_vmcnt<AJ + WJ>(); else wait_vmcnt<0>();
+    if (NS == 2) {
+        if (nk > 1) issue(1);
+        if (nk > 1) wait_vmcnt<AJ + WJ>(); else wait_vmcnt<0>();
+    } else {
+        // deep pipeline: all NS stages primed when the K range is long enough (else plain drain: short ranges are rare here)
+        if (nk >= NS) {
+#pragma unroll
+            for (int t = 1; t < NS; ++t) issue(t);
+            wait_vmcnt<(NS - 1) * (AJ + WJ)>();
+        } else {
+            for (int t = 1; t < nk; ++t) issue(t);
+            wait_vmcnt<0>();
+        }
+    }
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, pa, pw);
 
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         if (probe) { c0 = clock64(); w0 = wall_clock64(); }
         auto kstep = [&](int kt, auto more_c, auto dma_c) {
             constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
-            const char* st = smem + (kt & 1) * STAGE;
+            const char* st = smem + (kt % NS) * STAGE;
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
@@ -518,13 +532,14 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             if (more) {
-                wait_vmcnt<0>();
+                // tile kt+1 must have landed; in the steady state tiles kt+2 .. kt+NS-1 stay in flight (loads retire in order)
+                if (dma) wait_vmcnt<(NS - 2) * (AJ + WJ)>(); else wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
             }
-            const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt & 1) * STAGE);
-            const char* stn = smem + ((kt + 1) & 1) * STAGE;
-            const bf16_t* a_k2 = A + (kt + 2) * BK;  // uniform
-            const bf16_t* w_k2 = W + (kt + 2) * BK;
+            const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
+            const char* stn = smem + ((kt + 1) % NS) * STAGE;
+            const bf16_t* a_k2 = A + (kt + NS) * BK;  // uniform: tile kt+NS goes into the stage this step just finished reading
+            const bf16_t* w_k2 = W + (kt + NS) * BK;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
@@ -552,8 +567,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             using T = std::integral_constant<bool, true>;
             using F = std::integral_constant<bool, false>;
             int kt = 0;
-            for (; kt + 2 < nk; ++kt) kstep(kt, T{}, T{});      // steady state: branch-free
-            if (kt + 1 < nk) { kstep(kt, T{}, F{}); ++kt; }      // last-but-one K step: nothing left to prefetch
+            for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{});     // steady state: branch-free
+            for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{});       // the last NS-1 K steps but one: nothing left to prefetch
             kstep(kt, F{}, F{});                                 // last K step
         }
         if (probe) {
@@ -603,8 +618,9 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
         return;
     }
-    static int group_m = -1, xcd_m_env = -1, pers = 0;
+    static int group_m = -1, xcd_m_env = -1, pers = 0, deep_env = 0;
     if (group_m < 0) {
+        deep_env = env_int("ACE355_GEMM_DEEP", -1);    // -1 heuristic, 0 never, 1 always (4-wave tiles)
         pers = env_int("ACE355_GEMM_PERS", 1);         // persistent workgroups for multi-round launches
         group_m = env_int("ACE355_GEMM_GROUPM", 4);    // rasterisation group height
         xcd_m_env = env_int("ACE355_GEMM_XCDM", 0);    // pin the XCD grid shape
@@ -625,6 +641,8 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     const int xcd_n = 8 / xcd_m;
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
     const dim3 grid(8 * region, ep.ksplit > 1 ? ep.ksplit : 1);
+    // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
+    const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.ksplit > 1 ? ep.ksplit : 1) <= 256;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if (big == 2) {
         if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
@@ -633,6 +651,8 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
     } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+    else if (deep && mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 2, 0, 3>), 256);   // 3 x 40 KB stages
+    else if (deep) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 4>), 256);              // 4 x 32 KB stages
     else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
     else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2>), 256);
 #undef ACE_LAUNCH_SP
@@ -689,8 +709,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
         const int nk = K / BK;
         int ks = 1;
-        if (nwg < 128) {
-            while (ks < 8 && nwg * ks * 2 <= 512 && nk / (ks * 2) >= 4) ks *= 2;
+        if (nwg < 128) {  // stay at one workgroup per CU: that regime gets the deep (3-4 stage) pipeline, measured best together
+            while (ks < 8 && nwg * ks * 2 <= 256 && nk / (ks * 2) >= 4) ks *= 2;
         }
         if (ks_env >= 1) ks = ks_env;
         ep.ksplit = ks;

@@ -645,7 +645,12 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.ksplit > 1 ? ep.ksplit : 1) <= 256;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if (big == 2) {
-        if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);  // 192x128, 8 waves (wave tile 96x32)
+        static int mid_ns = -1;
+        if (mid_ns < 0) mid_ns = env_int("ACE355_GEMM_MIDNS", 3);
+        if constexpr (MODE != 3) {  // 192x128, 8 waves (wave tile 96x32); one workgroup per CU: 3 stages of 40 KB
+            if (mid_ns == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
+            else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
+        }
     } else if (big && pers && region > 32) {
         const dim3 pgrid(8 * 32);
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,

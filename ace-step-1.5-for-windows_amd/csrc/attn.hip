@@ -41,7 +41,7 @@ __device__ __forceinline__ void attn_glds16(unsigned voff, const void* sbase, un
 __device__ __forceinline__ int pi23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float scale_log2) {
+__global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float scale_log2, float defer_thr) {
     constexpr int QB = NW * 32;
     constexpr int BUF = 32768;                 // K tile 16 KB | V^T tile 16 KB
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -199,9 +199,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * scale_log2);
+        // Deferred rescale: the running max only moves when some row's tile max exceeds it by more than 2^8 (wave-uniform
+        // decision); otherwise p = 2^(s - m_run) may reach 256, harmless in fp32 / bf16, and the 64-multiply rescale of O
+        // plus the alpha bookkeeping are skipped.  (m_run = -inf on a row's first live tile always takes the move branch.)
+        const float m_tile = mx * scale_log2;
+        const bool move = __any(m_tile - m_run > defer_thr);
+        const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        const float alpha = move ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
                 psum += p;
             }
         l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.0f)) {
+        if (move && __any(alpha != 1.0f)) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -280,6 +285,8 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     ACE_CHECK((a.o_row_stride % 8) == 0, "attention: output rows must be 16-byte aligned");
     // 2 waves per SIMD (256-VGPR budget): 4-wave blocks (128 queries, two workgroups per CU) by default; 8-wave blocks
     // (256 queries, K/V staged once per 256 rows) when the sequence is long enough to fill the chip with them
+    static float thr = -1.f;  // deferred-rescale threshold in log2 units (ACE355_ATTN_DEFER; 0 = rescale whenever a max moves)
+    if (thr < 0.f) { const char* e = getenv("ACE355_ATTN_DEFER"); thr = e ? (float)atof(e) : 8.0f; }
     static int nw_env = -1, clk = -1;
     if (nw_env < 0) { const char* e = getenv("ACE355_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
     if (clk < 0) { const char* e = getenv("ACE355_ATTN_CLK"); clk = e ? atoi(e) : 0; }
@@ -290,8 +297,8 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.Sq + qbk - 1) / qbk, a.Hq, a.N);
     AttnArgs ap = a;
     ap.clk_probe = clk;
-    if (nw == 8) hipLaunchKernelGGL(attn3_kernel<8>, grid, dim3(512), 0, s, ap, scale_log2);
-    else hipLaunchKernelGGL(attn3_kernel<4>, grid, dim3(256), 0, s, ap, scale_log2);
+    if (nw == 8) hipLaunchKernelGGL(attn3_kernel<8>, grid, dim3(512), 0, s, ap, scale_log2, thr);
+    else hipLaunchKernelGGL(attn3_kernel<4>, grid, dim3(256), 0, s, ap, scale_log2, thr);
     ACE_LAUNCH_CHECK();
     if (clk) {
         unsigned long long hh[8] = {0};

@@ -112,15 +112,35 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
 
     // Q fragments (B operand of S^T = K Q^T): lane holds q = lq, d = ks*16 + half*8 .. +8
     bf16x8 qf[8];
-    {
+    if constexpr (NW == 4) {
+        // Each wave DMAs its own 32 Q rows (256 B each, full lines: a row-per-lane 16-byte load pattern fetches every line
+        // eight times) into its 8 KB slice of the K/V buffer that is idle until tile kt_lo+1 is issued, then reads the
+        // fragments back.  Own data: this wave's vmcnt is the only ordering needed; the loop's first barrier keeps every
+        // other wave's next-tile DMA out of the slice until the fragments are in registers.
+        const unsigned qbuf = lds0 + (unsigned)((kt_lo + 1) & 1) * BUF + (unsigned)wave * 8192u;
+        const bf16_t* qb = a.q + (long)n * a.q_seq_stride + h * 128;  // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row_l = 4 * i + (lane >> 4);
+            const int j = (lane & 15) ^ (row_l & 15);
+            const unsigned voff = (unsigned)(min(qw0 + row_l, a.Sq - 1) * a.q_row_stride + j * 8) * 2u;
+            attn_glds16(voff, qb, (unsigned)__builtin_amdgcn_readfirstlane((int)(qbuf + (unsigned)i * 1024u)));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const char* qs = smem + ((kt_lo + 1) & 1) * BUF + wave * 8192 + lq * 256;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(qs + (((ks * 2 + half) ^ (lq & 15)) << 4)));
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // fragments in registers before the loop's barrier releases the slice
+    } else {
         const bf16_t* qp = a.q + (long)n * a.q_seq_stride + (long)qrow_c * a.q_row_stride + h * 128 + half * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks] = as_bf16x8(ldg16(qp + ks * 16));
+        // vmcnt(0) in the BUILTIN form: hipcc's scoreboard must see the Q loads retired here.  Its own counted vmcnt waits do
+        // not know about the asm-issued DMA; left to itself it re-waits "for Q" inside the loop with counts that, with a
+        // prefetch in flight, drain the DMA in the middle of the QK MFMAs (simm16 0x0F70: vmcnt 0, expcnt 7, lgkmcnt 15).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
-    // vmcnt(0) in the BUILTIN form: hipcc's scoreboard must see the Q loads retired here.  Its own counted vmcnt waits do
-    // not know about the asm-issued DMA; left to itself it re-waits "for Q" inside the loop with counts that, with a
-    // prefetch in flight, drain the DMA in the middle of the QK MFMAs (simm16 0x0F70: vmcnt 0, expcnt 7, lgkmcnt 15).
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     f32x16 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)

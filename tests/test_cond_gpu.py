@@ -119,3 +119,51 @@ def test_condition_encoder_rejects_non_prefix_masks(gpu_device):
         enc(text, torch.tensor([[1, 0, 1, 0]]), lyric, torch.ones(1, 8, dtype=torch.long), refer, torch.tensor([0]))
     with pytest.raises(RuntimeError, match="finalize"):
         enc(text, torch.ones(1, 4, dtype=torch.long), lyric, torch.ones(1, 8, dtype=torch.long), refer, torch.tensor([0]))
+
+
+def test_request_chain_cond_encoder_to_sampler_to_vae(gpu_device):
+    """The widened path end to end on one request (tiny widths, real depth pattern): condition encoder -> condition slots ->
+    27-step... here 6-step CFG+APG sampler -> VAE decode, native vs the oracle chain on the same inputs.  Every hand-over is
+    the product's own: the encoder's packed output (padding rows included) is what the DiT attends."""
+    import ace355
+    from ace355 import weightgen
+    from ace355.cond import NativeCondEncoder
+    from ace355.dit import NativeDit, generate_latents
+    from ace355.vae import NativeVae
+    from oracle import cond as o_cond, dit as o_dit, oobleck as o_vae, sampler as o_sampler
+    tiny = dict(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
+    ccfg = ace355.CondConfig(**tiny, text_hidden_dim=64, timbre_hidden_dim=64, num_lyric_encoder_hidden_layers=2, num_timbre_encoder_hidden_layers=2)
+    dcfg = ace355.DitConfig(**tiny, num_hidden_layers=2)
+    cw = weightgen.make_dit_weights(ccfg.weight_shapes(), ccfg.hidden_size, seed=31, mode="test")
+    dw = weightgen.make_dit_weights(dcfg.weight_shapes(), dcfg.hidden_size, seed=32, mode="test")
+    null = weightgen.make_null_condition_emb(dcfg.hidden_size, seed=32)
+    g = torch.Generator().manual_seed(33)
+    B, Lt, Ll, Tref, T = 1, 12, 40, 30, 60
+    text, lyric, refer = torch.randn(B, Lt, 64, generator=g), torch.randn(B, Ll, 64, generator=g), torch.randn(1, Tref, 64, generator=g)
+    tmask = (torch.arange(Lt)[None, :] < 9).long()
+    lmask = (torch.arange(Ll)[None, :] < 25).long()
+    order = torch.tensor([0])
+    ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1)
+    kw = dict(seed=[77], infer_steps=6, diffusion_guidance_sale=7.0)
+    # oracle chain
+    o_enc, o_mask = o_cond.condition_encoder(o_cond.CondConfig(**tiny, text_hidden_dim=64, timbre_hidden_dim=64, num_lyric_encoder_hidden_layers=2,
+                                                               num_timbre_encoder_hidden_layers=2), cw, text, tmask, lyric, lmask, refer, order)
+    o_lat = o_sampler.generate_audio(o_dit.DitConfig(**tiny, num_hidden_layers=2), dw, null, o_enc, ctx, **kw)
+    # native chain
+    enc = NativeCondEncoder(ccfg, gpu_device)
+    enc.load_state_dict(cw)
+    n_enc, n_mask = enc(text, tmask, lyric, lmask, refer, order)
+    assert torch.equal(n_mask.cpu(), o_mask)
+    dit = NativeDit(dcfg, gpu_device)
+    dit.load_state_dict(dw)
+    n_lat = generate_latents(dit, null, n_enc, ctx, **kw)["target_latents"]
+    r = _rel(n_lat.cpu(), o_lat)
+    assert r < 6e-2, r   # same gate as the tiny sampler golden test
+    vcfg = ace355.VaeConfig()
+    vw = weightgen.make_vae_weights(vcfg.weight_shapes(), seed=34, mode="init")
+    vae = NativeVae(vcfg, gpu_device)
+    vae.load_state_dict(vw)
+    wav = vae.decode(n_lat[:, :24].transpose(1, 2).contiguous()).cpu()
+    wref = o_vae.decode(o_vae.VaeConfig(), vw, o_lat[:, :24].transpose(1, 2).contiguous())
+    snr = float(10 * torch.log10(wref.pow(2).sum() / (wav - wref).pow(2).sum()))
+    assert snr > 20.0, snr

@@ -150,6 +150,28 @@ class NativeVaeMixin:
             raise RuntimeError("native VAE backend is not initialised (call _init_native_vae)")
         return self.native_vae.decode(latents)
 
+    def _native_vae_encode_sample(self, audio: torch.Tensor) -> torch.Tensor:
+        """``audio [B,2,L]`` -> sampled latents fp32 ``[B,64,T]`` (counterpart of ``_mlx_vae_encode_sample``,
+        handler/vae_encode.py:33: whole-sequence encode; the 30 s / 2 s-overlap tiling is a memory workaround)."""
+        if self.native_vae is None or not getattr(self.native_vae, "has_encoder", False):
+            raise RuntimeError("native VAE encoder is not initialised (encoder.* weights missing)")
+        return self.native_vae.encode(audio)
+
+    def tiled_encode(self, audio, chunk_size=None, overlap=None, offload_latent_to_cpu=True):
+        """Same signature as handler/vae_encode.py:15-86.  Native fast path first; on failure the host's PyTorch
+        implementation (``VaeEncodeMixin.tiled_encode`` further up the MRO) runs, exactly like the MLX seam (:28-45)."""
+        if self.use_native_vae and self.native_vae is not None and getattr(self.native_vae, "has_encoder", False):
+            input_was_2d = audio.dim() == 2
+            try:
+                result = self._native_vae_encode_sample(audio.unsqueeze(0) if input_was_2d else audio)
+                return result.squeeze(0) if input_was_2d else result
+            except Exception as exc:
+                logger.warning("[tiled_encode] native VAE encode failed (%s: %s)", type(exc).__name__, exc)
+        parent = getattr(super(), "tiled_encode", None)
+        if parent is None:
+            raise RuntimeError("no VAE encode backend available")
+        return parent(audio, chunk_size=chunk_size, overlap=overlap, offload_latent_to_cpu=offload_latent_to_cpu)
+
     def tiled_decode(self, latents, chunk_size: Optional[int] = None, overlap: int = 64, offload_wav_to_cpu: Optional[bool] = None):
         """Same signature as handler/vae_decode.py:16-85.  Native fast path first (whole-sequence decode, which equals
         the overlap-discard tiling up to fp summation order); on failure the host's PyTorch

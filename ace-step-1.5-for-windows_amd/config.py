@@ -265,3 +265,41 @@ class VaeConfig:
         snk("decoder.snake1", self.decoder_channels)
         conv("decoder.conv2", self.audio_channels, self.decoder_channels, 7, bias=False)
         return sh
+
+    @property
+    def encoder_hidden_size(self) -> int:
+        return 2 * self.decoder_input_channels  # mean | scale
+
+    def encoder_block_dims(self) -> List[Tuple[int, int, int]]:
+        cm = [1] + list(self.channel_multiples)
+        e = self.encoder_hidden_size
+        return [(e * cm[i], e * cm[i + 1], s) for i, s in enumerate(self.downsampling_ratios)]
+
+    def encoder_weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """state_dict names/shapes of the encoder half (acestep/models/mlx/vae_model.py:92-116, 148-187)."""
+        sh: Dict[str, Tuple[int, ...]] = {}
+
+        def conv(name, cout, cin, k):
+            sh[name + ".weight_g"] = (cout, 1, 1)
+            sh[name + ".weight_v"] = (cout, cin, k)
+            sh[name + ".bias"] = (cout,)
+
+        def snk(name, c):
+            sh[name + ".alpha"] = (1, c, 1)
+            sh[name + ".beta"] = (1, c, 1)
+
+        conv("encoder.conv1", self.encoder_hidden_size, self.audio_channels, 7)
+        dims = self.encoder_block_dims()
+        for i, (cin, cout, s) in enumerate(dims):
+            p = f"encoder.block.{i}"
+            for j in (1, 2, 3):
+                r = f"{p}.res_unit{j}"
+                snk(r + ".snake1", cin)
+                conv(r + ".conv1", cin, cin, 7)
+                snk(r + ".snake2", cin)
+                conv(r + ".conv2", cin, cin, 1)
+            snk(p + ".snake1", cin)
+            conv(p + ".conv1", cout, cin, 2 * s)
+        snk("encoder.snake1", dims[-1][1])
+        conv("encoder.conv2", self.encoder_hidden_size, dims[-1][1], 3)
+        return sh

@@ -170,6 +170,9 @@ int launch_pack(const void* src, int src_dtype, void* dst, int dst_is_bf16, int 
 
 struct ConvArgs {
     const bf16_t* x; long x_batch_stride; int L_in; int Cin;   // x[b][l][ci] NLC bf16
+    // strided (down-sampling) conv as a 2-tap conv over the view x'[r][c'] = x_flat[r*Cin + c' + x_shift], Cin = stride*C:
+    // an element is read iff 0 <= flat < x_valid (x_valid == 0: plain conv, rows outside [0, L_in) are zero)
+    long x_shift; long x_valid;
     const bf16_t* w;                                             // w[n][tap][ci]
     const float* bias;                                           // [N] or null
     const float* alpha; const float* beta;                       // snake params [Cin] (log scale) or null

@@ -80,8 +80,10 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             const int wr = c >> 3;
             const int xr = x_row0 + wr;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (xr >= 0 && xr < a.L_in) {
-                v = *reinterpret_cast<const uint4*>(xb + (long)xr * Cin + ci0 + sslot * 8);
+            const long flat = (long)xr * Cin + ci0 + sslot * 8 + a.x_shift;
+            const bool inside = a.x_valid ? (flat >= 0 && flat < a.x_valid) : (xr >= 0 && xr < a.L_in);
+            if (inside) {
+                v = *reinterpret_cast<const uint4*>(xb + flat);
                 if (snake) {
                     uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
 #pragma unroll
@@ -226,6 +228,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     ACE_CHECK(a.Cin % 64 == 0, "conv: Cin must be a multiple of 64");
     ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil + 128 <= WIN_MAX && a.dil >= 1, "conv: window too large");
     ACE_CHECK(a.B > 0 && a.M > 0 && a.N > 0, "conv: empty problem");
+    ACE_CHECK(a.x_valid ? (a.x_shift % 8 == 0 && a.x_valid % 8 == 0) : a.x_shift == 0, "conv: x_shift / x_valid must be multiples of 8 (and x_shift needs x_valid)");
     ConvArgs aw = a;
     {
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

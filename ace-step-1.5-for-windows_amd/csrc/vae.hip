@@ -1,5 +1,6 @@
-// vae.hip - the Oobleck decoder handle behind ace355.h: weight-norm fusion + packing at load time, whole-sequence
-// decode as a chain of conv_kernel launches (conv.hip).  Architecture per acestep/models/mlx/vae_model.py:190-230.
+// vae.hip - the Oobleck VAE handle behind ace355.h: weight-norm fusion + packing at load time, whole-sequence decode
+// (architecture per acestep/models/mlx/vae_model.py:190-230) and - SURVEY.md section 8f row N3 - whole-sequence encode
+// (vae_model.py:92-116, 148-187, 285-310) as chains of conv_kernel launches (conv.hip).
 #include <math.h>
 #include <string.h>
 
@@ -34,6 +35,12 @@ struct BlockW {
     ConvW ct;
     int stride = 1, pad = 0, cin = 0, cout = 0;
     ResUnitW ru[3];
+};
+struct EncBlockW {
+    ResUnitW ru[3];
+    SnakeP s1;       // tiled `stride` times (virtual channel c' -> channel c' % cin)
+    ConvW cd;        // strided conv as 2 taps over stride*cin virtual channels
+    int stride = 1, pad = 0, cin = 0, cout = 0;
 };
 struct RawT {
     float* p = nullptr;
@@ -78,6 +85,66 @@ __global__ void pack_convt_kernel(const float* __restrict__ v, const float* __re
     const int r = k % s, tap = k >= s ? 0 : 1;
     w[(((long)r * Cout + co) * 2 + tap) * Cin + ci] = f2bf(x);
 }
+// strided Conv1d weight_v [Cout][C][2s] (+g, norm) -> w[co][g][s' * C + ci] with k = g*s + s'  (2 taps over s*C virtual channels)
+__global__ void pack_conv_strided_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ nrm,
+                                         bf16_t* __restrict__ w, int Cout, int C, int s) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = 2 * s;
+    if (i >= (long)Cout * C * K) return;
+    const int k = (int)(i % K);
+    const long t = i / K;
+    const int ci = (int)(t % C), co = (int)(t / C);
+    float x = v[i];
+    if (g) x = g[co] * x / (nrm[co] + 1e-9f);
+    const int gg = k / s, sp = k % s;
+    w[((long)co * 2 + gg) * ((long)s * C) + (long)sp * C + ci] = f2bf(x);
+}
+// first encoder conv (Cin = audio channels, k = 7) as a 1-tap conv over 64 virtual channels: w'[co][k*A + c] = w[co][c][k]
+__global__ void pack_conv_im2col_kernel(const float* __restrict__ v, const float* __restrict__ g, const float* __restrict__ nrm,
+                                        bf16_t* __restrict__ w, int Cout, int A, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Cout * 64) return;
+    const int cc = (int)(i % 64), co = (int)(i / 64);
+    float x = 0.f;
+    if (cc < K * A) {
+        const int k = cc / A, c = cc % A;
+        x = v[((long)co * A + c) * K + k];
+        if (g) x = g[co] * x / (nrm[co] + 1e-9f);
+    }
+    w[i] = f2bf(x);
+}
+// audio f32 [B][A][L] -> x'[b][l][k*A + c] = audio[b][c][l + k - K/2] (zero outside), 64 bf16 per row
+__global__ void audio_im2col_kernel(const float* __restrict__ audio, bf16_t* __restrict__ out, int A, long L, int K, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cc = (int)(i % 64);
+    const long bl = i / 64;
+    const long l = bl % L, b = bl / L;
+    float x = 0.f;
+    if (cc < K * A) {
+        const int k = cc / A, c = cc % A;
+        const long src = l + k - K / 2;
+        if (src >= 0 && src < L) x = audio[(b * A + c) * L + src];
+    }
+    out[i] = f2bf(x);
+}
+// OobleckDiagonalGaussianDistribution: h f32 [B][2*Z][T] -> z[b][c][t] = mean + (softplus(scale) + 1e-4) * noise (noise null: mean)
+__global__ void gaussian_head_kernel(const float* __restrict__ h, const float* __restrict__ noise, float* __restrict__ z, int Z, long T,
+                                     long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long t = i % T;
+    const long bc = i / T;
+    const long c = bc % Z, b = bc / Z;
+    const float mean = h[(b * 2 * Z + c) * T + t];
+    float out = mean;
+    if (noise) {
+        const float sc = h[(b * 2 * Z + Z + c) * T + t];
+        const float sp = sc > 20.f ? sc : log1pf(expf(sc));
+        out = mean + (sp + 1e-4f) * noise[i];
+    }
+    z[i] = out;
+}
 __global__ void snake_prep_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ ea,
                                   float* __restrict__ ib, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -106,6 +173,15 @@ struct ace355_vae {
     SnakeP s_out;
     std::vector<BlockW> blocks;
     bool finalized = false;
+    // encoder (optional: present when encoder.* tensors were loaded)
+    bool has_encoder = false;
+    ConvW e_conv1, e_conv2;
+    SnakeP e_s_out;
+    std::vector<EncBlockW> e_blocks;
+    bf16_t* ain = nullptr;      // im2col'ed audio [B][L][64]
+    size_t ain_elems = 0;
+    float* e_head = nullptr;    // conv2 output f32 [B][2Z][T]
+    size_t e_head_elems = 0;
     // activations
     bf16_t* buf[3] = {nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
@@ -208,6 +284,80 @@ int build_snake(ace355_vae* h, const std::string& base, int C, SnakeP* sp) {
     return 0;
 }
 
+int build_conv_strided(ace355_vae* h, const std::string& base, int Cout, int C, int s, ConvW* c) {
+    const RawT *v = nullptr, *g = nullptr, *b = nullptr;
+    int rc;
+    const int K = 2 * s;
+    const bool fused = find(h, base + ".weight") != nullptr;
+    if (fused) {
+        if ((rc = need(h, base + ".weight", (long)Cout * C * K, &v))) return rc;
+    } else {
+        if ((rc = need(h, base + ".weight_v", (long)Cout * C * K, &v))) return rc;
+        if ((rc = need(h, base + ".weight_g", Cout, &g))) return rc;
+    }
+    if ((rc = need(h, base + ".bias", Cout, &b))) return rc;
+    c->N = Cout; c->taps = 2; c->Cin = s * C;
+    if ((rc = valloc(h, &c->w, (size_t)Cout * C * K))) return rc;
+    float* nrm = nullptr;
+    if (g) {
+        if ((rc = valloc(h, &nrm, (size_t)Cout))) return rc;
+        hipLaunchKernelGGL(rownorm_kernel, dim3((Cout + 3) / 4), dim3(256), 0, 0, v->p, (long)C * K, nrm, Cout);
+    }
+    const long n = (long)Cout * C * K;
+    hipLaunchKernelGGL(pack_conv_strided_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v->p, g ? g->p : nullptr, nrm, c->w, Cout, C, s);
+    c->bias = b->p;
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int build_conv_im2col(ace355_vae* h, const std::string& base, int Cout, int A, int K, ConvW* c) {
+    const RawT *v = nullptr, *g = nullptr, *b = nullptr;
+    int rc;
+    ACE_CHECK(A * K <= 64, "vae_finalize: audio_channels * 7 must fit 64 virtual channels");
+    const bool fused = find(h, base + ".weight") != nullptr;
+    if (fused) {
+        if ((rc = need(h, base + ".weight", (long)Cout * A * K, &v))) return rc;
+    } else {
+        if ((rc = need(h, base + ".weight_v", (long)Cout * A * K, &v))) return rc;
+        if ((rc = need(h, base + ".weight_g", Cout, &g))) return rc;
+    }
+    if ((rc = need(h, base + ".bias", Cout, &b))) return rc;
+    c->N = Cout; c->taps = 1; c->Cin = 64;
+    if ((rc = valloc(h, &c->w, (size_t)Cout * 64))) return rc;
+    float* nrm = nullptr;
+    if (g) {
+        if ((rc = valloc(h, &nrm, (size_t)Cout))) return rc;
+        hipLaunchKernelGGL(rownorm_kernel, dim3((Cout + 3) / 4), dim3(256), 0, 0, v->p, (long)A * K, nrm, Cout);
+    }
+    const long n = (long)Cout * 64;
+    hipLaunchKernelGGL(pack_conv_im2col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v->p, g ? g->p : nullptr, nrm, c->w, Cout, A, K);
+    c->bias = b->p;
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+// Snake parameters repeated `reps` times (the strided conv's virtual channels)
+int build_snake_tiled(ace355_vae* h, const std::string& base, int C, int reps, SnakeP* sp) {
+    SnakeP one;
+    int rc = build_snake(h, base, C, &one);
+    if (rc) return rc;
+    if ((rc = valloc(h, &sp->ea, (size_t)C * reps))) return rc;
+    if ((rc = valloc(h, &sp->ib, (size_t)C * reps))) return rc;
+    hipLaunchKernelGGL(tile_bias_kernel, dim3((C * reps + 255) / 256), dim3(256), 0, 0, one.ea, sp->ea, C, reps);
+    hipLaunchKernelGGL(tile_bias_kernel, dim3((C * reps + 255) / 256), dim3(256), 0, 0, one.ib, sp->ib, C, reps);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int build_res_unit(ace355_vae* h, const std::string& r, int C, int dil, ResUnitW* R) {
+    int rc;
+    R->dil = dil;
+    if ((rc = build_snake(h, r + ".snake1", C, &R->s1))) return rc;
+    if ((rc = build_conv(h, r + ".conv1", C, C, 7, true, &R->c1))) return rc;
+    if ((rc = build_snake(h, r + ".snake2", C, &R->s2))) return rc;
+    return build_conv(h, r + ".conv2", C, C, 1, true, &R->c2);
+}
+
 int run_conv(ace355_vae* h, const ConvArgs& a, hipStream_t s) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profile) {
@@ -251,6 +401,8 @@ void ace355_vae_destroy(ace355_vae* h) {
     for (void* p : h->allocs) hipFree(p);
     for (int i = 0; i < 3; ++i) if (h->buf[i]) hipFree(h->buf[i]);
     if (h->zin) hipFree(h->zin);
+    if (h->ain) hipFree(h->ain);
+    if (h->e_head) hipFree(h->e_head);
     if (h->scratch) hipFree(h->scratch);
     for (auto& e : h->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
@@ -260,7 +412,10 @@ int ace355_vae_load_tensor(ace355_vae* h, const char* name, const void* data, in
     ACE_CHECK(h && name && data && numel > 0, "vae_load_tensor: null/empty argument");
     ACE_CHECK(dtype == ACE355_DTYPE_F32 || dtype == ACE355_DTYPE_BF16, "vae_load_tensor: dtype");
     const std::string key(name);
-    if (key.rfind("decoder.", 0) != 0) { set_error("vae_load_tensor: unknown tensor name '" + key + "' (decoder.* expected)"); return ACE355_ERR_INVALID; }
+    if (key.rfind("decoder.", 0) != 0 && key.rfind("encoder.", 0) != 0) {
+        set_error("vae_load_tensor: unknown tensor name '" + key + "' (decoder.* / encoder.* expected)");
+        return ACE355_ERR_INVALID;
+    }
     RawT& r = h->raw[key];
     if (r.p) { hipFree(r.p); r.p = nullptr; }
     ACE_HIP(hipMalloc((void**)&r.p, (size_t)numel * 4 + 256));
@@ -313,6 +468,31 @@ int ace355_vae_finalize(ace355_vae* h) {
     }
     if ((rc = build_snake(h, "decoder.snake1", c.decoder_channels, &h->s_out))) return rc;
     if ((rc = build_conv(h, "decoder.conv2", c.audio_channels, c.decoder_channels, 7, false, &h->conv2))) return rc;
+    // encoder half (optional): vae_model.py:148-187.  encoder_hidden_size = 2 * latent channels (mean | scale)
+    h->has_encoder = false;
+    for (auto& kv : h->raw) if (kv.first.rfind("encoder.", 0) == 0) { h->has_encoder = true; break; }
+    if (h->has_encoder) {
+        const int EH = 2 * c.decoder_input_channels;
+        ACE_CHECK(EH % 64 == 0, "vae_finalize: encoder width must be a multiple of 64");
+        if ((rc = build_conv_im2col(h, "encoder.conv1", EH, c.audio_channels, 7, &h->e_conv1))) return rc;
+        h->e_blocks.assign(nb, EncBlockW());
+        for (int i = 0; i < nb; ++i) {
+            EncBlockW& B = h->e_blocks[i];
+            B.cin = EH * cm[i];
+            B.cout = EH * cm[i + 1];
+            B.stride = c.upsampling_ratios[nb - 1 - i];  // downsampling_ratios = reversed upsampling_ratios
+            B.pad = (B.stride + 1) / 2;
+            ACE_CHECK(B.cin % 64 == 0 && B.cout % 64 == 0, "vae_finalize: encoder block channels must be multiples of 64");
+            const std::string p = "encoder.block." + std::to_string(i);
+            const int dils[3] = {1, 3, 9};
+            for (int j = 0; j < 3; ++j)
+                if ((rc = build_res_unit(h, p + ".res_unit" + std::to_string(j + 1), B.cin, dils[j], &B.ru[j]))) return rc;
+            if ((rc = build_snake_tiled(h, p + ".snake1", B.cin, B.stride, &B.s1))) return rc;
+            if ((rc = build_conv_strided(h, p + ".conv1", B.cout, B.cin, B.stride, &B.cd))) return rc;
+        }
+        if ((rc = build_snake(h, "encoder.snake1", EH * cm[nb], &h->e_s_out))) return rc;
+        if ((rc = build_conv(h, "encoder.conv2", EH, EH * cm[nb], 3, true, &h->e_conv2))) return rc;
+    }
     ACE_HIP(hipDeviceSynchronize());
     // raw weight_v / weight_g copies are no longer needed (biases are still referenced)
     for (auto& kv : h->raw) {
@@ -415,6 +595,121 @@ int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wa
     a.B = B; a.M = (int)L; a.N = c.audio_channels; a.taps = 7; a.dil = 1; a.center = 3;
     a.out_mode = 1; a.n_real = c.audio_channels;
     return run_conv(h, a, s);
+}
+
+// Residual unit in place on `state` (scratch `tmp`), shared by decode and encode: x + conv_k1(snake2(conv_k7_dil(snake1(x))))
+static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t* state, bf16_t* tmp, int B, long L, int C, hipStream_t s) {
+    ConvArgs a{};
+    a.x = state; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
+    a.w = R.c1.w; a.bias = R.c1.bias; a.alpha = R.s1.ea; a.beta = R.s1.ib;
+    a.y = tmp; a.y_batch_stride = L * C;
+    a.B = B; a.M = (int)L; a.N = C; a.taps = 7; a.dil = R.dil; a.center = 3;
+    a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
+    int rc = run_conv(h, a, s);
+    if (rc) return rc;
+    a = ConvArgs{};
+    a.x = tmp; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
+    a.w = R.c2.w; a.bias = R.c2.bias; a.alpha = R.s2.ea; a.beta = R.s2.ib;
+    a.res = state; a.res_batch_stride = L * C;
+    a.y = state; a.y_batch_stride = L * C;
+    a.B = B; a.M = (int)L; a.N = C; a.taps = 1; a.dil = 1; a.center = 0;
+    a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
+    return run_conv(h, a, s);
+}
+
+int ace355_vae_encode(ace355_vae* h, const float* audio_dev, const float* noise_dev, int B, int64_t L, float* latents_out_dev,
+                      void* stream) {
+    ACE_CHECK(h && audio_dev && latents_out_dev, "vae_encode: null argument");
+    if (!h->finalized) { set_error("vae_encode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
+    if (!h->has_encoder) { set_error("vae_encode: no encoder.* tensors were loaded"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && L > 0 && L < (1L << 30), "vae_encode: sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const ace355_vae_config& c = h->cfg;
+    const int EH = 2 * c.decoder_input_channels, Z = c.decoder_input_channels;
+    // stage lengths: Conv1d(k = 2s, stride s, pad ceil(s/2)): L_out = floor((L + 2 pad - 2 s) / s) + 1
+    long T = L;
+    for (const EncBlockW& Bk : h->e_blocks) {
+        T = (T + 2 * Bk.pad - 2 * Bk.stride) / Bk.stride + 1;
+        ACE_CHECK(T > 0, "vae_encode: audio shorter than one latent frame");
+    }
+    const size_t need_elems = (size_t)B * L * EH;
+    if (need_elems > h->buf_elems) {
+        ACE_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < 3; ++i) {
+            if (h->buf[i]) hipFree(h->buf[i]);
+            h->buf[i] = nullptr;
+            ACE_HIP(hipMalloc((void**)&h->buf[i], need_elems * 2 + 256));
+        }
+        h->buf_elems = need_elems;
+    }
+    const size_t ael = (size_t)B * L * 64;
+    if (ael > h->ain_elems) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->ain) hipFree(h->ain);
+        ACE_HIP(hipMalloc((void**)&h->ain, ael * 2 + 256));
+        h->ain_elems = ael;
+    }
+    const size_t hel = (size_t)B * EH * T;
+    if (hel > h->e_head_elems) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->e_head) hipFree(h->e_head);
+        ACE_HIP(hipMalloc((void**)&h->e_head, hel * 4 + 256));
+        h->e_head_elems = hel;
+    }
+    hipLaunchKernelGGL(audio_im2col_kernel, dim3((unsigned)((ael + 255) / 256)), dim3(256), 0, s, audio_dev, h->ain, c.audio_channels, (long)L, 7,
+                       (long)ael);
+    ACE_LAUNCH_CHECK();
+
+    bf16_t *cur = h->buf[0], *nxt = h->buf[1], *tmp = h->buf[2];
+    int rc;
+    ConvArgs a{};
+    // conv1 (k7 over the audio channels, vae_model.py:166) as one tap over the im2col'ed rows
+    a.x = h->ain; a.x_batch_stride = L * 64; a.L_in = (int)L; a.Cin = 64;
+    a.w = h->e_conv1.w; a.bias = h->e_conv1.bias;
+    a.y = cur; a.y_batch_stride = L * EH;
+    a.B = B; a.M = (int)L; a.N = EH; a.taps = 1; a.dil = 1; a.center = 0;
+    a.y_shift = 0; a.y_valid = L * EH; a.out_mode = 0;
+    if ((rc = run_conv(h, a, s))) return rc;
+    long Lc = L;
+    for (const EncBlockW& Bk : h->e_blocks) {
+        for (int j = 0; j < 3; ++j)
+            if ((rc = run_res_unit(h, Bk.ru[j], cur, tmp, B, Lc, Bk.cin, s))) return rc;
+        // snake -> Conv1d(k = 2s, stride s) as 2 taps over the shifted view x'[r][c'] = x_flat[(r*s - pad)*cin + c'] (vae_model.py:113-115)
+        const long Lo = (Lc + 2 * Bk.pad - 2 * Bk.stride) / Bk.stride + 1;
+        a = ConvArgs{};
+        a.x = cur; a.x_batch_stride = Lc * Bk.cin; a.L_in = (int)Lo + 1; a.Cin = Bk.stride * Bk.cin;
+        a.x_shift = -(long)Bk.pad * Bk.cin; a.x_valid = Lc * Bk.cin;
+        a.w = Bk.cd.w; a.bias = Bk.cd.bias; a.alpha = Bk.s1.ea; a.beta = Bk.s1.ib;
+        a.y = nxt; a.y_batch_stride = Lo * Bk.cout;
+        a.B = B; a.M = (int)Lo; a.N = Bk.cout; a.taps = 2; a.dil = 1; a.center = 0;
+        a.y_shift = 0; a.y_valid = Lo * Bk.cout; a.out_mode = 0;
+        if ((rc = run_conv(h, a, s))) return rc;
+        std::swap(cur, nxt);
+        Lc = Lo;
+    }
+    // snake -> conv k3 -> f32 [B][2Z][T] (vae_model.py:185-186), then the diagonal Gaussian head (:296-302)
+    const int Cl = h->e_conv2.Cin;
+    a = ConvArgs{};
+    a.x = cur; a.x_batch_stride = Lc * Cl; a.L_in = (int)Lc; a.Cin = Cl;
+    a.w = h->e_conv2.w; a.bias = h->e_conv2.bias; a.alpha = h->e_s_out.ea; a.beta = h->e_s_out.ib;
+    a.y = h->e_head; a.y_batch_stride = (long)EH * Lc;
+    a.B = B; a.M = (int)Lc; a.N = EH; a.taps = 3; a.dil = 1; a.center = 1;
+    a.out_mode = 1; a.n_real = EH;
+    if ((rc = run_conv(h, a, s))) return rc;
+    const long total = (long)B * Z * Lc;
+    hipLaunchKernelGGL(gaussian_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h->e_head, noise_dev, latents_out_dev, Z, Lc, total);
+    ACE_LAUNCH_CHECK();
+    return ACE355_OK;
+}
+
+int ace355_vae_latent_frames(const ace355_vae* h, int64_t L) {
+    if (!h || !h->finalized || !h->has_encoder || L <= 0) return -1;
+    long T = L;
+    for (const EncBlockW& Bk : h->e_blocks) {
+        T = (T + 2 * Bk.pad - 2 * Bk.stride) / Bk.stride + 1;
+        if (T <= 0) return -1;
+    }
+    return (int)T;
 }
 
 int ace355_vae_set_profile(ace355_vae* h, int enable) {

@@ -85,6 +85,8 @@ SIGNATURES = {
     "ace355_vae_finalize": (C.c_int, [C.c_void_p]),
     "ace355_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_vae_hop": (C.c_int, [C.c_void_p]),
+    "ace355_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ace355_vae_latent_frames": (C.c_int, [C.c_void_p, C.c_int64]),
     "ace355_vae_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_vae_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ace355_cond_create": (C.c_int, [C.POINTER(CondConfigC), C.POINTER(C.c_void_p)]),

@@ -1,4 +1,4 @@
-"""NativeVae: Python owner of an ``ace355_vae`` handle (Oobleck decoder, latent -> waveform).
+"""NativeVae: Python owner of an ``ace355_vae`` handle (Oobleck decoder, latent -> waveform; encoder, waveform -> latent).
 
 Mirror of the reference's MLX VAE seam (handler/mlx_vae_init.py:12-96, mlx_vae_decode_native.py:31-72,
 models/mlx/vae_convert.py): weights come from the loaded ``AutoencoderOobleck.state_dict()``.
@@ -47,10 +47,12 @@ class NativeVae:
         return int(self._lib.ace355_vae_hop(self._h))
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
-        """Decoder-half keys of ``AutoencoderOobleck.state_dict()``; encoder keys are ignored."""
+        """Keys of ``AutoencoderOobleck.state_dict()``: the decoder half is required, the encoder half optional
+        (``encode`` needs it)."""
+        self.has_encoder = any(k.startswith("encoder.") for k in sd)
         with torch.cuda.device(self.device):
             for name, t in sd.items():
-                if not name.startswith("decoder."):
+                if not (name.startswith("decoder.") or name.startswith("encoder.")):
                     continue
                 t = t.detach()
                 if t.dtype not in (torch.float32, torch.bfloat16):
@@ -71,6 +73,31 @@ class NativeVae:
         with torch.cuda.device(self.device):
             native.check(self._lib.ace355_vae_decode(self._h, native.ptr(z), B, T, native.ptr(out), native.current_stream_ptr()),
                          "vae_decode")
+        return out
+
+    def encode(self, audio: torch.Tensor, noise: torch.Tensor = None, generator: torch.Generator = None, sample: bool = True) -> torch.Tensor:
+        """audio [B, 2, L] -> latents fp32 [B, 64, T] = ``vae.encode(audio).latent_dist.sample()`` (handler/vae_encode.py:66).
+
+        ``noise`` [B, 64, T] makes the draw reproducible (parity tests); otherwise it is drawn here with ``generator``;
+        ``sample=False`` returns the mean (``latent_dist.mode()``)."""
+        B, Cc, L = audio.shape
+        if Cc != self.cfg.audio_channels:
+            raise ValueError(f"ace355: expected {self.cfg.audio_channels} audio channels, got {Cc}")
+        T = int(self._lib.ace355_vae_latent_frames(self._h, L))
+        if T <= 0:
+            raise RuntimeError("ace355: the VAE encoder is not available (encoder.* weights not loaded) or the audio is too short")
+        audio = audio.detach().to(self.device, torch.float32).contiguous()
+        Z = self.cfg.decoder_input_channels
+        if sample and noise is None:
+            noise = torch.randn(B, Z, T, device=self.device, dtype=torch.float32, generator=generator)
+        if noise is not None:
+            if tuple(noise.shape) != (B, Z, T):
+                raise ValueError(f"ace355: noise must be [{B}, {Z}, {T}]")
+            noise = noise.detach().to(self.device, torch.float32).contiguous()
+        out = torch.empty(B, Z, T, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_vae_encode(self._h, native.ptr(audio), native.ptr(noise) if sample else 0, B, L, native.ptr(out),
+                                                     native.current_stream_ptr()), "vae_encode")
         return out
 
     def set_profile(self, enable: bool) -> None:

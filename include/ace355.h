@@ -156,6 +156,14 @@ int ace355_vae_finalize(ace355_vae* h);
  * overlap-discard tiling away from fp summation order. */
 int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream);
 int ace355_vae_hop(const ace355_vae* h);
+/* Encoder half (vae_model.py:92-116, 148-187, 285-310): available when the encoder.* keys of
+ * AutoencoderOobleck.state_dict() were loaded before ace355_vae_finalize.  audio dev f32 [B, audio_channels, L];
+ * latents_out dev f32 [B, 64, T] with T = ace355_vae_latent_frames(h, L) (= L / hop for multiples of the hop);
+ * noise dev f32 [B, 64, T] -> `latent_dist.sample()` = mean + (softplus(scale) + 1e-4) * noise
+ * (handler/vae_encode.py:66); noise NULL -> the mean (`latent_dist.mode()`). */
+int ace355_vae_encode(ace355_vae* h, const float* audio_dev, const float* noise_dev, int B, int64_t L, float* latents_out_dev,
+                      void* stream);
+int ace355_vae_latent_frames(const ace355_vae* h, int64_t L);
 int ace355_vae_set_profile(ace355_vae* h, int enable);
 int ace355_vae_get_profile(ace355_vae* h, double* conv_ms, double* conv_flops, int64_t* conv_launches);
 

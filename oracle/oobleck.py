@@ -1,4 +1,4 @@
-"""fp32 CPU restatement of the Oobleck VAE *decoder* (latent -> waveform) (test oracle).
+"""fp32 CPU restatement of the Oobleck VAE decoder (latent -> waveform) and encoder (waveform -> latent) (test oracle).
 
 PARITY UNPINNED.  The arithmetic lives in third-party ``diffusers``
 (``diffusers.models.AutoencoderOobleck``; unpinned at
@@ -9,6 +9,8 @@ restatement:
   * acestep/models/mlx/vae_model.py:62-87   OobleckResidualUnit
   * acestep/models/mlx/vae_model.py:119-142 OobleckDecoderBlock
   * acestep/models/mlx/vae_model.py:190-230 OobleckDecoder
+  * acestep/models/mlx/vae_model.py:92-116, 148-187, 285-310  OobleckEncoderBlock / OobleckEncoder / encode_and_sample
+    (same unpinned status)
   * acestep/models/mlx/vae_convert.py:18-34 weight_norm fusion (w = g * v / (||v|| + 1e-9))
 in PyTorch NCL layout with ``F.conv1d`` / ``F.conv_transpose1d``.  Weight names are
 the keys of ``AutoencoderOobleck.state_dict()`` as consumed by vae_convert.py:62-127
@@ -37,6 +39,7 @@ class VaeConfig:
 
     decoder_channels: int = 128
     decoder_input_channels: int = 64
+    encoder_hidden_size: int = 128
     audio_channels: int = 2
     channel_multiples: Tuple[int, ...] = (1, 2, 4, 8, 16)
     downsampling_ratios: Tuple[int, ...] = (2, 4, 4, 6, 10)
@@ -55,6 +58,12 @@ class VaeConfig:
         s = self.upsampling_ratios
         n = len(s)
         return [(self.decoder_channels * cm[n - i], self.decoder_channels * cm[n - i - 1], s[i]) for i in range(n)]
+
+
+    def encoder_block_dims(self) -> List[Tuple[int, int, int]]:
+        """(in_ch, out_ch, stride) per encoder block, vae_model.py:171-179."""
+        cm = [1] + list(self.channel_multiples)
+        return [(self.encoder_hidden_size * cm[i], self.encoder_hidden_size * cm[i + 1], s) for i, s in enumerate(self.downsampling_ratios)]
 
 
 def fuse_weight_norm(g: Tensor, v: Tensor, eps: float = 1e-9) -> Tensor:
@@ -148,4 +157,61 @@ def decoder_weight_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
             conv(r + ".conv2", cout, cout, 1)
     snk("decoder.snake1", cfg.decoder_channels)
     conv("decoder.conv2", cfg.audio_channels, cfg.decoder_channels, 7, bias=False)
+    return shapes
+
+
+def encoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int, q=_ident) -> Tensor:
+    """vae_model.py:92-116: res units d=1,3,9 -> snake -> Conv1d(k=2s, stride=s, pad=ceil(s/2))."""
+    x = residual_unit(w, p + ".res_unit1", x, 1, q)
+    x = residual_unit(w, p + ".res_unit2", x, 3, q)
+    x = residual_unit(w, p + ".res_unit3", x, 9, q)
+    x = q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"]))
+    return q(F.conv1d(x, q(_w(w, p + ".conv1")), w[p + ".conv1.bias"], stride=stride, padding=math.ceil(stride / 2)))
+
+
+def encode_moments(cfg: VaeConfig, w: Dict[str, Tensor], audio: Tensor, emulate_bf16: bool = False) -> Tuple[Tensor, Tensor]:
+    """vae_model.py:148-187 + :296-302: audio [B,2,L] -> (mean, std), each [B, 64, L // hop]; std = softplus(scale) + 1e-4."""
+    q = _bf16 if emulate_bf16 else _ident
+    x = q(F.conv1d(q(audio), q(_w(w, "encoder.conv1")), w["encoder.conv1.bias"], padding=3))
+    for i, (_cin, _cout, s) in enumerate(cfg.encoder_block_dims()):
+        x = encoder_block(w, f"encoder.block.{i}", x, s, q)
+    x = q(snake(x, w["encoder.snake1.alpha"], w["encoder.snake1.beta"]))
+    h = F.conv1d(x, q(_w(w, "encoder.conv2")), w["encoder.conv2.bias"], padding=1)
+    mean, scale = h.chunk(2, dim=1)
+    return mean, F.softplus(scale) + 1e-4
+
+
+def encode(cfg: VaeConfig, w: Dict[str, Tensor], audio: Tensor, noise: Tensor = None, emulate_bf16: bool = False) -> Tensor:
+    """``vae.encode(audio).latent_dist.sample()`` (handler/vae_encode.py:66): mean + std * noise (noise None -> the mean)."""
+    mean, std = encode_moments(cfg, w, audio, emulate_bf16)
+    return mean if noise is None else mean + std * noise
+
+
+def encoder_weight_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
+    """state_dict names/shapes of the encoder half (weight-normed: weight_g / weight_v / bias)."""
+    shapes: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(name, cout, cin, k):
+        shapes[name + ".weight_g"] = (cout, 1, 1)
+        shapes[name + ".weight_v"] = (cout, cin, k)
+        shapes[name + ".bias"] = (cout,)
+
+    def snk(name, c):
+        shapes[name + ".alpha"] = (1, c, 1)
+        shapes[name + ".beta"] = (1, c, 1)
+
+    conv("encoder.conv1", cfg.encoder_hidden_size, cfg.audio_channels, 7)
+    dims = cfg.encoder_block_dims()
+    for i, (cin, cout, s) in enumerate(dims):
+        p = f"encoder.block.{i}"
+        for j in (1, 2, 3):
+            r = f"{p}.res_unit{j}"
+            snk(r + ".snake1", cin)
+            conv(r + ".conv1", cin, cin, 7)
+            snk(r + ".snake2", cin)
+            conv(r + ".conv2", cin, cin, 1)
+        snk(p + ".snake1", cin)
+        conv(p + ".conv1", cout, cin, 2 * s)
+    snk("encoder.snake1", dims[-1][1])
+    conv("encoder.conv2", cfg.encoder_hidden_size, dims[-1][1], 3)
     return shapes

@@ -28,6 +28,10 @@ def test_oracle_and_product_agree_on_names():
     from oracle import oobleck as o_vae
     assert ace355.DitConfig().weight_shapes() == o_dit.dit_weight_shapes(o_dit.DitConfig())
     assert ace355.VaeConfig().weight_shapes() == o_vae.decoder_weight_shapes(o_vae.VaeConfig())
+    assert ace355.VaeConfig().encoder_weight_shapes() == o_vae.encoder_weight_shapes(o_vae.VaeConfig())
+    from oracle import cond as o_cond, detok as o_detok
+    assert ace355.CondConfig().weight_shapes() == o_cond.cond_weight_shapes(o_cond.CondConfig())
+    assert ace355.DetokConfig().weight_shapes() == o_detok.detok_weight_shapes(o_detok.DetokConfig())
 
 
 def test_weightgen_is_deterministic_and_per_tensor():
@@ -126,6 +130,32 @@ def test_tiled_decode_native_first_then_pytorch_fallback():
     assert out.shape == (1, 2, 10) and h.calls[-1] == (128, 16, False)
     h.native_vae = type("V", (), {"decode": lambda self, z: torch.full((1, 2, 7), 3.0)})()
     assert float(h.tiled_decode(torch.zeros(1, 64, 5)).mean()) == 3.0 and len(h.calls) == 2
+
+
+def test_tiled_encode_native_first_then_pytorch_fallback():
+    """handler/vae_encode.py:28-45 seam: native encode when the encoder half is loaded, else / on failure the host's own."""
+    from ace355.backend import NativeVaeMixin
+
+    class _Base:
+        def tiled_encode(self, audio, chunk_size=None, overlap=None, offload_latent_to_cpu=True):
+            self.calls.append((chunk_size, overlap, offload_latent_to_cpu))
+            return torch.zeros(audio.shape[0], 64, 3) if audio.dim() == 3 else torch.zeros(64, 3)
+
+    class _Host(NativeVaeMixin, _Base):
+        def __init__(self):
+            self.calls = []
+
+    h = _Host()
+    assert h.tiled_encode(torch.zeros(1, 2, 100)).shape == (1, 64, 3) and h.calls == [(None, None, True)]
+    ok = type("V", (), {"has_encoder": True, "encode": lambda self, a: torch.full((a.shape[0], 64, 5), 2.0)})()
+    h.use_native_vae, h.native_vae = True, ok
+    assert float(h.tiled_encode(torch.zeros(2, 2, 100)).mean()) == 2.0 and len(h.calls) == 1
+    assert h.tiled_encode(torch.zeros(2, 100)).shape == (64, 5)          # 2-D input convention of the reference
+    h.native_vae = type("V", (), {"has_encoder": True, "encode": lambda self, a: (_ for _ in ()).throw(RuntimeError("boom"))})()
+    assert h.tiled_encode(torch.zeros(1, 2, 100), chunk_size=7).shape == (1, 64, 3) and h.calls[-1] == (7, None, True)
+    h.native_vae = type("V", (), {"has_encoder": False})()
+    h.tiled_encode(torch.zeros(1, 2, 100))
+    assert len(h.calls) == 3
 
 
 def test_generate_music_never_raises_and_returns_reference_payload_shape():

@@ -107,3 +107,46 @@ def test_full_length_decode_properties(gpu_device):
     keep = vae.hop * (500 - 40)  # stay 40 latent frames away from the cut
     err = float((part[:, :, :keep] - w1[:, :, :keep]).abs().max())
     assert err <= 2e-3 * float(w1.abs().max()), err
+
+
+@pytest.mark.parametrize("cfg_kw,B,frames", [
+    (dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6)), 2, 40),
+    (dict(), 1, 12),
+    (dict(), 2, 7),
+])
+def test_encode_vs_oracle(gpu_device, cfg_kw, B, frames):
+    """encoder half (strided convs as 2-tap convs over a shifted view, im2col'ed first conv, Gaussian head)
+    against the (parity-unpinned) oracle restatement: mean, and the sampled latent with the oracle's own noise."""
+    import ace355
+    from ace355 import weightgen
+    from ace355.vae import NativeVae
+    from oracle import oobleck as o_vae
+    cfg = ace355.VaeConfig(**cfg_kw)
+    w = weightgen.make_vae_weights({**cfg.weight_shapes(), **cfg.encoder_weight_shapes()}, seed=2, mode="test")
+    vae = NativeVae(cfg, gpu_device)
+    vae.load_state_dict(w)
+    L = cfg.hop * frames
+    g = torch.Generator().manual_seed(frames)
+    audio = 0.3 * torch.randn(B, 2, L, generator=g)
+    o_cfg = o_vae.VaeConfig(**cfg_kw, encoder_hidden_size=cfg.encoder_hidden_size)
+    mean_ref, std_ref = o_vae.encode_moments(o_cfg, w, audio)
+    mean_emu, _ = o_vae.encode_moments(o_cfg, w, audio, emulate_bf16=True)
+    mean = vae.encode(audio, sample=False)
+    assert mean.shape == (B, 64, frames) == tuple(mean_ref.shape)
+    snr_fp32, snr_emu, drift = _snr_db(mean, mean_ref), _snr_db(mean, mean_emu), _snr_db(mean_emu, mean_ref)
+    print(f"vae encode {cfg_kw or 'full'} B={B} T={frames}: mean SNR vs fp32 oracle {snr_fp32:.1f} dB, vs bf16-storage oracle {snr_emu:.1f} dB "
+          f"(oracle's own bf16 drift {drift:.1f} dB); latent rms {float(mean_ref.pow(2).mean().sqrt()):.3f}")
+    assert snr_fp32 > drift - 6.0, (snr_fp32, drift)
+    assert snr_emu > 30.0, snr_emu
+    noise = torch.randn(B, 64, frames, generator=g)
+    z = vae.encode(audio, noise=noise)
+    z_ref = mean_ref + std_ref * noise
+    assert _snr_db(z, z_ref) > min(snr_fp32, 40.0) - 3.0
+    # round trip through the native decoder keeps the shape contract of the pair
+    assert vae.decode(z).shape == (B, 2, L)
+
+
+def test_encode_requires_encoder_weights(gpu_device):
+    cfg, w, vae = _build(dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6)), gpu_device)
+    with pytest.raises(RuntimeError, match="encoder"):
+        vae.encode(torch.zeros(1, 2, cfg.hop * 4))

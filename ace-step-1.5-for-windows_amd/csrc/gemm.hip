@@ -53,13 +53,7 @@ template <int MODE, int MT, int NTW, bool ROWS_FULL>
 __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane) {
     const int frow = lane & 31, fhalf = lane >> 5;
-    // every wave must be done reading operand fragments before the stages are overwritten by the staging image
-    auto stages_free = [&]() {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-    };
     if constexpr (MODE == 0 || MODE == 3) {
-        stages_free();
         static_assert(MODE != 3 || NTW == 2, "SwiGLU pairs two column tiles per wave");
         constexpr int NJ = (MODE == 3) ? 1 : NTW;   // 32-column groups in the staged image
         constexpr int RB = NJ * 64;                 // staged row bytes
@@ -102,23 +96,6 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         constexpr int NT = MT * 4;  // 8-row groups per 32-column half
         const int rsub = lane >> 3, slot = lane & 7;
         const int rps = ep.rows_per_seq;
-        // fp32 residual update: the old H values of BOTH column halves are requested up front, before the barrier and the
-        // LDS staging, so that the two halves cost one memory round trip instead of two
-        float4 hv[NTW][NT];
-        if constexpr (MODE == 2) {
-            if (ep.ksplit <= 1) {
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    const float* hq = reinterpret_cast<const float*>(Cv) + nw0 + j * 32 + slot * 4;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int m = mw0 + t * 8 + rsub;
-                        hv[j][t] = ldf4(hq + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
-                    }
-                }
-            }
-        }
-        stages_free();
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
 #pragma unroll
@@ -157,6 +134,9 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     gB = {g1.x + b2.x, g1.y + b2.y, g1.z + b2.z, g1.w + b2.w};
                 }
                 if (ep.ksplit > 1) {
+                    // (Requesting the old H values of both column halves before the barrier / staging - one memory round
+                    //  trip instead of two - was tried for the read-modify-write variant below: neutral at M = 6000, and the
+                    //  larger live range slowed THIS path by 25-50 %; reverted.)
                     // split-K: this workgroup holds a partial sum over its K range; gate * partial is added with fp32 atomics
                     // (no workspace, no reduction pass), 64 consecutive-lane floats = two full 128-byte rows per instruction.
                     // The constant term is added by the first K range only.
@@ -185,6 +165,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     }
                     continue;
                 }
+                float4 hv[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int m = mw0 + t * 8 + rsub;
+                    hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int row = t * 8 + rsub;
@@ -195,7 +181,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         const float4 r2 = ldf4(ep.g2 + (long)(min(m, M - 1) / rps) * ep.g2_stride + n);
                         gt = {g1.x + r2.x, g1.y + r2.y, g1.z + r2.z, g1.w + r2.w};
                     }
-                    float4 o = {hv[j][t].x + gt.x * a.x, hv[j][t].y + gt.y * a.y, hv[j][t].z + gt.z * a.z, hv[j][t].w + gt.w * a.w};
+                    float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                     if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                     if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
                 }
@@ -247,7 +233,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem
                                               int bm = MT * 64, int bn = 128) {
     const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NTW * 32);
     if (ep.wide_ok && n0 + bn <= N) {  // workgroup-uniform
-        char* stg = smem + wave * (MT * 32 * 128);  // (the workgroup barrier that frees the stages is inside the callee)
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();  // every wave is done reading operand fragments: the stages may be overwritten
+        char* stg = smem + wave * (MT * 32 * 128);
         if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane);
         else gemm_epilogue_wide<MODE, MT, NTW, false>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane);
     } else {
@@ -485,14 +473,6 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int j = 0; j < NTW; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
         }
-    };
-    auto mma = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[i][j] = mfma32(fw[h][j], fa[h][i], acc[i][j]);
     };
 
     bf16x8 pa[2][MT], pw[2][NTW], qa[2][MT], qw[2][NTW];

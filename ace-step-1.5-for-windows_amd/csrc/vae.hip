@@ -507,6 +507,26 @@ int ace355_vae_finalize(ace355_vae* h) {
 
 int ace355_vae_hop(const ace355_vae* h) { return h ? h->hop : 0; }
 
+// Residual unit in place on `state` (scratch `tmp`), shared by decode and encode: x + conv_k1(snake2(conv_k7_dil(snake1(x))))
+static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t* state, bf16_t* tmp, int B, long L, int C, hipStream_t s) {
+    ConvArgs a{};
+    a.x = state; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
+    a.w = R.c1.w; a.bias = R.c1.bias; a.alpha = R.s1.ea; a.beta = R.s1.ib;
+    a.y = tmp; a.y_batch_stride = L * C;
+    a.B = B; a.M = (int)L; a.N = C; a.taps = 7; a.dil = R.dil; a.center = 3;
+    a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
+    int rc = run_conv(h, a, s);
+    if (rc) return rc;
+    a = ConvArgs{};
+    a.x = tmp; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
+    a.w = R.c2.w; a.bias = R.c2.bias; a.alpha = R.s2.ea; a.beta = R.s2.ib;
+    a.res = state; a.res_batch_stride = L * C;
+    a.y = state; a.y_batch_stride = L * C;
+    a.B = B; a.M = (int)L; a.N = C; a.taps = 1; a.dil = 1; a.center = 0;
+    a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
+    return run_conv(h, a, s);
+}
+
 int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream) {
     ACE_CHECK(h && z_dev && wav_out_dev, "vae_decode: null argument");
     if (!h->finalized) { set_error("vae_decode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
@@ -564,26 +584,8 @@ int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wa
         a.B = B; a.M = (int)L + 1; a.N = Bk.ct.N; a.taps = 2; a.dil = 1; a.center = 1;
         a.y_shift = -(long)Bk.pad * Bk.cout; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
         if ((rc = run_conv(h, a, s))) return rc;
-        for (int j = 0; j < 3; ++j) {
-            const ResUnitW& R = Bk.ru[j];
-            // snake1 -> conv k7 dilated (vae_model.py:79)
-            a = ConvArgs{};
-            a.x = nxt; a.x_batch_stride = Lout * Bk.cout; a.L_in = (int)Lout; a.Cin = Bk.cout;
-            a.w = R.c1.w; a.bias = R.c1.bias; a.alpha = R.s1.ea; a.beta = R.s1.ib;
-            a.y = tmp; a.y_batch_stride = Lout * Bk.cout;
-            a.B = B; a.M = (int)Lout; a.N = Bk.cout; a.taps = 7; a.dil = R.dil; a.center = 3;
-            a.y_shift = 0; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
-            if ((rc = run_conv(h, a, s))) return rc;
-            // snake2 -> conv k1, + residual, in place on the block state (vae_model.py:80-87)
-            a = ConvArgs{};
-            a.x = tmp; a.x_batch_stride = Lout * Bk.cout; a.L_in = (int)Lout; a.Cin = Bk.cout;
-            a.w = R.c2.w; a.bias = R.c2.bias; a.alpha = R.s2.ea; a.beta = R.s2.ib;
-            a.res = nxt; a.res_batch_stride = Lout * Bk.cout;
-            a.y = nxt; a.y_batch_stride = Lout * Bk.cout;
-            a.B = B; a.M = (int)Lout; a.N = Bk.cout; a.taps = 1; a.dil = 1; a.center = 0;
-            a.y_shift = 0; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
-            if ((rc = run_conv(h, a, s))) return rc;
-        }
+        for (int j = 0; j < 3; ++j)  // x + conv_k1(snake2(conv_k7_dil(snake1(x)))), in place on the block state (vae_model.py:79-87)
+            if ((rc = run_res_unit(h, Bk.ru[j], nxt, tmp, B, Lout, Bk.cout, s))) return rc;
         std::swap(cur, nxt);
         L = Lout;
     }
@@ -594,26 +596,6 @@ int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wa
     a.y = wav_out_dev; a.y_batch_stride = L * c.audio_channels;
     a.B = B; a.M = (int)L; a.N = c.audio_channels; a.taps = 7; a.dil = 1; a.center = 3;
     a.out_mode = 1; a.n_real = c.audio_channels;
-    return run_conv(h, a, s);
-}
-
-// Residual unit in place on `state` (scratch `tmp`), shared by decode and encode: x + conv_k1(snake2(conv_k7_dil(snake1(x))))
-static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t* state, bf16_t* tmp, int B, long L, int C, hipStream_t s) {
-    ConvArgs a{};
-    a.x = state; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
-    a.w = R.c1.w; a.bias = R.c1.bias; a.alpha = R.s1.ea; a.beta = R.s1.ib;
-    a.y = tmp; a.y_batch_stride = L * C;
-    a.B = B; a.M = (int)L; a.N = C; a.taps = 7; a.dil = R.dil; a.center = 3;
-    a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
-    int rc = run_conv(h, a, s);
-    if (rc) return rc;
-    a = ConvArgs{};
-    a.x = tmp; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
-    a.w = R.c2.w; a.bias = R.c2.bias; a.alpha = R.s2.ea; a.beta = R.s2.ib;
-    a.res = state; a.res_batch_stride = L * C;
-    a.y = state; a.y_batch_stride = L * C;
-    a.B = B; a.M = (int)L; a.N = C; a.taps = 1; a.dil = 1; a.center = 0;
-    a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
     return run_conv(h, a, s);
 }
 

@@ -249,3 +249,44 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
     return {"target_latents": out,
             "time_costs": {"encoder_time_cost": t1 - t0, "diffusion_time_cost": t2 - t1,
                            "diffusion_per_step_time_cost": (t2 - t1) / max(steps, 1), "total_time_cost": t2 - t0}}
+
+
+# ------------------------------------------------------------------------------------------------ turbo (8-step distilled)
+TURBO_VALID_SHIFTS = [1.0, 2.0, 3.0]
+TURBO_VALID_TIMESTEPS = [
+    1.0, 0.9545454545454546, 0.9333333333333333, 0.9, 0.875, 0.8571428571428571, 0.8333333333333334, 0.7692307692307693, 0.75,
+    0.6666666666666666, 0.6428571428571429, 0.625, 0.5454545454545454, 0.5, 0.4, 0.375, 0.3, 0.25, 0.2222222222222222, 0.125]
+TURBO_SHIFT_TIMESTEPS = {
+    1.0: [1.0, 0.875, 0.75, 0.625, 0.5, 0.375, 0.25, 0.125],
+    2.0: [1.0, 0.9333333333333333, 0.8571428571428571, 0.7692307692307693, 0.6666666666666666, 0.5454545454545454, 0.4, 0.2222222222222222],
+    3.0: [1.0, 0.9545454545454546, 0.9, 0.8333333333333334, 0.75, 0.6428571428571429, 0.5, 0.3],
+}
+
+
+def turbo_schedule(shift: float = 3.0, timesteps=None) -> List[float]:
+    """Timestep table of the turbo model (models/turbo/modeling_acestep_v15_turbo.py:1807-1865): fixed 8-value tables for
+    shift in {1,2,3} (other shifts snap to the nearest); explicit ``timesteps`` drop trailing zeros, are cut to 20 entries and
+    snapped to the 20 trained values."""
+    if timesteps is not None:
+        ts = [float(x) for x in (timesteps.tolist() if isinstance(timesteps, torch.Tensor) else list(timesteps))]
+        while ts and ts[-1] == 0:
+            ts.pop()
+        if len(ts) >= 1:
+            return [min(TURBO_VALID_TIMESTEPS, key=lambda x: abs(x - t)) for t in ts[:20]]
+    return list(TURBO_SHIFT_TIMESTEPS[min(TURBO_VALID_SHIFTS, key=lambda x: abs(x - shift))])
+
+
+def generate_latents_turbo(dit: NativeDit, encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor, seed=None,
+                           shift: float = 3.0, timesteps=None, infer_method: str = "ode", audio_cover_strength: float = 1.0,
+                           cover_noise_strength: float = 0.0, src_latents: Optional[torch.Tensor] = None,
+                           encoder_hidden_states_non_cover: Optional[torch.Tensor] = None,
+                           context_latents_non_cover: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                           sde_noise: Optional[torch.Tensor] = None) -> Dict:
+    """The turbo model's ``generate_audio`` after ``prepare_condition`` (turbo.py:1900-1995): same network, no CFG / null
+    branch, fixed tables, last step ``x0 = xt - vt * t``: the base loop on ``table + [0]`` with guidance 1."""
+    table = turbo_schedule(shift, timesteps)
+    return generate_latents(dit, None, encoder_hidden_states, context_latents, seed=seed, infer_method=infer_method,
+                            infer_steps=len(table), diffusion_guidance_sale=1.0, shift=shift, timesteps=table + [0.0],
+                            audio_cover_strength=audio_cover_strength, cover_noise_strength=cover_noise_strength, src_latents=src_latents,
+                            encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
+                            context_latents_non_cover=context_latents_non_cover, noise=noise, sde_noise=sde_noise)

@@ -135,3 +135,43 @@ def generate_audio(
         if trace is not None:
             trace.append(xt.clone())
     return xt
+
+
+# --------------------------------------------------------------------------- turbo (8-step distilled, no CFG)
+TURBO_VALID_SHIFTS = [1.0, 2.0, 3.0]
+TURBO_VALID_TIMESTEPS = [
+    1.0, 0.9545454545454546, 0.9333333333333333, 0.9, 0.875, 0.8571428571428571, 0.8333333333333334, 0.7692307692307693, 0.75,
+    0.6666666666666666, 0.6428571428571429, 0.625, 0.5454545454545454, 0.5, 0.4, 0.375, 0.3, 0.25, 0.2222222222222222, 0.125]
+TURBO_SHIFT_TIMESTEPS = {
+    1.0: [1.0, 0.875, 0.75, 0.625, 0.5, 0.375, 0.25, 0.125],
+    2.0: [1.0, 0.9333333333333333, 0.8571428571428571, 0.7692307692307693, 0.6666666666666666, 0.5454545454545454, 0.4, 0.2222222222222222],
+    3.0: [1.0, 0.9545454545454546, 0.9, 0.8333333333333334, 0.75, 0.6428571428571429, 0.5, 0.3],
+}
+
+
+def turbo_schedule(shift: float = 3.0, timesteps: Optional[Sequence[float]] = None) -> List[float]:
+    """turbo/modeling_acestep_v15_turbo.py:1807-1865: fixed 8-value tables per shift in {1,2,3}; explicit ``timesteps`` lose
+    trailing zeros, are truncated to 20 and snapped to the 20 trained values (an empty list falls back to the shift table)."""
+    if timesteps is not None:
+        ts = [float(x) for x in (timesteps.tolist() if isinstance(timesteps, torch.Tensor) else list(timesteps))]
+        while ts and ts[-1] == 0:
+            ts.pop()
+        if len(ts) >= 1:
+            ts = ts[:20]
+            return [min(TURBO_VALID_TIMESTEPS, key=lambda x: abs(x - t)) for t in ts]
+    return list(TURBO_SHIFT_TIMESTEPS[min(TURBO_VALID_SHIFTS, key=lambda x: abs(x - shift))])
+
+
+def generate_audio_turbo(cfg: DitConfig, w: Dict[str, Tensor], encoder_hidden_states: Tensor, context_latents: Tensor,
+                         seed: Union[int, List[int], None] = None, shift: float = 3.0, timesteps: Optional[Sequence[float]] = None,
+                         infer_method: str = "ode", audio_cover_strength: float = 1.0, cover_noise_strength: float = 0.0,
+                         src_latents: Optional[Tensor] = None, encoder_hidden_states_non_cover: Optional[Tensor] = None,
+                         context_latents_non_cover: Optional[Tensor] = None, noise: Optional[Tensor] = None) -> Tensor:
+    """Sampling loop of the turbo model (turbo.py:1780-1995) given prepared conditions: no CFG / null branch, the last step is
+    ``x0 = xt - vt * t`` (:1976-1978), i.e. the base loop on ``table + [0]`` with guidance 1 (no momentum, no interval)."""
+    table = turbo_schedule(shift, timesteps)
+    return generate_audio(cfg, w, torch.zeros(1, 1, cfg.hidden_size), encoder_hidden_states, context_latents, seed=seed,
+                          infer_method=infer_method, infer_steps=len(table), diffusion_guidance_sale=1.0, shift=shift,
+                          timesteps=table + [0.0], audio_cover_strength=audio_cover_strength, cover_noise_strength=cover_noise_strength,
+                          src_latents=src_latents, encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
+                          context_latents_non_cover=context_latents_non_cover, noise=noise)

@@ -68,7 +68,7 @@ def test_condition_encoder_vs_reference_golden(gpu_device, golden_dir, case):
     G = np.load(f"{golden_dir}/g7_cond_encoder.npz")
     cfg = _tiny_cfg(int(G[f"{case}_window"]))
     w = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=int(G["seed"]), mode="test")
-    assert weightgen.checksum(w) == float(G[f"{case}_wsum"])
+    assert abs(weightgen.checksum(w) - float(G[f"{case}_wsum"])) < 1e-6 * float(G[f"{case}_wsum"])
     enc = NativeCondEncoder(cfg, gpu_device)
     enc.load_state_dict(w)
     h, m = enc(T(G[f"{case}_text"]), T(G[f"{case}_tmask"]), T(G[f"{case}_lyric"]), T(G[f"{case}_lmask"]), T(G[f"{case}_refer"]),

@@ -288,3 +288,23 @@ def test_full_size_properties_batch_invariance_and_determinism(gpu_device):
     assert r < 5e-3, r
     # different seeds really give different songs (guards against a broadcast bug hiding behind the checks above)
     assert _rel(a[0:1], a[1:2]) > 0.5
+
+
+@pytest.mark.parametrize("name", ["shift3", "explicit", "cover"])
+def test_turbo_sampler_vs_reference_golden(gpu_device, golden_dir, name):
+    """Turbo model family: 8-step tables, no CFG (models/turbo/modeling_acestep_v15_turbo.py:1780-1995) vs vectors captured from
+    the imported turbo reference; same DiT kernels, `generate_latents_turbo` on the host side."""
+    from ace355 import weightgen
+    from ace355.dit import generate_latents_turbo
+    G = np.load(f"{golden_dir}/g9_turbo_sampler.npz")
+    cfg, w, dit = _make(TINY, 4, gpu_device)
+    assert abs(weightgen.checksum(w) - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    ts = G[f"{name}_timesteps"].tolist()
+    t = lambda k: torch.from_numpy(G[k])  # noqa: E731
+    out = generate_latents_turbo(dit, t("enc"), t("ctx"), seed=G["seeds"].tolist(), shift=float(G[f"{name}_shift"]),
+                                 timesteps=ts if ts else None, audio_cover_strength=float(G[f"{name}_acs"]),
+                                 cover_noise_strength=float(G[f"{name}_cns"]), src_latents=t("src"),
+                                 encoder_hidden_states_non_cover=t("enc_nc"), context_latents_non_cover=t("ctx_nc"))["target_latents"]
+    r = _rel(out, t(f"{name}_out"))
+    print(f"turbo sampler {name}: rel L2 vs the turbo reference (fp32 CPU) = {r:.3e}")
+    assert r < 1e-2, r

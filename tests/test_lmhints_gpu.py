@@ -18,7 +18,7 @@ def test_detokenizer_vs_reference_golden(gpu_device, golden_dir):
     G = np.load(f"{golden_dir}/g8_detokenizer.npz")
     cfg = ace355.DetokConfig(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
     w = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=int(G["seed"]), mode="test")
-    assert weightgen.checksum(w) == float(G["wsum"])
+    assert abs(weightgen.checksum(w) - float(G["wsum"])) < 1e-6 * float(G["wsum"])
     det = NativeDetokenizer(cfg, gpu_device)
     det.load_state_dict(w)
     y = det(torch.from_numpy(G["x"]))

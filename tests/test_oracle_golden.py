@@ -140,7 +140,7 @@ def test_g7_condition_encoder(golden_dir, case):
     G = np.load(f"{golden_dir}/g7_cond_encoder.npz")
     cfg = tiny_cond_config(int(G[f"{case}_window"]))
     w = weightgen.make_dit_weights(o_cond.cond_weight_shapes(cfg), cfg.hidden_size, seed=int(G["seed"]), mode="test")
-    assert weightgen.checksum(w) == float(G[f"{case}_wsum"])
+    assert abs(weightgen.checksum(w) - float(G[f"{case}_wsum"])) < 1e-6 * float(G[f"{case}_wsum"])
     h, m = o_cond.condition_encoder(cfg, w, T(G[f"{case}_text"]), T(G[f"{case}_tmask"]), T(G[f"{case}_lyric"]), T(G[f"{case}_lmask"]),
                                     T(G[f"{case}_refer"]), T(G[f"{case}_order"]))
     assert torch.equal(m.long(), T(G[f"{case}_m"]))
@@ -152,7 +152,7 @@ def test_g8_detokenizer_and_code_parser(golden_dir):
     G = np.load(f"{golden_dir}/g8_detokenizer.npz")
     cfg = o_detok.DetokConfig(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
     w = weightgen.make_dit_weights(o_detok.detok_weight_shapes(cfg), cfg.hidden_size, seed=int(G["seed"]), mode="test")
-    assert weightgen.checksum(w) == float(G["wsum"])
+    assert abs(weightgen.checksum(w) - float(G["wsum"])) < 1e-6 * float(G["wsum"])
     y = o_detok.detokenizer(cfg, w, T(G["x"]))
     assert float((y - T(G["y"])).abs().max()) < 2e-5
     for i, c in enumerate(G["parse_cases"].tolist()):
@@ -163,6 +163,23 @@ def test_g8_detokenizer_and_code_parser(golden_dir):
     assert torch.allclose(codes[2], torch.tensor([-0.75, -1, -1, -1, -1, -1])) and torch.allclose(codes[3], torch.tensor([-1, -0.75, -1, -1, -1, -1]))
     assert torch.allclose(codes[4], torch.tensor([-1, -1, -1, -0.5, -1, -1]))
     assert len({tuple(r.tolist()) for r in o_detok.fsq_codes_from_indices(torch.arange(64000), (8, 8, 8, 5, 5, 5))}) == 64000
+
+
+@pytest.mark.parametrize("name", ["shift3", "shift1", "snap", "explicit", "cover"])
+def test_g9_turbo_sampler(golden_dir, name):
+    """The turbo model's 8-step loop (turbo.py:1780-1995) vs the imported turbo reference."""
+    G = np.load(f"{golden_dir}/g9_turbo_sampler.npz")
+    cfg = o_dit.DitConfig(**TINY)
+    w = weightgen.make_dit_weights(o_dit.dit_weight_shapes(cfg), cfg.hidden_size, seed=4, mode="test")
+    assert abs(weightgen.checksum(w) - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    ts = G[f"{name}_timesteps"].tolist()
+    out = o_sampler.generate_audio_turbo(cfg, w, T(G["enc"]), T(G["ctx"]), seed=G["seeds"].tolist(), shift=float(G[f"{name}_shift"]),
+                                         timesteps=ts if ts else None, audio_cover_strength=float(G[f"{name}_acs"]),
+                                         cover_noise_strength=float(G[f"{name}_cns"]), src_latents=T(G["src"]),
+                                         encoder_hidden_states_non_cover=T(G["enc_nc"]), context_latents_non_cover=T(G["ctx_nc"]))
+    assert float((out - T(G[f"{name}_out"])).abs().max()) < 5e-4
+    from ace355.dit import turbo_schedule
+    assert turbo_schedule(float(G[f"{name}_shift"]), ts if ts else None) == o_sampler.turbo_schedule(float(G[f"{name}_shift"]), ts if ts else None)
 
 
 def test_latent_guards():

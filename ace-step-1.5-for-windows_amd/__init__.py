@@ -7,6 +7,7 @@ Layout:
   vae.py       NativeVae: weight-norm fusion, decode
   cond.py      NativeCondEncoder: lyric / timbre encoders + sequence packing
   lmhints.py   audio-code parsing, FSQ index decode, NativeDetokenizer
+  audio_out.py normalize_audio, AudioSaver: GPU normalise / PCM conversion + threaded FLAC / WAV writers
   backend.py   NativeDitMixin / NativeVaeMixin / NativeHandler: the reference's handler seam
   dist.py      one-process-per-GPU data-parallel runner (RCCL broadcast of conditioning)
   weightgen.py deterministic synthetic weights (no checkpoints exist on the boxes)

@@ -11,7 +11,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libace355.so")
-SOURCES = ["gemm.hip", "attn.hip", "elementwise.hip", "conv.hip", "dit.hip", "vae.hip", "cond.hip", "api.hip"]
+SOURCES = ["gemm.hip", "attn.hip", "elementwise.hip", "conv.hip", "dit.hip", "vae.hip", "cond.hip", "audio_out.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -161,6 +161,8 @@ int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, 
 int launch_adg_step(const float* v, long uncond_offset, float* xt, bf16_t* xin, int copies, int B, int T, int Tpad, float guidance,
                     float sigma, float dt, const StepUpdate& up, hipStream_t s);
 int launch_peak_normalize(float* wav, int B, long per_item, float* scratch, hipStream_t s);
+int launch_normalize_db(float* wav, int B, long per_item, float amp, float* peaks, hipStream_t s);
+int launch_interleave(const float* wav, int B, int C, long S, void* out, int as_pcm16, hipStream_t s);
 int launch_latent_check(const float* x, long n, int* flags_dev, hipStream_t s);
 
 // generic pack: dst bf16 / f32 from src (f32 or bf16) with an index mapping

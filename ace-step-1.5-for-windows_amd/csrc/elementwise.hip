@@ -402,6 +402,41 @@ __global__ void peak_scale_kernel(float* __restrict__ wav, long per_item, int B,
     float* p = wav + (long)b * per_item;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_item; i += (long)gridDim.x * blockDim.x) p[i] *= inv;
 }
+// normalize_audio (acestep/audio_utils.py:24-62): gain = fp32(10^(dB/20)) * (1 / peak) exactly as torch evaluates
+// `target_amp / peak` (Tensor.__rtruediv__ = reciprocal * scalar); items with peak < 1e-6 stay untouched.
+__global__ void normalize_db_kernel(float* __restrict__ wav, long per_item, float amp, const float* __restrict__ peaks) {
+    const int b = blockIdx.y;
+    const float peak = peaks[b];
+    if (peak < 1e-6f) return;
+    const float gain = __fmul_rn(1.0f / peak, amp);  // correctly rounded divide (hipcc default), as torch.reciprocal
+    float* p = wav + (long)b * per_item;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_item; i += (long)gridDim.x * blockDim.x) p[i] = __fmul_rn(p[i], gain);
+}
+// [items][C][S] f32 -> [items][S][C] int16, lrintf(x * 32767) (libsndfile's float -> PCM_16 rule, round half to even),
+// saturated.  C <= 8; 8 frames per thread so both the loads (per channel) and the store stream are contiguous.
+template <int C>
+__global__ void pcm16_interleave_kernel(const float* __restrict__ wav, long S, int16_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const float* p = wav + (long)b * C * S;
+    int16_t* o = out + (long)b * C * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int v = __float2int_rn(__fmul_rn(p[(long)c * S + i], 32767.f));
+            o[i * C + c] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+        }
+    }
+}
+template <int C>
+__global__ void f32_interleave_kernel(const float* __restrict__ wav, long S, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const float* p = wav + (long)b * C * S;
+    float* o = out + (long)b * C * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += (long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[i * C + c] = p[(long)c * S + i];
+    }
+}
 __global__ void latent_check_kernel(const float* __restrict__ x, long n, int* __restrict__ flags) {
     bool bad = false, nz = false;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -655,6 +690,31 @@ int launch_peak_normalize(float* wav, int B, long per_item, float* scratch, hipS
     const int g = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
     hipLaunchKernelGGL(absmax_kernel, dim3(g, B), dim3(256), 0, s, wav, per_item, scratch);
     hipLaunchKernelGGL(peak_scale_kernel, dim3(g, B), dim3(256), 0, s, wav, per_item, B, scratch);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_normalize_db(float* wav, int B, long per_item, float amp, float* peaks, hipStream_t s) {
+    ACE_HIP(hipMemsetAsync(peaks, 0, sizeof(float) * B, s));
+    const int gx = (int)((per_item + 256L * 16 - 1) / (256L * 16));
+    const int g = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(absmax_kernel, dim3(g, B), dim3(256), 0, s, wav, per_item, peaks);
+    hipLaunchKernelGGL(normalize_db_kernel, dim3(g, B), dim3(256), 0, s, wav, per_item, amp, peaks);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_interleave(const float* wav, int B, int C, long S, void* out, int as_pcm16, hipStream_t s) {
+    const int gx = (int)((S + 255) / 256);
+    const dim3 grid(gx < 1 ? 1 : (gx > 2048 ? 2048 : gx), B);
+    if (C == 1) {
+        if (as_pcm16) hipLaunchKernelGGL(pcm16_interleave_kernel<1>, grid, dim3(256), 0, s, wav, S, (int16_t*)out);
+        else hipLaunchKernelGGL(f32_interleave_kernel<1>, grid, dim3(256), 0, s, wav, S, (float*)out);
+    } else if (C == 2) {
+        if (as_pcm16) hipLaunchKernelGGL(pcm16_interleave_kernel<2>, grid, dim3(256), 0, s, wav, S, (int16_t*)out);
+        else hipLaunchKernelGGL(f32_interleave_kernel<2>, grid, dim3(256), 0, s, wav, S, (float*)out);
+    } else {
+        set_error("interleave: 1 or 2 channels");
+        return 1;
+    }
     ACE_LAUNCH_CHECK();
     return 0;
 }

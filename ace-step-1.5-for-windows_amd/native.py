@@ -104,6 +104,15 @@ SIGNATURES = {
     "ace355_detok_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_peak_normalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p]),
     "ace355_latent_check": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_void_p]),
+    "ace355_normalize_audio": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "ace355_audio_interleave": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "ace355_flac_bound": (C.c_int64, [C.c_int64, C.c_int]),
+    "ace355_flac_encode_pcm16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "ace355_flac_info": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "ace355_flac_decode_pcm16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int]),
+    "ace355_wav_bound": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "ace355_wav_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "ace355_save_audio_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_void_p]),
     "ace355_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_gemm_bf16_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

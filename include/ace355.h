@@ -248,6 +248,47 @@ int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream)
 int ace355_latent_check(const float* lat_dev, int64_t numel, int32_t* flags_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Output stage: what acestep/inference.py:649-726 does per item after the decode,
+ * batched.  Replaces normalize_audio (acestep/audio_utils.py:24-62) and AudioSaver.save_audio / save_batch
+ * (audio_utils.py:65-215, 259-313) for the formats whose codecs are containers over PCM: "flac" (PCM_16, the
+ * reference default), "wav" / "wav32" (IEEE float32, what torchaudio's soundfile backend writes for a float32
+ * tensor).  "mp3" / "opus" / "aac" go through ffmpeg in the reference and stay there.
+ * ------------------------------------------------------------------------------------------ */
+#define ACE355_AUDIO_FLAC 0      /* FLAC, 16 bits per sample */
+#define ACE355_AUDIO_WAV_F32 1   /* RIFF/WAVE, IEEE float32 ("wav" and "wav32" of the reference) */
+#define ACE355_AUDIO_WAV_PCM16 2 /* RIFF/WAVE, PCM_16 */
+
+/* normalize_audio(audio, target_db), audio_utils.py:24-62, per item and in place: peak = max|x| over the item
+ * ([channels, samples] jointly); items with peak < 1e-6 are left alone; x *= fp32(10^(dB/20)) * (1 / peak) with the
+ * roundings torch applies.  wav dev f32 [n_items, per_item]; peaks_host (may be NULL) receives the peaks. */
+int ace355_normalize_audio(float* wav_dev, int n_items, int64_t per_item, float target_db, float* peaks_host, void* stream);
+/* dev f32 [n_items, channels, samples] -> dev interleaved [n_items, samples, channels]: int16 = lrintf(x * 32767)
+ * saturated (libsndfile's float -> PCM_16 rule) when as_pcm16 != 0, else float32.  channels 1 or 2.  Asynchronous. */
+int ace355_audio_interleave(const float* wav_dev, int n_items, int channels, int64_t samples, void* out_dev, int as_pcm16,
+                            void* stream);
+/* Host-side codecs (no GPU involved).  FLAC: RFC 9639 subset - fixed 4096-sample blocks, constant / verbatim /
+ * fixed-predictor subframes, partitioned Rice coding, stereo decorrelation, CRC-8/16, MD5 in STREAMINFO; frames are
+ * encoded by n_threads host threads (0 = up to 16).  pcm = interleaved int16 [frames, channels], channels 1 or 2. */
+int64_t ace355_flac_bound(int64_t frames, int channels);
+int ace355_flac_encode_pcm16(const int16_t* pcm, int64_t frames, int channels, int sample_rate, int n_threads, uint8_t* out,
+                             int64_t cap, int64_t* out_len);
+/* Decoder for AudioSaver.convert_audio (audio_utils.py:217-257) and round-trip checks: <= 16 bits per sample, 1-2
+ * channels; constant / verbatim / fixed / LPC subframes, Rice and Rice2 residuals; checks every CRC, and the MD5
+ * when verify_md5 != 0 and STREAMINFO carries one. */
+int ace355_flac_info(const uint8_t* data, int64_t size, int64_t* frames, int32_t* channels, int32_t* sample_rate,
+                     int32_t* bits_per_sample);
+int ace355_flac_decode_pcm16(const uint8_t* data, int64_t size, int16_t* pcm_out, int64_t cap_samples, int verify_md5);
+/* RIFF/WAVE: interleaved float32 (is_float != 0; format tag 3 + `fact` chunk) or int16 PCM. */
+int64_t ace355_wav_bound(int64_t frames, int channels, int is_float);
+int ace355_wav_encode(const void* interleaved, int64_t frames, int channels, int sample_rate, int is_float, uint8_t* out,
+                      int64_t cap, int64_t* out_len);
+/* AudioSaver.save_batch for a decoded batch still in HBM: interleave (+ quantise) on the GPU, one D2H copy of the
+ * converted samples, all (item, block) encode jobs on one pool of n_threads host threads, files written in parallel.
+ * wav dev f32 [n_items, channels, samples]; paths[n_items]; format = ACE355_AUDIO_*.  Synchronous. */
+int ace355_save_audio_batch(const float* wav_dev, int n_items, int channels, int64_t samples, int sample_rate, int format,
+                            const char* const* paths, int n_threads, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Unit kernels (test hooks; each has an oracle twin in oracle/ used by tests/)
  * ---------------------------------------------------------------------------------------- */
 /* C = A[M,K] * W[N,K]^T, bf16 in, fp32 accumulate (MFMA).  out_dtype: ACE355_DTYPE_*; bias f32 [N] or NULL. */

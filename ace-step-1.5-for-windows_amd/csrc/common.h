@@ -185,6 +185,7 @@ struct ConvArgs {
     int out_mode;                                                // 0: bf16 NLC flat; 1: f32 NCL [b][n][m] (n < n_real)
     int n_real;
     int wide_ok;                                                 // set by launch_conv: y / res / strides allow the 16-byte staged epilogue
+    int clk_probe;                                               // ACE355_CONV_CLK=1: one workgroup records its shader-clock phases
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s);

@@ -14,6 +14,9 @@
 // window (128 + (taps-1)*dil rows) is loaded ONCE, Snake applied in registers (fp32), and parked in LDS (swizzled);
 // every tap then reads its shifted rows from LDS, so Snake costs (1 + halo) instead of `taps` evaluations and x is
 // read from HBM/L2 once per chunk.  Weight tiles stream through a 2-stage LDS ring, one barrier per tap.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ace355 {
@@ -22,13 +25,30 @@ namespace {
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-constexpr int WIN_MAX = 192;  // 128 + 6*9 = 182 rows needed at most
+// ACE355_CONV_CLK=1: shader-clock phases of one interior workgroup (thread 0): [0] total, [1] window staging + first weight
+// tile (incl. the wait for the loads), [2] tap loops, [3] epilogue, [4] wall clock (100 MHz), [5] chunks.
+__device__ unsigned long long g_conv_probe[8];
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
+// Register-staged tiles use the native vector type: hipcc does not scalarise arrays of HIP's `uint4` struct that live across
+// the tap loop (they ended up as LDS / scratch allocas: every weight prefetch was written out and waited for on the spot).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld_u32x4(const void* p) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(p));
+}
+
+constexpr int HALO_MAX = 64;  // (taps-1)*dil <= 6*9 = 54 rows of halo at most
+
+// TM = positions per workgroup, one wave per 64 x 64 (BN = 128) sub-tile: 128 -> 4 waves, 256 -> 8 waves.  The 8-wave
+// form shares each weight tile between twice as many MFMAs, shrinks the Snake halo from 1.42x to 1.21x of the tile and puts
+// 4 waves on every SIMD (2 workgroups per CU either way), which is what hides the per-tap barrier and the staging phases.
+template <int BN, int TM>
+__global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
+    static_assert(TM == 128 || (TM == 256 && BN == 128), "tile shapes");
+    constexpr int NTHR = TM * 2;
+    constexpr int WIN_MAX = TM + HALO_MAX;
     constexpr int MT = (BN == 128) ? 2 : 1;
     constexpr int NT = (BN == 128) ? 2 : 1;
-    constexpr int WCH = BN * 8 / 256;  // 16-B weight chunks per thread per tile
+    constexpr int WCH = BN * 8 / NTHR;  // 16-B weight chunks per thread per tile
     __shared__ __attribute__((aligned(16))) char smem[WIN_MAX * 128 + 2 * BN * 128];
     char* As = smem;
     char* Wbase = smem + WIN_MAX * 128;
@@ -37,9 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
     const int lq = lane & 31, half = lane >> 5;
     const int wm = (BN == 128) ? (wave >> 1) : wave;
     const int wn = (BN == 128) ? (wave & 1) : 0;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN, b = blockIdx.z;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * BN, b = blockIdx.z;
     const int Cin = a.Cin, taps = a.taps, dil = a.dil;
-    const int win_rows = 128 + (taps - 1) * dil;
+    const int win_rows = TM + (taps - 1) * dil;
     const int x_row0 = m0 - a.center * dil;
     const bf16_t* xb = a.x + (long)b * a.x_batch_stride;
     const long wrow = (long)taps * Cin;  // elements per output channel in w
@@ -53,22 +73,36 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sslot = tid & 7;
-    // weight staging addresses: chunk c = tid + i*256 -> row = c>>3 (i-th: + 32*i), slot = tid&7
+    // weight staging addresses: chunk c = tid + i*NTHR -> row = c>>3 (i-th: + NTHR/8*i), slot = tid&7
     const bf16_t* wsrc[WCH];
     int wst[WCH];
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
-        const int row = (tid >> 3) + 32 * i;
+        const int row = (tid >> 3) + (NTHR / 8) * i;
         wsrc[i] = a.w + (long)min(n0 + row, a.N - 1) * wrow + sslot * 8;
         wst[i] = lds_off(row, sslot);
     }
-    uint4 rw[WCH];
+    u32x4 rw[WCH];
 
-    for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
-        __syncthreads();  // previous chunk fully consumed
-        // ---- stage the input window once (Snake in fp32 registers)
+    // Input window of one 64-channel chunk: all of a thread's (up to 6) 16-byte loads are issued back to back into
+    // registers - and, for the next chunk, before the tap loop of the current one - so a workgroup pays one memory latency
+    // per chunk instead of one per load (the loads used to sit in a load -> Snake -> ds_write loop).
+    constexpr int WLD = (WIN_MAX * 8 + NTHR - 1) / NTHR;
+    u32x4 wv[WLD];
+    const bool snake = a.alpha != nullptr;
+    auto win_load = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int c = tid + i * NTHR;
+            const int xr = x_row0 + (c >> 3);
+            const long flat = (long)xr * Cin + ci0 + sslot * 8 + a.x_shift;
+            const bool inside = (c < win_rows * 8) && (a.x_valid ? (flat >= 0 && flat < a.x_valid) : (xr >= 0 && xr < a.L_in));
+            wv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (inside) wv[i] = ld_u32x4(xb + flat);
+        }
+    };
+    auto win_store = [&](int ci0) {
         float sa[8], sib[8];
-        const bool snake = a.alpha != nullptr;
         if (snake) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -76,38 +110,50 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
                 sib[e] = a.beta[ci0 + sslot * 8 + e];   // already 1/(exp(beta)+1e-9)
             }
         }
-        for (int c = tid; c < win_rows * 8; c += 256) {
-            const int wr = c >> 3;
-            const int xr = x_row0 + wr;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const long flat = (long)xr * Cin + ci0 + sslot * 8 + a.x_shift;
-            const bool inside = a.x_valid ? (flat >= 0 && flat < a.x_valid) : (xr >= 0 && xr < a.L_in);
-            if (inside) {
-                v = *reinterpret_cast<const uint4*>(xb + flat);
-                if (snake) {
-                    uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int c = tid + i * NTHR;
+            if (c < win_rows * 8) {
+                u32x4 v = wv[i];
+                if (snake) {  // Snake(0) = 0: rows outside the signal stay zero
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) {
-                        const float x0 = bf_lo(pv[e2]), x1 = bf_hi(pv[e2]);
+                        const float x0 = bf_lo(v[e2]), x1 = bf_hi(v[e2]);
                         const float s0 = __sinf(sa[2 * e2] * x0), s1 = __sinf(sa[2 * e2 + 1] * x1);
-                        pv[e2] = pack_bf2(x0 + sib[2 * e2] * s0 * s0, x1 + sib[2 * e2 + 1] * s1 * s1);
+                        v[e2] = pack_bf2(x0 + sib[2 * e2] * s0 * s0, x1 + sib[2 * e2 + 1] * s1 * s1);
                     }
                 }
+                *reinterpret_cast<u32x4*>(As + lds_off(c >> 3, sslot)) = v;
             }
-            *reinterpret_cast<uint4*>(As + lds_off(wr, sslot)) = v;
         }
+    };
+
+    const bool probe = a.clk_probe && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+    unsigned long long p_t0 = 0, p_w0 = 0, p_stage = 0, p_taps = 0, p_mark = 0;
+    if (probe) p_t0 = clock64(), p_w0 = wall_clock64();
+    // the 4-wave form keeps the next chunk's window loads in flight across the tap loop; with 4 waves per SIMD the 8-wave
+    // form has no registers to spare for that (128-VGPR budget) and other waves to cover the latency instead
+    constexpr bool PREFETCH = (TM == 128);
+    if (PREFETCH) win_load(0);
+    for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
+        if (probe) p_mark = clock64();
+        if (!PREFETCH) win_load(ci0);
+        __syncthreads();  // previous chunk fully consumed
+        win_store(ci0);   // Snake in fp32 registers, parked in LDS once per chunk
+        if (PREFETCH && ci0 + 64 < Cin) win_load(ci0 + 64);
         // ---- weight tile for tap 0 of this chunk
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const uint4*>(wsrc[i] + ci0);
+        for (int i = 0; i < WCH; ++i) rw[i] = ld_u32x4(wsrc[i] + ci0);
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(Wbase + wst[i]) = rw[i];
+        for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(Wbase + wst[i]) = rw[i];
         __syncthreads();
+        if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
 
         for (int tap = 0; tap < taps; ++tap) {
             const bool more = (tap + 1) < taps;
             if (more) {
 #pragma unroll
-                for (int i = 0; i < WCH; ++i) rw[i] = *reinterpret_cast<const uint4*>(wsrc[i] + (long)(tap + 1) * Cin + ci0);
+                for (int i = 0; i < WCH; ++i) rw[i] = ld_u32x4(wsrc[i] + (long)(tap + 1) * Cin + ci0);
             }
             const char* Ws = Wbase + (tap & 1) * (BN * 128);
             const int arow = wm * (MT * 32) + tap * dil + lq;
@@ -128,23 +174,32 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
             if (more) {
                 char* Wd = Wbase + ((tap + 1) & 1) * (BN * 128);
 #pragma unroll
-                for (int i = 0; i < WCH; ++i) *reinterpret_cast<uint4*>(Wd + wst[i]) = rw[i];
+                for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(Wd + wst[i]) = rw[i];
                 __syncthreads();
             }
         }
+        if (probe) p_taps += clock64() - p_mark;
     }
+    const unsigned long long p_e0 = probe ? clock64() : 0ull;
+    auto probe_done = [&]() {
+        if (!probe) return;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // stores acknowledged
+        const unsigned long long t = clock64();
+        g_conv_probe[0] = t - p_t0, g_conv_probe[1] = p_stage, g_conv_probe[2] = p_taps, g_conv_probe[3] = t - p_e0;
+        g_conv_probe[4] = wall_clock64() - p_w0, g_conv_probe[5] = (unsigned long long)(Cin / 64);
+    };
 
     // ---------------------------------------------------------------- epilogue
     // Operands are swapped in the MFMAs, so lane l holds output ROW (position) lq of each 32x32 tile and, per register quad
     // g = r>>2, four consecutive channels n = .. + 8g + 4*half + (r&3).  Stores (and the residual loads) of an MFMA epilogue
     // are issue-bound per instruction: interior bf16 tiles go through a wave-private fp32 LDS staging image, one 32-channel
     // half at a time, and leave as 16-byte row-major accesses (8 loads + 8 stores per lane instead of 64 + 64 two-byte ones).
-    const bool full = (m0 + 128 <= a.M) && (n0 + BN <= a.N) &&
-                      ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + 127) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
+    const bool full = (m0 + TM <= a.M) && (n0 + BN <= a.N) &&
+                      ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + TM - 1) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
     const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NT * 32);
     if (BN == 128 && a.out_mode == 0 && full && a.wide_ok) {  // workgroup-uniform
         __syncthreads();  // every wave is done with the operand tiles: the LDS may be overwritten
-        char* stg = smem + wave * 8192;  // 64 rows x 128 B (32 floats)
+        char* stg = smem + wave * (MT * 32 * 128);  // MT*32 rows x 128 B (32 floats)
         const int row_l = lane >> 2, c4 = lane & 3;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -185,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs a) {
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.y) + col + (long)(mw0 + row) * a.N) = pk;
             }
         }
+        probe_done();
         return;
     }
     // generic per-element path (edge tiles, cropped transposed-conv spans, the fp32 NCL output of the last conv)
@@ -226,7 +282,7 @@ __global__ void ncl_to_nlc_kernel(const float* __restrict__ z, bf16_t* __restric
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
     ACE_CHECK(a.Cin % 64 == 0, "conv: Cin must be a multiple of 64");
-    ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil + 128 <= WIN_MAX && a.dil >= 1, "conv: window too large");
+    ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil <= HALO_MAX && a.dil >= 1, "conv: window too large");
     ACE_CHECK(a.B > 0 && a.M > 0 && a.N > 0, "conv: empty problem");
     ACE_CHECK(a.x_valid ? (a.x_shift % 8 == 0 && a.x_valid % 8 == 0) : a.x_shift == 0, "conv: x_shift / x_valid must be multiples of 8 (and x_shift needs x_valid)");
     ConvArgs aw = a;
@@ -235,14 +291,40 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
                      (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
     }
+    static int tm_env = -1, clk_env = -1;
+    if (clk_env < 0) {
+        const char* e = getenv("ACE355_CONV_CLK");
+        clk_env = e ? atoi(e) : 0;
+    }
+    aw.clk_probe = clk_env;
+    if (tm_env < 0) {
+        const char* e = getenv("ACE355_CONV_TM");  // 128 / 256 force a tile height (A/B runs); default: by problem size
+        tm_env = e ? atoi(e) : 0;
+    }
     if (a.N >= 128 || a.N % 128 == 0) {
-        dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.B);
-        hipLaunchKernelGGL(conv_kernel<128>, grid, dim3(256), 0, s, aw);
+        const long wgs128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.B;
+        // 8-wave tiles pay off where the tap loop dominates (Cin >= 256: +2-5 %); at Cin = 128 and for k = 1 the exposed
+        // window load of the un-prefetched form costs more than the sharing saves (-5 % / -35 %)
+        const bool tall = tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 2);
+        if (tall) {
+            dim3 grid((a.M + 255) / 256, (a.N + 127) / 128, a.B);
+            hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);
+        } else {
+            dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.B);
+            hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(256), 0, s, aw);
+        }
     } else {
         dim3 grid((a.M + 127) / 128, (a.N + 31) / 32, a.B);
-        hipLaunchKernelGGL(conv_kernel<32>, grid, dim3(256), 0, s, aw);
+        hipLaunchKernelGGL((conv_kernel<32, 128>), grid, dim3(256), 0, s, aw);
     }
     ACE_LAUNCH_CHECK();
+    if (aw.clk_probe) {
+        ACE_HIP(hipStreamSynchronize(s));
+        unsigned long long h[8];
+        ACE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_probe), sizeof(h)));
+        fprintf(stderr, "[conv clk] Cin=%d N=%d taps=%d dil=%d M=%d: total %llu cyc = stage %llu + taps %llu + epilogue %llu (+%llu other), wall %.2f us, %llu chunks\n",
+                a.Cin, a.N, a.taps, a.dil, a.M, h[0], h[1], h[2], h[3], h[0] - h[1] - h[2] - h[3], h[4] / 100.0, h[5]);
+    }
     return 0;
 }
 

@@ -120,6 +120,14 @@ struct AttnArgs {
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 
+struct ModEntry {  // one modulated norm: g = w * (1 + sc1 + tproj[sc2_off..]), sft = sh1 + tproj[sh2_off..]
+    const float *w, *sc1, *sh1;
+    long sc2_off, sh2_off;
+};
+int launch_rmsnorm_gs(const float* x, const float* g, const float* sft, bf16_t* y, int M, int D, float eps, long stride,
+                      int rows_per_seq, hipStream_t s);
+int launch_mod_gs(const ModEntry* entries_dev, int n_entries, const float* tproj, long tp_stride, int rows, float* out, int D,
+                  hipStream_t s);
 int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, float eps, const float* sc1,
                        const float* sc2, const float* sh1, const float* sh2, int stride, int rows_per_seq, hipStream_t s);
 int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const float* w, float eps,

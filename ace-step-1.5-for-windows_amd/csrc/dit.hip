@@ -56,6 +56,8 @@ struct ace355_dit {
     std::vector<void*> ws_allocs;
     bf16_t *xin = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr;
     float *h = nullptr, *vpad = nullptr, *tfreq = nullptr, *ta1 = nullptr, *temb = nullptr, *tsilu = nullptr, *tproj = nullptr;
+    ModEntry* mod_tab = nullptr;  // [NL][2] (self-attention norm, MLP norm), built at finalize
+    float* gs = nullptr;          // [rows][NL][2][2][D] folded (g, sft) vectors of the current forward
     float *xt = nullptr, *avg = nullptr;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_S = 0;
@@ -222,6 +224,7 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
     ALLOC(h->ws_allocs, h->temb, (size_t)capN * D);
     ALLOC(h->ws_allocs, h->tsilu, (size_t)capN * D);
     ALLOC(h->ws_allocs, h->tproj, (size_t)capN * 6 * D);
+    ALLOC(h->ws_allocs, h->gs, (size_t)capN * h->NL * 4 * D);
     ALLOC(h->ws_allocs, h->xt, (size_t)capN * capT * h->OUTC);
     ALLOC(h->ws_allocs, h->avg, (size_t)capN * capT * h->OUTC);
     h->ws_N = capN;
@@ -277,6 +280,11 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     const int Nc = N - n_sc, Mc = Nc * S;
     const float* cconst = n_sc ? h->slots[slots[N - 1]].cross_const : nullptr;
 
+    // fold w * (1 + scale) and shift of the 2 * NL modulated norms for this forward's timestep rows (one launch)
+    rc = launch_mod_gs(h->mod_tab, 2 * h->NL, h->tproj, 6L * D, temb_rows, h->gs, D, s);
+    if (rc) return rc;
+    const long gs_stride = temb_rows == 1 ? 0 : (long)h->NL * 4 * D;
+
     // patchify: Conv1d(192 -> D, k=2, s=2) == GEMM over [M, 384] (base.py:1358)
     ep = GemmEpilogue{1, h->b_in, nullptr, nullptr, 0, 0};
     rc = gemm(h, h->xin, 2 * h->cfg.in_channels, h->w_in, 2 * h->cfg.in_channels, h->h, D, M, D, 2 * h->cfg.in_channels, ep, s);
@@ -286,8 +294,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const LayerW& W = h->layers[li];
         const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
         // ---- self attention (base.py:499-511)
-        rc = launch_rmsnorm_mod(h->h, W.n_sa, h->xn, M, D, eps, W.sst + 1 * D, h->tproj + 1 * D, W.sst + 0 * D, h->tproj + 0 * D,
-                                tstride, S, s);
+        rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, M, D, eps,
+                               gs_stride, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
         rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
@@ -356,8 +364,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         }
 
         // ---- SwiGLU MLP (base.py:530-533)
-        rc = launch_rmsnorm_mod(h->h, W.n_mlp, h->xn, M, D, eps, W.sst + 4 * D, h->tproj + 4 * D, W.sst + 3 * D, h->tproj + 3 * D,
-                                tstride, S, s);
+        rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 1) * 2 * D, h->gs + (size_t)(li * 2 + 1) * 2 * D + D, h->xn, M, D, eps,
+                               gs_stride, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{3, nullptr, nullptr, nullptr, 0, 0};
         rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
@@ -496,6 +504,15 @@ int ace355_dit_finalize(ace355_dit* h) {
         return ACE355_ERR_STATE;
     }
     if (h->stage) { hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+    {   // modulated norms: scale_shift_table rows (shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate), base.py:492-497
+        std::vector<ModEntry> tab;
+        for (const LayerW& L : h->layers) {
+            tab.push_back(ModEntry{L.n_sa, L.sst + 1 * h->D, L.sst + 0 * h->D, 1L * h->D, 0L * h->D});
+            tab.push_back(ModEntry{L.n_mlp, L.sst + 4 * h->D, L.sst + 3 * h->D, 4L * h->D, 3L * h->D});
+        }
+        if (!h->mod_tab) ALLOC(h->allocs, h->mod_tab, tab.size());
+        ACE_HIP(hipMemcpy(h->mod_tab, tab.data(), tab.size() * sizeof(ModEntry), hipMemcpyHostToDevice));
+    }
     h->finalized = true;
     return ACE355_OK;
 }

@@ -66,6 +66,75 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same norm with the per-column factors folded beforehand: y = bf16( (x * rstd) * g + sft ), g = w * (1 + sc1 + sc2),
+// sft = sh1 + sh2.  The five-vector form above reads 40 KB of (cached) vectors per 8 KB row and was bound by those loads
+// (19.4 us at M = 6000 against 14.1 us unmodulated); the DiT folds the vectors of all layers once per forward
+// (mod_gs_kernel) and streams x through this kernel: 8 consecutive columns per lane, one 16-byte store per 8 outputs.
+template <int NP>  // NP = D / 512 passes held in registers (0: generic two-pass)
+__global__ __launch_bounds__(256) void rmsnorm_gs_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ sft, bf16_t* __restrict__ y, int M, int D,
+                                                         float eps, long stride, int rows_per_seq) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* xr = x + (long)row * D;
+    float4 xa[NP > 0 ? NP : 1], xb[NP > 0 ? NP : 1];
+    float ss = 0.f;
+    if (NP > 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            xa[p] = *reinterpret_cast<const float4*>(xr + p * 512 + lane * 8);
+            xb[p] = *reinterpret_cast<const float4*>(xr + p * 512 + lane * 8 + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            ss += xa[p].x * xa[p].x + xa[p].y * xa[p].y + xa[p].z * xa[p].z + xa[p].w * xa[p].w + xb[p].x * xb[p].x + xb[p].y * xb[p].y +
+                  xb[p].z * xb[p].z + xb[p].w * xb[p].w;
+    } else {
+        for (int c = lane * 8; c < D; c += 512) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + c), b = *reinterpret_cast<const float4*>(xr + c + 4);
+            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    const long so = stride ? (long)(row / rows_per_seq) * stride : 0;
+    const float* gp = g + so;
+    const float* sp = sft ? sft + so : nullptr;
+    bf16_t* yr = y + (long)row * D;
+    auto emit = [&](int c, const float4 a, const float4 b) {
+        const float4 ga = *reinterpret_cast<const float4*>(gp + c), gb = *reinterpret_cast<const float4*>(gp + c + 4);
+        float o[8] = {(a.x * rstd) * ga.x, (a.y * rstd) * ga.y, (a.z * rstd) * ga.z, (a.w * rstd) * ga.w,
+                      (b.x * rstd) * gb.x, (b.y * rstd) * gb.y, (b.z * rstd) * gb.z, (b.w * rstd) * gb.w};
+        if (sp) {
+            const float4 sa = *reinterpret_cast<const float4*>(sp + c), sb = *reinterpret_cast<const float4*>(sp + c + 4);
+            o[0] += sa.x, o[1] += sa.y, o[2] += sa.z, o[3] += sa.w, o[4] += sb.x, o[5] += sb.y, o[6] += sb.z, o[7] += sb.w;
+        }
+        *reinterpret_cast<uint4*>(yr + c) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+    };
+    if (NP > 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) emit(p * 512 + lane * 8, xa[p], xb[p]);
+    } else {
+        for (int c = lane * 8; c < D; c += 512)
+            emit(c, *reinterpret_cast<const float4*>(xr + c), *reinterpret_cast<const float4*>(xr + c + 4));
+    }
+}
+// g / sft of every modulated norm of a forward in one launch.  entries[e] = {w, sc1, sh1, sc2_off, sh2_off}: the per-step
+// halves come from tproj[row * tp_stride + off + c].  out[(row * n_entries + e) * 2 * D + {0, D} + c].
+__global__ void mod_gs_kernel(const ModEntry* __restrict__ entries, int n_entries, const float* __restrict__ tproj, long tp_stride,
+                              float* __restrict__ out, int D) {
+    const int e = blockIdx.x, row = blockIdx.y;
+    const ModEntry me = entries[e];
+    const float* tp = tproj + (long)row * tp_stride;
+    float* o = out + ((long)row * n_entries + e) * 2 * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        o[c] = me.w[c] * (1.f + (me.sc1[c] + tp[me.sc2_off + c]));
+        o[D + c] = me.sh1[c] + tp[me.sh2_off + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // In-place per-head RMSNorm(128) (+ RoPE, rotate-half form) on bf16 x[M, ld], heads at col0 + h*128.
 // 16 lanes per head: lane j holds d = 4j..4j+3 and 64+4j..64+4j+3 (the rotate_half partners).
 __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__ x, int M, int ld, int col0, int heads,
@@ -529,9 +598,26 @@ int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, 
     ACE_CHECK(D % 4 == 0, "rmsnorm: D % 4");
     ACE_CHECK(!sc1 || (sc2 && sh1 && sh2 && rows_per_seq > 0), "rmsnorm: modulation needs all four vectors");
     const int rps = rows_per_seq > 0 ? rows_per_seq : 1;
+    if (!sc1 && D % 8 == 0) return launch_rmsnorm_gs(x, w, nullptr, y, M, D, eps, 0, rps, s);
     if (D == 2048) hipLaunchKernelGGL(rmsnorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     else if (D == 256) hipLaunchKernelGGL(rmsnorm_mod_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     else hipLaunchKernelGGL(rmsnorm_mod_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_rmsnorm_gs(const float* x, const float* g, const float* sft, bf16_t* y, int M, int D, float eps, long stride,
+                      int rows_per_seq, hipStream_t s) {
+    ACE_CHECK(D % 8 == 0 && stride % 4 == 0, "rmsnorm_gs: D % 8, stride % 4");
+    const int rps = rows_per_seq > 0 ? rows_per_seq : 1;
+    if (D == 2048) hipLaunchKernelGGL(rmsnorm_gs_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
+    else hipLaunchKernelGGL(rmsnorm_gs_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_mod_gs(const ModEntry* entries_dev, int n_entries, const float* tproj, long tp_stride, int rows, float* out, int D,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(mod_gs_kernel, dim3(n_entries, rows), dim3(256), 0, s, entries_dev, n_entries, tproj, tp_stride, out, D);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -204,7 +204,9 @@ def test_apg_euler(lib, gpu_device, B, T):
 
 @pytest.mark.parametrize("B,L,Cin,Cout,taps,dil,snake,res", [
     (2, 300, 128, 128, 7, 1, True, False), (1, 517, 128, 128, 7, 9, True, False), (2, 200, 256, 256, 7, 3, True, False),
-    (2, 300, 128, 128, 1, 1, True, True), (1, 40, 64, 2048, 7, 1, False, False), (1, 1000, 128, 2, 7, 1, True, False)])
+    (2, 300, 128, 128, 1, 1, True, True), (1, 40, 64, 2048, 7, 1, False, False), (1, 1000, 128, 2, 7, 1, True, False),
+    # >= 4096 workgroups at Cin >= 256: the launcher picks the 8-wave 256-row tile (ragged last tile: 66000 % 256 = 208)
+    (4, 66000, 256, 256, 7, 3, True, True)])
 def test_conv1d_nlc(lib, gpu_device, B, L, Cin, Cout, taps, dil, snake, res):
     from oracle import oobleck as o_vae
     g = torch.Generator().manual_seed(L + Cin + taps + dil)

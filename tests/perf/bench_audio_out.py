@@ -4,7 +4,7 @@ GPU path: normalize_audio_batch + AudioSaver.save_paths (GPU quantise/interleave
 CPU baseline ("port"): the reference's loop shape (inference.py:649-726) - per item .cpu(), oracle normalize_audio on the
 host, numpy quantise, then THIS library's FLAC encoder on one thread (libFLAC / libsndfile / torchaudio are absent, so the
 codec itself cannot be the reference's; the loop structure is).
-Usage: python tools/bench_audio_out.py [--batch 8] [--seconds 30] [--dir /dev/shm]"""
+Usage: python tests/perf/bench_audio_out.py [--batch 8] [--seconds 30] [--dir /dev/shm]"""
 import argparse
 import json
 import os
@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ace355.audio_out import AudioSaver, flac_encode_pcm16, normalize_audio_batch  # noqa: E402
 
 

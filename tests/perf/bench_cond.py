@@ -2,7 +2,7 @@
 """Condition-encoder timing at the product shape: B items x (256 text + 512 lyric tokens) + one 30 s
 reference clip (750 x 64 latent frames) per item.  Prints GPU ms per encode, achieved TFLOP/s, and the fp32 CPU oracle on
 a bounded sample of the same workload (one item) for the same box.
-Usage: python tools/bench_cond.py [--batch 8] [--no-cpu]"""
+Usage: python tests/perf/bench_cond.py [--batch 8] [--no-cpu]"""
 import argparse
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ace355  # noqa: E402
 from ace355 import weightgen  # noqa: E402
 from ace355.cond import NativeCondEncoder  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Detokenizer timing at the metric shape: B=8 songs x 150 five-Hz tokens (30 s) -> [8, 750, 64] hints,
 plus parity vs the fp32 oracle on a bounded sample and the oracle's CPU time on this box.
-Usage: python tools/bench_detok.py [--no-cpu]"""
+Usage: python tests/perf/bench_detok.py [--no-cpu]"""
 import argparse
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ace355  # noqa: E402
 from ace355 import weightgen  # noqa: E402
 from ace355.lmhints import NativeDetokenizer  # noqa: E402

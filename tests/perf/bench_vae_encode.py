@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """VAE encoder timing: B x 30 s of 48 kHz stereo -> [B, 64, 750] latents, with the achieved conv
 TFLOP/s from the library's HIP-event profile and the fp32 oracle on a bounded sample (CPU, same box).
-Usage: python tools/bench_vae_encode.py [--batch 8] [--seconds 30] [--no-cpu]"""
+Usage: python tests/perf/bench_vae_encode.py [--batch 8] [--seconds 30] [--no-cpu]"""
 import argparse
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ace355  # noqa: E402
 from ace355 import weightgen  # noqa: E402
 from ace355.vae import NativeVae  # noqa: E402

@@ -97,6 +97,13 @@ struct GemmEpilogue {
     int clk_probe;  // set by launch_gemm (ACE355_GEMM_CLK diagnostic)
     int ksplit;     // set by launch_gemm: > 1 = split-K (mode 2 only): blockIdx.y owns a K range and ADDS into H with fp32 atomics
     int wide_ok;  // set by launch_gemm: C / ldc / per-column vectors are 16-byte aligned, so the 16-byte staged epilogue may be used
+    // mode 4 (self-attention QKV projection with PACK_ROWS_HEADPAIR q / k rows): columns [0, hn_q_cols) are q heads, up to
+    // hn_qk_cols k heads, the rest v.  q / k leave the GEMM head-normed (weights hn_wq / hn_wk [128], eps hn_eps) and rotated
+    // (hn_cos / hn_sin [pos][64], pos = row % rows_per_seq) straight from the fp32 accumulators; v as in mode 0.  launch_gemm
+    // falls back to mode 0 + headnorm_rope_kernel(paired) for tile shapes whose waves do not pair up over a head.
+    const float *hn_wq, *hn_wk, *hn_cos, *hn_sin;
+    int hn_q_cols, hn_qk_cols;
+    float hn_eps;
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
@@ -134,7 +141,7 @@ int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const fl
                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s);
 // one launch for q heads [0,split) with weight w and k heads [split,heads) with weight w2 (contiguous columns)
 int launch_headnorm_rope2(bf16_t* x, int M, int ld, int col0, int heads, const float* w, const float* w2, int split, float eps,
-                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s);
+                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s, int paired = 0);
 // vt[n][h][d][s] (ld = s_pad) <- x[(n*S + s)*ld + col0 + h*128 + d]
 int launch_transpose_v(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf16_t* vt, int s_pad, hipStream_t s);
 int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s);
@@ -174,7 +181,10 @@ int launch_interleave(const float* wav, int B, int C, long S, void* out, int as_
 int launch_latent_check(const float* x, long n, int* flags_dev, hipStream_t s);
 
 // generic pack: dst bf16 / f32 from src (f32 or bf16) with an index mapping
-enum PackMode { PACK_ROWS = 0, PACK_ROWS_IL32 = 1, PACK_CONV_IN = 2, PACK_CONVT_OUT = 3 };
+// PACK_ROWS_HEADPAIR: rows of a [heads*128, cols] projection land so that the rotate-half partners (d, d+64) of every head
+// are neighbours: dst row = head*128 + (d < 64 ? 2d : 2(d-64)+1).  q.k is invariant under a common permutation of the head
+// dims, and RoPE / head-norm become local to 2 / 128 adjacent columns (see headnorm_rope_kernel's `paired` form).
+enum PackMode { PACK_ROWS = 0, PACK_ROWS_IL32 = 1, PACK_CONV_IN = 2, PACK_CONVT_OUT = 3, PACK_ROWS_HEADPAIR = 4 };
 int launch_pack(const void* src, int src_dtype, void* dst, int dst_is_bf16, int mode, long rows, long cols, long dst_ld,
                 long dst_row0, int p0, int p1, hipStream_t s);
 

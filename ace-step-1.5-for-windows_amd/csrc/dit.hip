@@ -116,8 +116,9 @@ bool resolve(ace355_dit* h, const std::string& name, Dest* d) {
         if (r == "self_attn_norm.weight") return rows(L.n_sa, 0, 1, D, D, 0);
         if (r == "cross_attn_norm.weight") return rows(L.n_ca, 0, 1, D, D, 0);
         if (r == "mlp_norm.weight") return rows(L.n_mlp, 0, 1, D, D, 0);
-        if (r == "self_attn.q_proj.weight") return rows(L.wqkv, 1, QD, D, D, 0);
-        if (r == "self_attn.k_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD);
+        // self-attention q / k rows in the head-pair order (common.h PackMode): RoPE partners adjacent
+        if (r == "self_attn.q_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, QD, D, D, 0, 0, 0}; return true; }
+        if (r == "self_attn.k_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, KVD, D, D, QD, 0, 0}; return true; }
         if (r == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
         if (r == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
         if (r == "self_attn.q_norm.weight") return rows(L.qn_s, 0, 1, 128, 128, 0);
@@ -297,10 +298,11 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, M, D, eps,
                                gs_stride, S, s);
         if (rc) return rc;
-        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        // QKV projection with q / k head-norm + RoPE in its epilogue (mode 4; launch_gemm falls back to two kernels)
+        ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};
+        ep.hn_wq = W.qn_s, ep.hn_wk = W.kn_s, ep.hn_cos = h->rope_cos, ep.hn_sin = h->rope_sin;
+        ep.hn_q_cols = QD, ep.hn_qk_cols = QD + KVD, ep.hn_eps = eps;
         rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
-        if (rc) return rc;
-        rc = launch_headnorm_rope2(h->qkv, M, QKV, 0, h->HQ + h->KVH, W.qn_s, W.kn_s, h->HQ, eps, h->rope_cos, h->rope_sin, S, s);
         if (rc) return rc;
         rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
         if (rc) return rc;

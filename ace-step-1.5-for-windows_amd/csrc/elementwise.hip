@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__
                                                             const float* __restrict__ w, const float* __restrict__ w2, int split,
                                                             float eps,
                                                             const float* __restrict__ cos_tab,
-                                                            const float* __restrict__ sin_tab, int S) {
+                                                            const float* __restrict__ sin_tab, int S, int paired) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long unit = gid >> 4;  // (row, head)
     const int j = threadIdx.x & 15;
@@ -149,14 +149,24 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__
     const bool ok = unit < total;
     const int row = ok ? (int)(unit / heads) : 0;
     const int head = ok ? (int)(unit - (long)row * heads) : 0;
-    bf16_t* p = x + (long)row * ld + col0 + head * 128 + j * 4;
+    // paired layout (PACK_ROWS_HEADPAIR projections): dims d and d+64 sit in columns 2d and 2d+1, so lane j's eight values
+    // are one 16-byte access; the arithmetic below is the same in both layouts
+    bf16_t* p = x + (long)row * ld + col0 + head * 128 + (paired ? j * 8 : j * 4);
     uint2 lo = make_uint2(0, 0), hi = make_uint2(0, 0);
-    if (ok) {
-        lo = *reinterpret_cast<const uint2*>(p);
-        hi = *reinterpret_cast<const uint2*>(p + 64);
+    float a[4], b[4];
+    if (paired) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) v = *reinterpret_cast<const uint4*>(p);
+        a[0] = bf_lo(v.x), b[0] = bf_hi(v.x), a[1] = bf_lo(v.y), b[1] = bf_hi(v.y);
+        a[2] = bf_lo(v.z), b[2] = bf_hi(v.z), a[3] = bf_lo(v.w), b[3] = bf_hi(v.w);
+    } else {
+        if (ok) {
+            lo = *reinterpret_cast<const uint2*>(p);
+            hi = *reinterpret_cast<const uint2*>(p + 64);
+        }
+        a[0] = bf_lo(lo.x), a[1] = bf_hi(lo.x), a[2] = bf_lo(lo.y), a[3] = bf_hi(lo.y);
+        b[0] = bf_lo(hi.x), b[1] = bf_hi(hi.x), b[2] = bf_lo(hi.y), b[3] = bf_hi(hi.y);
     }
-    float a[4] = {bf_lo(lo.x), bf_hi(lo.x), bf_lo(lo.y), bf_hi(lo.y)};
-    float b[4] = {bf_lo(hi.x), bf_hi(hi.x), bf_lo(hi.y), bf_hi(hi.y)};
     float ss = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) ss += a[e] * a[e] + b[e] * b[e];
@@ -181,7 +191,9 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__
             b[e] = hi_;
         }
     }
-    if (ok) {
+    if (ok && paired) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf2(a[0], b[0]), pack_bf2(a[1], b[1]), pack_bf2(a[2], b[2]), pack_bf2(a[3], b[3]));
+    } else if (ok) {
         *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
         *reinterpret_cast<uint2*>(p + 64) = make_uint2(pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3]));
     }
@@ -536,6 +548,9 @@ __global__ void pack_kernel(const SRC* __restrict__ src, void* __restrict__ dst,
         di = (dst_row0 + r) * dst_ld + c;
     } else if (mode == PACK_ROWS_IL32) {
         di = (dst_row0 + (r >> 5) * 64 + p0 * 32 + (r & 31)) * dst_ld + c;
+    } else if (mode == PACK_ROWS_HEADPAIR) {
+        const long d = r & 127;
+        di = (dst_row0 + (r - d) + (d < 64 ? 2 * d : 2 * (d - 64) + 1)) * dst_ld + c;
     } else if (mode == PACK_CONV_IN) {  // src [O][C][P] -> dst[o][p*C + c]
         const long cc = c / p1, pp = c - cc * p1;
         di = (dst_row0 + r) * dst_ld + pp * p0 + cc;
@@ -646,10 +661,11 @@ int launch_expand_add(const float* emb, const float* special, float* out, long r
 }
 
 int launch_headnorm_rope2(bf16_t* x, int M, int ld, int col0, int heads, const float* w, const float* w2, int split, float eps,
-                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s) {
+                          const float* cos_tab, const float* sin_tab, int S, hipStream_t s, int paired) {
+    ACE_CHECK(!paired || (ld % 8 == 0 && col0 % 8 == 0), "headnorm_rope: the paired layout uses 16-byte accesses");
     const long threads = (long)M * heads * 16;
     hipLaunchKernelGGL(headnorm_rope_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, x, M, ld, col0, heads, w, w2, split, eps,
-                       cos_tab, sin_tab, S > 0 ? S : 1);
+                       cos_tab, sin_tab, S > 0 ? S : 1, paired);
     ACE_LAUNCH_CHECK();
     return 0;
 }
@@ -657,7 +673,7 @@ int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const fl
                          const float* sin_tab, int S, hipStream_t s) {
     const long threads = (long)M * heads * 16;
     hipLaunchKernelGGL(headnorm_rope_kernel, dim3(blocks_for(threads, 256)), dim3(256), 0, s, x, M, ld, col0, heads, w, w, heads, eps,
-                       cos_tab, sin_tab, S > 0 ? S : 1);
+                       cos_tab, sin_tab, S > 0 ? S : 1, 0);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -51,15 +51,60 @@ __device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cas
 
 template <int MODE, int MT, int NTW, bool ROWS_FULL>
 __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
-                                                   int M, const GemmEpilogue& ep, int mw0, int nw0, int lane) {
+                                                   int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
+                                                   int wave = 0) {
     const int frow = lane & 31, fhalf = lane >> 5;
-    if constexpr (MODE == 0 || MODE == 3) {
+    if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
+        // mode 4, q / k tiles (workgroup-uniform): per-row sum of squares over the head's 128 columns = this wave's 64 (two
+        // half-rows in lanes l and l^32) + the neighbouring wave's 64, swapped through `xw`; then w * (v * rstd) and the
+        // rotation of the adjacent (d, d+64) pairs, all on the fp32 accumulators (one bf16 rounding instead of two)
+        float rstd[MT];
+        const bool hn = (MODE == 4) && (nw0 < ep.hn_qk_cols);
+        const float* hw = nullptr;
+        if constexpr (MODE == 4) {
+            static_assert(MODE != 4 || NTW == 2, "head epilogue: a wave pair covers one 128-column head");
+            if (hn) {
+                hw = (nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk;
+                float ss[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) a += acc[i][j][r] * acc[i][j][r];
+                    ss[i] = a + __shfl_xor(a, 32, 64);
+                    if (lane < 32) xw[wave * (MT * 32) + i * 32 + frow] = ss[i];
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < MT; ++i) rstd[i] = rsqrtf((ss[i] + xw[(wave ^ 1) * (MT * 32) + i * 32 + frow]) * (1.f / 128.f) + ep.hn_eps);
+            }
+        }
+        // lane's columns c = (nw0 & 127) + j*32 + 8g + 4*fhalf .. c+3 in pair order = dims (t, t+64), (t+1, t+65), t = c / 2.
+        // The norm weights are per column (every row-lane of a half reads the same address) and are applied here; the
+        // rotation needs cos / sin of (row, pair), which in THIS layout (lane = row) is a 256-byte-strided gather - 32 cache
+        // lines per load, +20 us per launch, the whole gain of the fusion - so it is applied in the read-back below, where 8
+        // lanes hold one row's 64 columns and read 128 contiguous bytes of the table row.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 hwl[8], hwh[8];
+        const int tb = (MODE == 4) ? (((nw0 & 127) + 4 * fhalf) >> 1) : 0;
+        if constexpr (MODE == 4) {
+            if (hn) {
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    hwl[q8] = *reinterpret_cast<const f32x2*>(hw + tb + (q8 >> 2) * 16 + (q8 & 3) * 4);
+                    hwh[q8] = *reinterpret_cast<const f32x2*>(hw + 64 + tb + (q8 >> 2) * 16 + (q8 & 3) * 4);
+                }
+            }
+        }
         static_assert(MODE != 3 || NTW == 2, "SwiGLU pairs two column tiles per wave");
         constexpr int NJ = (MODE == 3) ? 1 : NTW;   // 32-column groups in the staged image
         constexpr int RB = NJ * 64;                 // staged row bytes
         constexpr int J1 = NTW - 1;
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -72,9 +117,18 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         v3 = silu_f(acc[i][0][4 * g + 3]) * acc[i][J1][4 * g + 3];
                     } else {
                         v0 = acc[i][j][4 * g + 0]; v1 = acc[i][j][4 * g + 1]; v2 = acc[i][j][4 * g + 2]; v3 = acc[i][j][4 * g + 3];
-                        if (ep.bias) {
-                            const float4 b = ldf4(ep.bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
-                            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                        if constexpr (MODE != 4) {  // (the head epilogue takes no bias: launch_gemm checks)
+                            if (ep.bias) {
+                                const float4 b = ldf4(ep.bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+                                v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                            }
+                        }
+                        if constexpr (MODE == 4) {
+                            if (hn) {
+                                const int q8 = j * 4 + g;  // head-norm here (per-column weights broadcast over the rows) ...
+                                v0 = hwl[q8].x * (v0 * rstd[i]), v1 = hwh[q8].x * (v1 * rstd[i]);
+                                v2 = hwl[q8].y * (v2 * rstd[i]), v3 = hwh[q8].y * (v3 * rstd[i]);
+                            }
                         }
                     }
                     uint2 pk;
@@ -82,14 +136,28 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     pk.y = pack_bf2(v2, v3);
                     *reinterpret_cast<uint2*>(stg + stage_off<RB>(i * 32 + frow, j * 4 + g) + 8 * fhalf) = pk;
                 }
+        }
         constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per staged row, rows per store instruction
         const int rsub = lane / LPR, slot = lane % LPR;
         bf16_t* out = reinterpret_cast<bf16_t*>(Cv) + (MODE == 3 ? (nw0 >> 1) : nw0) + slot * 8;
 #pragma unroll
         for (int t = 0; t < MT * 32 / RPI; ++t) {
             const int row = t * RPI + rsub;
-            const uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
+            uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
             const int m = mw0 + row;
+            if constexpr (MODE == 4) {
+                if (hn) {  // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path)
+                    const long po = (long)(m % ep.rows_per_seq) * 64 + ((nw0 & 127) >> 1) + slot * 4;
+                    const float4 cs = ldf4(ep.hn_cos + po), sn = ldf4(ep.hn_sin + po);
+                    const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+                    uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = bf_lo(pv[e]), b = bf_hi(pv[e]);
+                        pv[e] = pack_bf2(a * c4[e] - b * s4[e], b * c4[e] + a * s4[e]);
+                    }
+                }
+            }
             if (ROWS_FULL || m < M) *reinterpret_cast<uint4*>(out + (long)m * ldc) = v;
         }
     } else {
@@ -212,7 +280,7 @@ __device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], voi
                 const int n = nw0 + nl;
                 if (n >= N) continue;
                 const float v = acc[i][j][r];
-                if (MODE == 0) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + (ep.bias ? ep.bias[n] : 0.f));
+                if (MODE == 0 || MODE == 4) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + (ep.bias ? ep.bias[n] : 0.f));  // (4: launch_gemm never sends the head epilogue here)
                 else if (MODE == 1) reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + (ep.bias ? ep.bias[n] : 0.f);
                 else {
                     float gate = 1.f;
@@ -236,8 +304,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();  // every wave is done reading operand fragments: the stages may be overwritten
         char* stg = smem + wave * (MT * 32 * 128);
-        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane);
-        else gemm_epilogue_wide<MODE, MT, NTW, false>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane);
+        float* xw = reinterpret_cast<float*>(smem + (bn / (NTW * 32)) * (bm / (MT * 32)) * (MT * 32 * 128));  // behind the last staging slice
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
+        else gemm_epilogue_wide<MODE, MT, NTW, false>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
     } else {
         gemm_epilogue_scalar<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
     }
@@ -392,7 +461,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     constexpr int AJ = BMv / (8 * NW);          // A DMA pieces per wave per tile (8 rows each)
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
-    constexpr int EPI_BYTES = NW * MT * 32 * 128;  // epilogue staging: MT*32 rows x 128 B per wave
+    constexpr int EPI_BYTES = NW * MT * 32 * 128 + NW * MT * 32 * 4;  // epilogue staging: MT*32 rows x 128 B per wave (+ mode 4's row sums)
     __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES];
 
     // Workgroup -> tile map.  Block b runs on XCD b % 8 (observed, speed only).  The 8 XCDs (private L2s) form an
@@ -609,9 +678,11 @@ static int env_int(const char* name, int dflt) {
 template <int MODE>
 static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc,
                         int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
-    if (variant == 1) {
-        hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
-        return;
+    if constexpr (MODE != 4) {
+        if (variant == 1) {
+            hipLaunchKernelGGL(gemm_kernel<MODE>, dim3(nwg), dim3(256), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+            return;
+        }
     }
     static int group_m = -1, xcd_m_env = -1, pers = 0, deep_env = 0;
     if (group_m < 0) {
@@ -639,7 +710,13 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.ksplit > 1 ? ep.ksplit : 1) <= 256;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
-    if (big == 2) {
+    if constexpr (MODE == 4) {  // head epilogue: only the 192x256 tile is instantiated (launch_gemm routes everything else to mode 0)
+        if (pers && region > 32) {
+            const dim3 pgrid(8 * 32);
+            hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
+                               xcd_m);
+        } else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+    } else if (big == 2) {
         static int mid_ns = -1;
         if (mid_ns < 0) mid_ns = env_int("ACE355_GEMM_MIDNS", 3);
         if constexpr (MODE != 3) {  // 192x128, 8 waves (wave tile 96x32); one workgroup per CU: 3 stages of 40 KB
@@ -663,7 +740,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     GemmEpilogue ep = ep_in;
     {
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        const int per16 = (ep.mode == 0 || ep.mode == 3) ? 8 : 4;  // elements of C per 16 bytes
+        const int per16 = (ep.mode == 0 || ep.mode == 3 || ep.mode == 4) ? 8 : 4;  // elements of C per 16 bytes
         ep.wide_ok = al16(C) && (ldc % per16) == 0 && al16(ep.bias) && al16(ep.g1) && al16(ep.g2) && al16(ep.cvec) &&
                      (ep.g2_stride % 4) == 0;
         if (env_int("ACE355_GEMM_SCALAR_EPI", 0)) ep.wide_ok = 0;  // A/B + test hook
@@ -720,6 +797,25 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         case 1: launch_mode<1>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         case 2: launch_mode<2>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         case 3: launch_mode<3>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
+        case 4: {
+            static int fuse = -1;
+            if (fuse < 0) fuse = env_int("ACE355_GEMM_HEADEPI", 1);  // 0: always mode 0 + the standalone kernel (A/B runs)
+            ACE_CHECK(ep.hn_wq && ep.hn_wk && ep.hn_cos && ep.hn_sin && ep.rows_per_seq > 0 && ep.hn_q_cols % 128 == 0 &&
+                      ep.hn_qk_cols % 128 == 0 && ep.hn_qk_cols <= N && !ep.bias, "gemm: head epilogue arguments");
+            const bool fused = fuse && variant != 1 && big == 1 && ep.wide_ok && N % 256 == 0 && ep.hn_q_cols % 256 == 0 &&
+                               ep.hn_qk_cols % 256 == 0;
+            if (fused) {
+                launch_mode<4>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+            } else {
+                ep.mode = 0;
+                launch_mode<0>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
+                ACE_LAUNCH_CHECK();
+                const int rc = launch_headnorm_rope2(reinterpret_cast<bf16_t*>(C), M, ldc, 0, ep.hn_qk_cols / 128, ep.hn_wq, ep.hn_wk,
+                                                     ep.hn_q_cols / 128, ep.hn_eps, ep.hn_cos, ep.hn_sin, ep.rows_per_seq, s, /*paired*/ 1);
+                if (rc) return rc;
+            }
+            break;
+        }
         default: ACE_CHECK(false, "gemm: bad epilogue mode");
     }
     ACE_LAUNCH_CHECK();

@@ -337,10 +337,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         if (Nc > 0) {
         rc = launch_rmsnorm_mod(h->h, W.n_ca, h->xn, Mc, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
         if (rc) return rc;
-        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};  // q head-norm in the epilogue (no RoPE on the cross path)
+        ep.hn_wq = ep.hn_wk = W.qn_c, ep.hn_cos = ep.hn_sin = nullptr;
+        ep.hn_q_cols = ep.hn_qk_cols = QD, ep.hn_eps = eps;
         rc = gemm(h, h->xn, D, W.wq_c, D, h->qkv, QD, Mc, QD, D, ep, s);
-        if (rc) return rc;
-        rc = launch_headnorm_rope(h->qkv, Mc, QD, 0, h->HQ, W.qn_c, eps, nullptr, nullptr, S, s);
         if (rc) return rc;
         {
             AttnArgs a{};

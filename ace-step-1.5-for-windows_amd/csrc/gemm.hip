@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         const bool hn = (MODE == 4) && (nw0 < ep.hn_qk_cols);
         const float* hw = nullptr;
         if constexpr (MODE == 4) {
-            static_assert(MODE != 4 || NTW == 2, "head epilogue: a wave pair covers one 128-column head");
+            constexpr int HW = 4 / NTW;  // waves per 128-column head: a pair (64 columns each) or all four N-waves of a 128-wide tile
             if (hn) {
                 hw = (nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk;
                 float ss[MT];
@@ -79,7 +79,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
-                for (int i = 0; i < MT; ++i) rstd[i] = rsqrtf((ss[i] + xw[(wave ^ 1) * (MT * 32) + i * 32 + frow]) * (1.f / 128.f) + ep.hn_eps);
+                for (int i = 0; i < MT; ++i) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int k = 0; k < HW; ++k) tot += xw[((wave & ~(HW - 1)) + k) * (MT * 32) + i * 32 + frow];
+                    rstd[i] = rsqrtf(tot * (1.f / 128.f) + ep.hn_eps);
+                }
             }
         }
         // lane's columns c = (nw0 & 127) + j*32 + 8g + 4*fhalf .. c+3 in pair order = dims (t, t+64), (t+1, t+65), t = c / 2.
@@ -88,14 +93,22 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         // lines per load, +20 us per launch, the whole gain of the fusion - so it is applied in the read-back below, where 8
         // lanes hold one row's 64 columns and read 128 contiguous bytes of the table row.
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 hwl[8], hwh[8];
-        const int tb = (MODE == 4) ? (((nw0 & 127) + 4 * fhalf) >> 1) : 0;
+        f32x2 hwl[NTW * 4], hwh[NTW * 4];
+        const bool rope = (MODE == 4) && ep.hn_cos != nullptr;  // no table: plain column order, norm only (cross-attention q)
+        const int cb = (MODE == 4) ? ((nw0 & 127) + 4 * fhalf) : 0;
         if constexpr (MODE == 4) {
             if (hn) {
 #pragma unroll
-                for (int q8 = 0; q8 < 8; ++q8) {
-                    hwl[q8] = *reinterpret_cast<const f32x2*>(hw + tb + (q8 >> 2) * 16 + (q8 & 3) * 4);
-                    hwh[q8] = *reinterpret_cast<const f32x2*>(hw + 64 + tb + (q8 >> 2) * 16 + (q8 & 3) * 4);
+                for (int q8 = 0; q8 < NTW * 4; ++q8) {
+                    const int c = cb + (q8 >> 2) * 32 + (q8 & 3) * 8;
+                    if (rope) {
+                        hwl[q8] = *reinterpret_cast<const f32x2*>(hw + (c >> 1));
+                        hwh[q8] = *reinterpret_cast<const f32x2*>(hw + 64 + (c >> 1));
+                    } else {
+                        const float4 w4 = ldf4(hw + c);
+                        hwl[q8] = f32x2{w4.x, w4.z};
+                        hwh[q8] = f32x2{w4.y, w4.w};
+                    }
                 }
             }
         }
@@ -146,7 +159,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
             uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
             const int m = mw0 + row;
             if constexpr (MODE == 4) {
-                if (hn) {  // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path)
+                if (hn && rope) {  // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path)
                     const long po = (long)(m % ep.rows_per_seq) * 64 + ((nw0 & 127) >> 1) + slot * 4;
                     const float4 cs = ldf4(ep.hn_cos + po), sn = ldf4(ep.hn_sin + po);
                     const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
@@ -710,8 +723,9 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.ksplit > 1 ? ep.ksplit : 1) <= 256;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
-    if constexpr (MODE == 4) {  // head epilogue: only the 192x256 tile is instantiated (launch_gemm routes everything else to mode 0)
-        if (pers && region > 32) {
+    if constexpr (MODE == 4) {  // head epilogue: only the two 8-wave tiles are instantiated (launch_gemm routes everything else to mode 0)
+        if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
+        else if (pers && region > 32) {
             const dim3 pgrid(8 * 32);
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
@@ -800,18 +814,22 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         case 4: {
             static int fuse = -1;
             if (fuse < 0) fuse = env_int("ACE355_GEMM_HEADEPI", 1);  // 0: always mode 0 + the standalone kernel (A/B runs)
-            ACE_CHECK(ep.hn_wq && ep.hn_wk && ep.hn_cos && ep.hn_sin && ep.rows_per_seq > 0 && ep.hn_q_cols % 128 == 0 &&
+            ACE_CHECK(ep.hn_wq && ep.hn_wk && (!ep.hn_cos == !ep.hn_sin) && ep.rows_per_seq > 0 && ep.hn_q_cols % 128 == 0 &&
                       ep.hn_qk_cols % 128 == 0 && ep.hn_qk_cols <= N && !ep.bias, "gemm: head epilogue arguments");
-            const bool fused = fuse && variant != 1 && big == 1 && ep.wide_ok && N % 256 == 0 && ep.hn_q_cols % 256 == 0 &&
-                               ep.hn_qk_cols % 256 == 0;
+            static int mid_ns4 = -1;
+            if (mid_ns4 < 0) mid_ns4 = env_int("ACE355_GEMM_MIDNS", 3);
+            const int tw = big == 1 ? 256 : 128;  // tile width: q | k | v boundaries must fall on tile edges
+            const bool fused = fuse && variant != 1 && (big == 1 || (big == 2 && mid_ns4 == 3)) && ep.wide_ok && N % tw == 0 &&
+                               ep.hn_q_cols % tw == 0 && ep.hn_qk_cols % tw == 0;
             if (fused) {
                 launch_mode<4>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
-            } else {
+            } else {  // two kernels; with a table the q / k columns are in head-pair order (PACK_ROWS_HEADPAIR), without in plain order
                 ep.mode = 0;
                 launch_mode<0>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
                 ACE_LAUNCH_CHECK();
                 const int rc = launch_headnorm_rope2(reinterpret_cast<bf16_t*>(C), M, ldc, 0, ep.hn_qk_cols / 128, ep.hn_wq, ep.hn_wk,
-                                                     ep.hn_q_cols / 128, ep.hn_eps, ep.hn_cos, ep.hn_sin, ep.rows_per_seq, s, /*paired*/ 1);
+                                                     ep.hn_q_cols / 128, ep.hn_eps, ep.hn_cos, ep.hn_sin, ep.rows_per_seq, s,
+                                                     /*paired*/ ep.hn_cos ? 1 : 0);
                 if (rc) return rc;
             }
             break;

@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void headnorm_rope_kernel(bf16_t* __restrict__
 // vt[n][h][d][s] = x[(n*S + s)*ld + col0 + h*128 + d]; pad keys s in [S, s_pad) are written as zero.
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ x, int ld, int col0, int S, int heads,
                                                           bf16_t* __restrict__ vt, int s_pad) {
-    __shared__ bf16_t tile[64][136];  // +8 pad: 272-B rows
+    // 16-byte chunks of a row are XOR-swizzled with (key >> 3): the transposed reads below walk keys 8 apart, which any
+    // 16-byte-aligned row pitch maps onto the same banks (the former +8 padding left them 8-way conflicted)
+    __shared__ bf16_t tile[64][128];
     const int s0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
     const int tid = threadIdx.x;
 #pragma unroll
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
         const int c = tid + i * 256, key = c >> 4, ch = c & 15;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (s0 + key < S) v = *reinterpret_cast<const uint4*>(x + ((long)n * S + s0 + key) * ld + col0 + h * 128 + ch * 8);
-        *reinterpret_cast<uint4*>(&tile[key][ch * 8]) = v;
+        *reinterpret_cast<uint4*>(&tile[key][(ch ^ ((key >> 3) & 7)) * 8]) = v;
     }
     __syncthreads();
     bf16_t* base = vt + ((long)n * heads + h) * 128 * s_pad;
@@ -220,7 +222,10 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
         const int c = tid + i * 256, d = c >> 3, kc = c & 7;
         uint32_t o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)tile[kc * 8 + 2 * e][d] | ((uint32_t)tile[kc * 8 + 2 * e + 1][d] << 16);
+        for (int e = 0; e < 4; ++e) {  // rows kc*8 .. kc*8+7 share (row >> 3) = kc
+            const int col = (((d >> 3) ^ kc) << 3) | (d & 7);
+            o[e] = (uint32_t)tile[kc * 8 + 2 * e][col] | ((uint32_t)tile[kc * 8 + 2 * e + 1][col] << 16);
+        }
         if (s0 + kc * 8 < s_pad) *reinterpret_cast<uint4*>(base + (long)d * s_pad + s0 + kc * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }

@@ -341,15 +341,18 @@ __global__ void copy_v_kernel(const float* __restrict__ vpad, float* __restrict_
 // One sampler step after the decoder forward (base.py:1946-1979 + apg_guidance.py:33-56):
 //   diff = cond - uncond; avg = diff + (-0.75) * avg_prev; d = avg * min(1, 2.5/||avg||_T)
 //   (fp64) u = cond/||cond||_T; orth = d - (d.u) u;  v = cond + (g-1) orth;  xt -= v * dt
-// reductions are over the T axis per (item, channel).  grid (B, 4), block 256 = 16 channels x 16 t-slices.
+// reductions are over the T axis per (item, channel).  grid (B, 16), block 256 = 4 channels x 64 t-slices.
 __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict__ v, long uncond_off, float* __restrict__ avg,
                                                         float* __restrict__ xt, bf16_t* __restrict__ xin, int copies, int B,
                                                         int T, int Tpad, float guidance, float dt, int apply_cfg, int do_cfg,
                                                         int first, StepUpdate up) {
-    __shared__ double red[3][16][16];
-    __shared__ double tot[3][16];
-    const int b = blockIdx.x, cl = threadIdx.x & 15, ts = threadIdx.x >> 4;
-    const int c = blockIdx.y * 16 + cl;
+    // block = CL channels x TS time slices: 4 x 64 spreads an item over 16 workgroups (B x 16 on the chip instead of B x 4;
+    // the kernel is a chain of three latency-bound passes over T, 87 -> ~30 us per step at B = 8)
+    constexpr int CL = 4, TS = 64;
+    __shared__ double red[3][TS][CL];
+    __shared__ double tot[3][CL];
+    const int b = blockIdx.x, cl = threadIdx.x % CL, ts = threadIdx.x / CL;
+    const int c = blockIdx.y * CL + cl;
     const float* vc = v + (long)b * Tpad * 64 + c;
     const float* vu = vc + uncond_off;
     float* av = avg + (long)b * T * 64 + c;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict_
     const bool guided = do_cfg && apply_cfg;
     double saa = 0, scc = 0, sac = 0;
     if (guided) {
-        for (int t = ts; t < T; t += 16) {
+        for (int t = ts; t < T; t += TS) {
             const float pc = vc[(long)t * 64], pu = vu[(long)t * 64];
             float a = pc - pu;
             if (!first) a = a + (-0.75f) * av[(long)t * 64];
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict_
         if (ts < 3) {
             double s = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s += red[ts][i][cl];
+            for (int i = 0; i < TS; ++i) s += red[ts][i][cl];
             tot[ts][cl] = s;
         }
         __syncthreads();
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict_
     if (guided) {
         // dot = sum_t (double)(float)(a*scale) * (cond/nc): needs a second reduction because d is rounded to fp32 first
         double sd = 0;
-        for (int t = ts; t < T; t += 16) {
+        for (int t = ts; t < T; t += TS) {
             const float d = av[(long)t * 64] * scale;
             sd += (double)d * ((double)vc[(long)t * 64] * inv_nc);
         }
@@ -400,13 +403,13 @@ __global__ __launch_bounds__(256) void apg_euler_kernel(const float* __restrict_
         if (ts == 0) {
             double s = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s += red[0][i][cl];
+            for (int i = 0; i < TS; ++i) s += red[0][i][cl];
             tot[0][cl] = s;
         }
         __syncthreads();
         dotf = tot[0][cl];
     }
-    for (int t = ts; t < T; t += 16) {
+    for (int t = ts; t < T; t += TS) {
         const float pc = vc[(long)t * 64];
         float vv = pc;
         if (guided) {
@@ -777,7 +780,7 @@ int launch_copy_v(const float* vpad, float* v, int N, int T, int Tpad, hipStream
 
 int launch_apg_euler(const float* v, long uncond_offset, float* avg, float* xt, bf16_t* xin, int copies, int B, int T, int Tpad,
                      float guidance, float dt, int apply_cfg, int do_cfg, int first, const StepUpdate& up, hipStream_t s) {
-    hipLaunchKernelGGL(apg_euler_kernel, dim3(B, 4), dim3(256), 0, s, v, uncond_offset, avg, xt, xin, copies, B, T, Tpad, guidance,
+    hipLaunchKernelGGL(apg_euler_kernel, dim3(B, 16), dim3(256), 0, s, v, uncond_offset, avg, xt, xin, copies, B, T, Tpad, guidance,
                        dt, apply_cfg, do_cfg, first, up);
     ACE_LAUNCH_CHECK();
     return 0;

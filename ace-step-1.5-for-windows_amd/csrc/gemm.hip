@@ -93,21 +93,28 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         // lines per load, +20 us per launch, the whole gain of the fusion - so it is applied in the read-back below, where 8
         // lanes hold one row's 64 columns and read 128 contiguous bytes of the table row.
         typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
         f32x2 hwl[NTW * 4], hwh[NTW * 4];
         const bool rope = (MODE == 4) && ep.hn_cos != nullptr;  // no table: plain column order, norm only (cross-attention q)
         const int cb = (MODE == 4) ? ((nw0 & 127) + 4 * fhalf) : 0;
         if constexpr (MODE == 4) {
             if (hn) {
+                // (the layout test stays outside the unrolled loops: a branch per element fences every load behind the
+                //  previous one's wait)
+                if (rope) {
 #pragma unroll
-                for (int q8 = 0; q8 < NTW * 4; ++q8) {
-                    const int c = cb + (q8 >> 2) * 32 + (q8 & 3) * 8;
-                    if (rope) {
+                    for (int q8 = 0; q8 < NTW * 4; ++q8) {
+                        const int c = cb + (q8 >> 2) * 32 + (q8 & 3) * 8;
                         hwl[q8] = *reinterpret_cast<const f32x2*>(hw + (c >> 1));
                         hwh[q8] = *reinterpret_cast<const f32x2*>(hw + 64 + (c >> 1));
-                    } else {
-                        const float4 w4 = ldf4(hw + c);
-                        hwl[q8] = f32x2{w4.x, w4.z};
-                        hwh[q8] = f32x2{w4.y, w4.w};
+                    }
+                } else {
+#pragma unroll
+                    for (int q8 = 0; q8 < NTW * 4; ++q8) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + cb + (q8 >> 2) * 32 + (q8 & 3) * 8);
+                        hwl[q8] = f32x2{w4[0], w4[2]};
+                        hwh[q8] = f32x2{w4[1], w4[3]};
                     }
                 }
             }
@@ -153,25 +160,43 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per staged row, rows per store instruction
         const int rsub = lane / LPR, slot = lane % LPR;
         bf16_t* out = reinterpret_cast<bf16_t*>(Cv) + (MODE == 3 ? (nw0 >> 1) : nw0) + slot * 8;
+        constexpr int NTI = MT * 32 / RPI;  // read-back iterations
+        if (MODE == 4 && hn && rope) {
+            // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path);
+            // table rows requested four iterations at a time, ahead of the arithmetic
+            constexpr int NB = NTI % 4 == 0 ? 4 : (NTI % 3 == 0 ? 3 : 1);
+            const int pc = ((nw0 & 127) >> 1) + slot * 4;
 #pragma unroll
-        for (int t = 0; t < MT * 32 / RPI; ++t) {
-            const int row = t * RPI + rsub;
-            uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
-            const int m = mw0 + row;
-            if constexpr (MODE == 4) {
-                if (hn && rope) {  // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path)
-                    const long po = (long)(m % ep.rows_per_seq) * 64 + ((nw0 & 127) >> 1) + slot * 4;
-                    const float4 cs = ldf4(ep.hn_cos + po), sn = ldf4(ep.hn_sin + po);
-                    const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
-                    uint32_t* pv = reinterpret_cast<uint32_t*>(&v);
+            for (int t0 = 0; t0 < NTI; t0 += NB) {
+                f32x4 cs[NB], sn[NB];
+                u32x4e v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int row = (t0 + u) * RPI + rsub;
+                    const long po = (long)((mw0 + row) % ep.rows_per_seq) * 64 + pc;
+                    cs[u] = *reinterpret_cast<const f32x4*>(ep.hn_cos + po);
+                    sn[u] = *reinterpret_cast<const f32x4*>(ep.hn_sin + po);
+                    v[u] = *reinterpret_cast<const u32x4e*>(stg + stage_off<RB>(row, slot));
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int m = mw0 + (t0 + u) * RPI + rsub;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float a = bf_lo(pv[e]), b = bf_hi(pv[e]);
-                        pv[e] = pack_bf2(a * c4[e] - b * s4[e], b * c4[e] + a * s4[e]);
+                        const float a = bf_lo(v[u][e]), b = bf_hi(v[u][e]);
+                        v[u][e] = pack_bf2(a * cs[u][e] - b * sn[u][e], b * cs[u][e] + a * sn[u][e]);
                     }
+                    if (ROWS_FULL || m < M) *reinterpret_cast<u32x4e*>(out + (long)m * ldc) = v[u];
                 }
             }
-            if (ROWS_FULL || m < M) *reinterpret_cast<uint4*>(out + (long)m * ldc) = v;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NTI; ++t) {
+                const int row = t * RPI + rsub;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
+                const int m = mw0 + row;
+                if (ROWS_FULL || m < M) *reinterpret_cast<uint4*>(out + (long)m * ldc) = v;
+            }
         }
     } else {
         constexpr int NT = MT * 4;  // 8-row groups per 32-column half

@@ -70,54 +70,65 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
 // sft = sh1 + sh2.  The five-vector form above reads 40 KB of (cached) vectors per 8 KB row and was bound by those loads
 // (19.4 us at M = 6000 against 14.1 us unmodulated); the DiT folds the vectors of all layers once per forward
 // (mod_gs_kernel) and streams x through this kernel: 8 consecutive columns per lane, one 16-byte store per 8 outputs.
-template <int NP>  // NP = D / 512 passes held in registers (0: generic two-pass)
+template <int NP, bool SHIFT>  // NP = D / 512 passes held in registers (0: generic two-pass); SHIFT: sft != nullptr
 __global__ __launch_bounds__(256) void rmsnorm_gs_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ sft, bf16_t* __restrict__ y, int M, int D,
                                                          float eps, long stride, int rows_per_seq) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* xr = x + (long)row * D;
-    float4 xa[NP > 0 ? NP : 1], xb[NP > 0 ? NP : 1];
-    float ss = 0.f;
-    if (NP > 0) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            xa[p] = *reinterpret_cast<const float4*>(xr + p * 512 + lane * 8);
-            xb[p] = *reinterpret_cast<const float4*>(xr + p * 512 + lane * 8 + 4);
-        }
-#pragma unroll
-        for (int p = 0; p < NP; ++p)
-            ss += xa[p].x * xa[p].x + xa[p].y * xa[p].y + xa[p].z * xa[p].z + xa[p].w * xa[p].w + xb[p].x * xb[p].x + xb[p].y * xb[p].y +
-                  xb[p].z * xb[p].z + xb[p].w * xb[p].w;
-    } else {
-        for (int c = lane * 8; c < D; c += 512) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + c), b = *reinterpret_cast<const float4*>(xr + c + 4);
-            ss += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
-        }
-    }
-    ss = wave_sum(ss);
-    const float rstd = rsqrtf(ss / (float)D + eps);
     const long so = stride ? (long)(row / rows_per_seq) * stride : 0;
     const float* gp = g + so;
-    const float* sp = sft ? sft + so : nullptr;
+    const float* sp = SHIFT ? sft + so : nullptr;
     bf16_t* yr = y + (long)row * D;
-    auto emit = [&](int c, const float4 a, const float4 b) {
-        const float4 ga = *reinterpret_cast<const float4*>(gp + c), gb = *reinterpret_cast<const float4*>(gp + c + 4);
-        float o[8] = {(a.x * rstd) * ga.x, (a.y * rstd) * ga.y, (a.z * rstd) * ga.z, (a.w * rstd) * ga.w,
-                      (b.x * rstd) * gb.x, (b.y * rstd) * gb.y, (b.z * rstd) * gb.z, (b.w * rstd) * gb.w};
-        if (sp) {
-            const float4 sa = *reinterpret_cast<const float4*>(sp + c), sb = *reinterpret_cast<const float4*>(sp + c + 4);
-            o[0] += sa.x, o[1] += sa.y, o[2] += sa.z, o[3] += sa.w, o[4] += sb.x, o[5] += sb.y, o[6] += sb.z, o[7] += sb.w;
+    auto emit = [&](int c, const f32x4 a, const f32x4 b, const f32x4 ga, const f32x4 gb, const f32x4 sa, const f32x4 sb, float rstd) {
+        float o[8] = {(a[0] * rstd) * ga[0], (a[1] * rstd) * ga[1], (a[2] * rstd) * ga[2], (a[3] * rstd) * ga[3],
+                      (b[0] * rstd) * gb[0], (b[1] * rstd) * gb[1], (b[2] * rstd) * gb[2], (b[3] * rstd) * gb[3]};
+        if (SHIFT) {
+            o[0] += sa[0], o[1] += sa[1], o[2] += sa[2], o[3] += sa[3], o[4] += sb[0], o[5] += sb[1], o[6] += sb[2], o[7] += sb[3];
         }
         *reinterpret_cast<uint4*>(yr + c) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
     };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     if (NP > 0) {
+        // every load of the row - x and the (cached) per-column vectors - is requested before the reduction: with the vector
+        // loads left after it, and a run-time `if (shift)` between them, each pass paid its own L2 round trip
+        f32x4 xa[NP > 0 ? NP : 1], xb[NP > 0 ? NP : 1], ga[NP > 0 ? NP : 1], gb[NP > 0 ? NP : 1], sa[NP > 0 ? NP : 1], sb[NP > 0 ? NP : 1];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) emit(p * 512 + lane * 8, xa[p], xb[p]);
+        for (int p = 0; p < NP; ++p) {
+            xa[p] = *reinterpret_cast<const f32x4*>(xr + p * 512 + lane * 8);
+            xb[p] = *reinterpret_cast<const f32x4*>(xr + p * 512 + lane * 8 + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            ga[p] = *reinterpret_cast<const f32x4*>(gp + p * 512 + lane * 8);
+            gb[p] = *reinterpret_cast<const f32x4*>(gp + p * 512 + lane * 8 + 4);
+            sa[p] = SHIFT ? *reinterpret_cast<const f32x4*>(sp + p * 512 + lane * 8) : z4;
+            sb[p] = SHIFT ? *reinterpret_cast<const f32x4*>(sp + p * 512 + lane * 8 + 4) : z4;
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+            ss += xa[p][0] * xa[p][0] + xa[p][1] * xa[p][1] + xa[p][2] * xa[p][2] + xa[p][3] * xa[p][3] + xb[p][0] * xb[p][0] +
+                  xb[p][1] * xb[p][1] + xb[p][2] * xb[p][2] + xb[p][3] * xb[p][3];
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)D + eps);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) emit(p * 512 + lane * 8, xa[p], xb[p], ga[p], gb[p], sa[p], sb[p], rstd);
     } else {
+        float ss = 0.f;
+        for (int c = lane * 8; c < D; c += 512) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(xr + c), b = *reinterpret_cast<const f32x4*>(xr + c + 4);
+            ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)D + eps);
         for (int c = lane * 8; c < D; c += 512)
-            emit(c, *reinterpret_cast<const float4*>(xr + c), *reinterpret_cast<const float4*>(xr + c + 4));
+            emit(c, *reinterpret_cast<const f32x4*>(xr + c), *reinterpret_cast<const f32x4*>(xr + c + 4), *reinterpret_cast<const f32x4*>(gp + c),
+                 *reinterpret_cast<const f32x4*>(gp + c + 4), SHIFT ? *reinterpret_cast<const f32x4*>(sp + c) : z4,
+                 SHIFT ? *reinterpret_cast<const f32x4*>(sp + c + 4) : z4, rstd);
     }
 }
 // g / sft of every modulated norm of a forward in one launch.  entries[e] = {w, sc1, sh1, sc2_off, sh2_off}: the per-step
@@ -633,8 +644,11 @@ int launch_rmsnorm_gs(const float* x, const float* g, const float* sft, bf16_t* 
                       int rows_per_seq, hipStream_t s) {
     ACE_CHECK(D % 8 == 0 && stride % 4 == 0, "rmsnorm_gs: D % 8, stride % 4");
     const int rps = rows_per_seq > 0 ? rows_per_seq : 1;
-    if (D == 2048) hipLaunchKernelGGL(rmsnorm_gs_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
-    else hipLaunchKernelGGL(rmsnorm_gs_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
+    const dim3 grid((M + 3) / 4);
+    if (D == 2048 && sft) hipLaunchKernelGGL((rmsnorm_gs_kernel<4, true>), grid, dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
+    else if (D == 2048) hipLaunchKernelGGL((rmsnorm_gs_kernel<4, false>), grid, dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
+    else if (sft) hipLaunchKernelGGL((rmsnorm_gs_kernel<0, true>), grid, dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
+    else hipLaunchKernelGGL((rmsnorm_gs_kernel<0, false>), grid, dim3(256), 0, s, x, g, sft, y, M, D, eps, stride, rps);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -748,13 +748,17 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.ksplit > 1 ? ep.ksplit : 1) <= 256;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
-    if constexpr (MODE == 4) {  // head epilogue: only the two 8-wave tiles are instantiated (launch_gemm routes everything else to mode 0)
+    if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
         if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
-        else if (pers && region > 32) {
+        else if (big && pers && region > 32) {
             const dim3 pgrid(8 * 32);
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
-        } else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+        } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+        else if (deep && mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 2, 0, 3>), 256);
+        else if (deep) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 4>), 256);
+        else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
+        else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2>), 256);
     } else if (big == 2) {
         static int mid_ns = -1;
         if (mid_ns < 0) mid_ns = env_int("ACE355_GEMM_MIDNS", 3);
@@ -844,8 +848,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
             static int mid_ns4 = -1;
             if (mid_ns4 < 0) mid_ns4 = env_int("ACE355_GEMM_MIDNS", 3);
             const int tw = big == 1 ? 256 : 128;  // tile width: q | k | v boundaries must fall on tile edges
-            const bool fused = fuse && variant != 1 && (big == 1 || (big == 2 && mid_ns4 == 3)) && ep.wide_ok && N % tw == 0 &&
-                               ep.hn_q_cols % tw == 0 && ep.hn_qk_cols % tw == 0;
+            const bool fused = fuse && variant != 1 && (big != 2 || mid_ns4 == 3) && ep.wide_ok && N % tw == 0 && ep.hn_q_cols % tw == 0 &&
+                               ep.hn_qk_cols % tw == 0;
             if (fused) {
                 launch_mode<4>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
             } else {  // two kernels; with a table the q / k columns are in head-pair order (PACK_ROWS_HEADPAIR), without in plain order

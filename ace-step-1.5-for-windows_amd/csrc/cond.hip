@@ -129,8 +129,9 @@ bool resolve(ace355_cond* h, const std::string& name, Dest* d) {
         const std::string q = r.substr(dot + 1);
         if (q == "input_layernorm.weight") return rows(L.n_in, 0, 1, D, D, 0);
         if (q == "post_attention_layernorm.weight") return rows(L.n_post, 0, 1, D, D, 0);
-        if (q == "self_attn.q_proj.weight") return rows(L.wqkv, 1, QD, D, D, 0);
-        if (q == "self_attn.k_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD);
+        // q / k rows in head-pair order for the QKV GEMM's head epilogue (common.h PackMode, gemm.hip mode 4)
+        if (q == "self_attn.q_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, QD, D, D, 0, 0, false}; return true; }
+        if (q == "self_attn.k_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, KVD, D, D, QD, 0, false}; return true; }
         if (q == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
         if (q == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
         if (q == "self_attn.q_norm.weight") return rows(L.qn, 0, 1, 128, 128, 0);
@@ -200,10 +201,10 @@ int encoder_layers(EncBase* h, const EncoderW& E, int N, int S, const int* kv_le
         // self attention (base.py:414-427)
         rc = launch_rmsnorm_mod(h->h, W.n_in, h->xn, M, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
         if (rc) return rc;
-        ep = GemmEpilogue{0, nullptr, nullptr, nullptr, 0, 0};
+        ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};  // q / k head-norm + RoPE in the epilogue, as in the DiT
+        ep.hn_wq = W.qn, ep.hn_wk = W.kn, ep.hn_cos = h->rope_cos, ep.hn_sin = h->rope_sin;
+        ep.hn_q_cols = QD, ep.hn_qk_cols = QD + KVD, ep.hn_eps = eps;
         rc = launch_gemm(h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
-        if (rc) return rc;
-        rc = launch_headnorm_rope2(h->qkv, M, QKV, 0, h->HQ + h->KVH, W.qn, W.kn, h->HQ, eps, h->rope_cos, h->rope_sin, S, s);
         if (rc) return rc;
         rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
         if (rc) return rc;
@@ -477,8 +478,9 @@ bool resolve_detok(ace355_detok* h, const std::string& name, Dest* d) {
     const std::string q = name.substr(dot + 1);
     if (q == "input_layernorm.weight") return rows(L.n_in, 0, 1, D, D, 0);
     if (q == "post_attention_layernorm.weight") return rows(L.n_post, 0, 1, D, D, 0);
-    if (q == "self_attn.q_proj.weight") return rows(L.wqkv, 1, QD, D, D, 0);
-    if (q == "self_attn.k_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD);
+    // q / k rows in head-pair order for the QKV GEMM's head epilogue (common.h PackMode, gemm.hip mode 4)
+    if (q == "self_attn.q_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, QD, D, D, 0, 0, false}; return true; }
+    if (q == "self_attn.k_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, KVD, D, D, QD, 0, false}; return true; }
     if (q == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
     if (q == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
     if (q == "self_attn.q_norm.weight") return rows(L.qn, 0, 1, 128, 128, 0);

@@ -308,3 +308,39 @@ def test_turbo_sampler_vs_reference_golden(gpu_device, golden_dir, name):
     r = _rel(out, t(f"{name}_out"))
     print(f"turbo sampler {name}: rel L2 vs the turbo reference (fp32 CPU) = {r:.3e}")
     assert r < 1e-2, r
+
+
+def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_path):
+    """The QKV / cross-q GEMMs norm and rotate q, k in their epilogue (gemm.hip mode 4); tile shapes without that form, the v1
+    kernel and ACE355_GEMM_HEADEPI=0 take GEMM + headnorm_rope_kernel(paired) instead.  Both must read the head-pair packing
+    the same way: the reference golden forward is run in two fresh processes, one per path (the switch is read once per
+    process), and each is held to the golden's tolerance and to the other."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import ace355\n"
+        "from ace355 import weightgen\n"
+        "from ace355.dit import NativeDit\n"
+        "G = np.load(%r)\n"
+        "cfg = ace355.DitConfig(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,\n"
+        "                       head_dim=128, sliding_window=int(G['a_window']))\n"
+        "dit = NativeDit(cfg, 'cuda:0')\n"
+        "dit.load_state_dict(weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=int(G['seed']), mode='test'))\n"
+        "x, ctx, enc, t = (torch.from_numpy(G['a_' + k]) for k in ('x', 'ctx', 'enc', 't'))\n"
+        "for n in range(x.shape[0]): dit.set_condition(n, enc[n])\n"
+        "v = dit.forward(x, ctx, t.tolist(), t.tolist(), list(range(x.shape[0])))\n"
+        "np.save(sys.argv[1], v.float().cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f"{golden_dir}/g2_tiny_forward.npz")
+    outs = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"v{flag}.npy")
+        env = dict(os.environ, ACE355_GEMM_HEADEPI=flag)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+        outs[flag] = torch.from_numpy(np.load(out))
+    ref = torch.from_numpy(np.load(f"{golden_dir}/g2_tiny_forward.npz")["a_v"])
+    r1, r0, rx = _rel(outs["1"], ref), _rel(outs["0"], ref), _rel(outs["1"], outs["0"])
+    print(f"head epilogue: fused vs reference {r1:.3e}, two-kernel vs reference {r0:.3e}, fused vs two-kernel {rx:.3e}")
+    assert r1 < 2e-2 and r0 < 2e-2 and rx < 1e-2, (r1, r0, rx)

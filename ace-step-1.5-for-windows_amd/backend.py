@@ -106,6 +106,17 @@ class NativeDitMixin:
         ts_list = None
         if timesteps is not None:
             ts_list = timesteps.tolist() if hasattr(timesteps, "tolist") else list(timesteps)
+        if bool(getattr(getattr(self, "config", None), "is_turbo", False)):
+            # turbo checkpoints (handler init_service_catalog.py:69-73 `is_turbo_model`): the model's own generate_audio has no
+            # CFG / step count, only the shift -> 8-step table (turbo modeling file :1780-1995); same native loop
+            from .dit import generate_latents_turbo
+            out = generate_latents_turbo(
+                self.native_dit, encoder_hidden_states, context_latents, seed=seed, shift=shift, timesteps=ts_list,
+                infer_method=infer_method, audio_cover_strength=audio_cover_strength, cover_noise_strength=cover_noise_strength,
+                src_latents=src_latents, encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
+                context_latents_non_cover=context_latents_non_cover)
+            out["target_latents"] = out["target_latents"].to(device=self.device, dtype=self.dtype)
+            return out
         from .dit import generate_latents
         out = generate_latents(
             self.native_dit, self.model.null_condition_emb.detach(), encoder_hidden_states, context_latents, seed=seed,

@@ -95,6 +95,32 @@ def test_native_run_diffusion_validation_mirrors_mlx_seam():
         h3._native_run_diffusion(**_args())
 
 
+def test_native_run_diffusion_routes_turbo_checkpoints(monkeypatch):
+    """config.is_turbo (handler init_service_catalog.py:69-73) selects the turbo model's loop: shift -> table, no CFG knobs."""
+    import types
+    from ace355 import dit as a_dit
+    calls = {}
+
+    def fake_turbo(native, enc, ctx, **kw):
+        calls["turbo"] = kw
+        return {"target_latents": torch.zeros(enc.shape[0], ctx.shape[1], 64), "time_costs": {}}
+
+    def fake_base(native, null, enc, ctx, **kw):
+        calls["base"] = kw
+        return {"target_latents": torch.zeros(enc.shape[0], ctx.shape[1], 64), "time_costs": {}}
+
+    monkeypatch.setattr(a_dit, "generate_latents_turbo", fake_turbo)
+    monkeypatch.setattr(a_dit, "generate_latents", fake_base)
+    h = _DitHost()
+    h.config = types.SimpleNamespace(is_turbo=True)
+    out = h._native_run_diffusion(**_args(), shift=2.0, infer_steps=50, guidance_scale=9.0)
+    assert "turbo" in calls and "base" not in calls and calls["turbo"]["shift"] == 2.0 and "infer_steps" not in calls["turbo"]
+    assert out["target_latents"].shape == (2, 6, 64)
+    h.config = types.SimpleNamespace(is_turbo=False)
+    h._native_run_diffusion(**_args(), infer_steps=27)
+    assert calls["base"]["infer_steps"] == 27
+
+
 def test_init_native_refuses_lora_quant_offload_and_never_raises():
     for flag in ("use_lora", "quantization", "offload_to_cpu"):
         h = _DitHost()

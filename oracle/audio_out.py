@@ -227,3 +227,122 @@ def flac_decode(data: bytes) -> Tuple[np.ndarray, Dict]:
     if info["bps"] == 16 and info["md5"] != bytes(16):
         assert hashlib.md5(pcm.astype("<i2").tobytes()).digest() == info["md5"], "STREAMINFO MD5"
     return pcm, info
+
+
+# ---------------------------------------------------------------------------------------------------- test-stream writer
+class _BitsOut:
+    def __init__(self):
+        self.b, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, v: int, n: int):
+        if n == 0:
+            return
+        self.acc = (self.acc << n) | (v & ((1 << n) - 1))
+        self.n += n
+        while self.n >= 8:
+            self.n -= 8
+            self.b.append((self.acc >> self.n) & 0xFF)
+        self.acc &= (1 << self.n) - 1
+
+    def align(self):
+        if self.n:
+            self.put(0, 8 - self.n)
+
+
+def flac_encode_test_stream(pcm: np.ndarray, sample_rate: int = 44100, block: int = 1152, lpc_order: int = 4, precision: int = 12,
+                            rice2: bool = False, escape_first_partition: bool = False, wasted: int = 0, variable_blocks: bool = False) -> bytes:
+    """A deliberately different FLAC writer (RFC 9639 features the native encoder never emits: LPC subframes with quantised
+    coefficients, 5-bit Rice parameters, an escaped partition, wasted bits, 1152-sample blocks, sample-number frame headers) so
+    that the native DECODER is exercised on streams it did not write.  pcm int [frames, channels] (independent channels)."""
+    pcm = np.asarray(pcm, dtype=np.int64)
+    frames, ch = pcm.shape
+    bps = 16
+    out = bytearray(b"fLaC")
+    si = _BitsOut()
+    si.put(0x80, 8), si.put(34, 24)
+    si.put(block if not variable_blocks else 16, 16), si.put(block, 16), si.put(0, 24), si.put(0, 24)
+    si.put(sample_rate, 20), si.put(ch - 1, 3), si.put(bps - 1, 5), si.put(frames, 36)
+    for byte in hashlib.md5(pcm.astype("<i2").tobytes()).digest():
+        si.put(byte, 8)
+    out += si.b
+    pos, fno = 0, 0
+    while pos < frames:
+        n = min(block if not variable_blocks else max(16, block >> (fno % 3)), frames - pos)
+        fr = _BitsOut()
+        fr.put(0x3FFE, 14), fr.put(0, 1), fr.put(1 if variable_blocks else 0, 1)
+        fr.put(7, 4)                                     # 16-bit block size at the end of the header
+        fr.put({44100: 9, 48000: 10}.get(sample_rate, 0), 4)
+        fr.put(ch - 1, 4), fr.put(4, 3), fr.put(0, 1)
+        num = pos if variable_blocks else fno            # UTF-8-like coded number
+        if num < 0x80:
+            fr.put(num, 8)
+        else:
+            nb = 2
+            while nb < 7 and (num >> (5 * nb + 1)):
+                nb += 1
+            fr.put(((0xFF00 >> nb) & 0xFF) | (num >> (6 * (nb - 1))), 8)
+            for i in range(nb - 2, -1, -1):
+                fr.put(0x80 | ((num >> (6 * i)) & 0x3F), 8)
+        fr.put(n - 1, 16)
+        fr.put(_crc(bytes(fr.b), 0x07, 8), 8)
+        for c in range(ch):
+            s = pcm[pos:pos + n, c].copy()
+            w = wasted if wasted and np.all((s & ((1 << wasted) - 1)) == 0) else 0
+            s >>= w
+            b = bps - w
+            order = min(lpc_order, n - 1)
+            fr.put(0, 1), fr.put(32 | (order - 1), 6)
+            if w:
+                fr.put(1, 1)
+                for _ in range(w - 1):
+                    fr.put(0, 1)
+                fr.put(1, 1)
+            else:
+                fr.put(0, 1)
+            # least-squares predictor on this block, quantised to `precision` bits with a common shift
+            X = np.stack([s[order - 1 - k:n - 1 - k] for k in range(order)], 1).astype(np.float64)
+            coef = np.linalg.lstsq(X, s[order:].astype(np.float64), rcond=None)[0] if n > order else np.zeros(order)
+            cmax = max(np.abs(coef).max(), 1e-9)
+            shift = int(max(0, min(15, precision - 1 - int(np.ceil(np.log2(cmax + 1e-12))) - 1)))
+            q = np.clip(np.rint(coef * (1 << shift)), -(1 << (precision - 1)), (1 << (precision - 1)) - 1).astype(np.int64)
+            for k in range(order):
+                fr.put(int(s[k]), b)
+            fr.put(precision - 1, 4), fr.put(shift, 5)
+            for k in range(order):
+                fr.put(int(q[k]), precision)
+            pred = (X.astype(np.int64) @ q) >> shift if n > order else np.zeros(0, np.int64)
+            res = s[order:] - pred
+            fr.put(1 if rice2 else 0, 2)
+            po = 0
+            while po < 3 and (n >> (po + 1)) << (po + 1) == n and (n >> (po + 1)) > order:
+                po += 1
+            fr.put(po, 4)
+            plen, i0 = n >> po, 0
+            for p in range(1 << po):
+                cnt = plen - (order if p == 0 else 0)
+                r = res[i0:i0 + cnt]
+                i0 += cnt
+                u = np.where(r >= 0, 2 * r, -2 * r - 1)
+                if escape_first_partition and p == 0:
+                    fr.put(31 if rice2 else 15, 5 if rice2 else 4)
+                    nb = int(max(1, int(np.abs(r).max(initial=0)))).bit_length() + 1
+                    fr.put(nb, 5)
+                    for v in r:
+                        fr.put(int(v), nb)
+                    continue
+                k = int(max(0, int(np.log2(max(u.mean() if cnt else 1, 1)))))
+                k = min(k, 30 if rice2 else 14)
+                fr.put(k, 5 if rice2 else 4)
+                for v in u:
+                    v = int(v)
+                    for _ in range(v >> k):
+                        fr.put(0, 1)
+                    fr.put(1, 1)
+                    fr.put(v, k)
+        fr.align()
+        crc = _crc(bytes(fr.b), 0x8005, 16)
+        out += fr.b
+        out += bytes([crc >> 8, crc & 0xFF])
+        pos += n
+        fno += 1
+    return bytes(out)

@@ -145,3 +145,27 @@ def test_convert_audio_flac_to_wav(tmp_path):
     assert sr == 48000 and np.array_equal(got, pcm.astype(np.float32) / np.float32(32768.0))
     with pytest.raises(FileNotFoundError):
         audio_out.AudioSaver().convert_audio(tmp_path / "missing.flac", tmp_path / "z", "wav")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lpc_order=8, precision=14), dict(rice2=True), dict(escape_first_partition=True),
+                                dict(wasted=3), dict(variable_blocks=True), dict(lpc_order=1, precision=5, rice2=True, escape_first_partition=True)])
+def test_native_decoder_reads_streams_it_did_not_write(kw):
+    """LPC subframes, 5-bit Rice parameters, escaped partitions, wasted bits, 1152-sample and variable blocks: features of FLAC
+    files in the wild (libFLAC output) that the native encoder never produces.  A second writer in the oracle emits them; the
+    native decoder (AudioSaver.convert_audio's reader) and the oracle decoder must both return the PCM."""
+    from ace355 import audio_out
+    from oracle import audio_out as o_audio
+    rng = np.random.default_rng(17)
+    n = 1152 * 3 + 401
+    t = np.arange(n) / 44100.0
+    x = np.stack([0.5 * np.sin(2 * np.pi * 330 * t) + 0.2 * np.sin(2 * np.pi * 1234 * t + 1), 0.4 * np.sin(2 * np.pi * 220 * t)], 1)
+    pcm = np.clip(np.rint((x + 0.002 * rng.standard_normal((n, 2))) * 30000), -32768, 32767).astype(np.int16)
+    if kw.get("wasted"):
+        pcm = (pcm >> 3) << 3
+    data = o_audio.flac_encode_test_stream(pcm, 44100, **kw)
+    got, info = o_audio.flac_decode(data)
+    assert np.array_equal(got, pcm.astype(np.int64)), "oracle reader"
+    nat, sr = audio_out.flac_decode_pcm16(data)
+    assert sr == 44100 and np.array_equal(nat, pcm), kw
+    if not kw.get("escape_first_partition"):
+        assert len(data) < 0.8 * pcm.nbytes   # the predictor is doing something

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -801,18 +802,32 @@ int ace355_save_audio_batch(const float* wav_dev, int n_items, int channels, int
     for (int i = 0; i < n_items; ++i) ACE_CHECK(paths[i] && paths[i][0], "save_audio_batch: empty path");
     const bool is_float = format == ACE355_AUDIO_WAV_F32;
     const size_t per_item = (size_t)samples * channels * (is_float ? 4 : 2), total = per_item * n_items;
-    void* dev = nullptr;
-    uint8_t* host = nullptr;
-    ACE_HIP(hipMalloc(&dev, total));
-    hipError_t e = hipHostMalloc((void**)&host, total, hipHostMallocDefault);
-    int rc = e == hipSuccess ? launch_interleave(wav_dev, n_items, channels, (long)samples, dev, is_float ? 0 : 1, (hipStream_t)stream) : 0;
-    if (e == hipSuccess && rc == 0) e = hipMemcpyAsync(host, dev, total, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess && rc == 0) e = hipStreamSynchronize((hipStream_t)stream);
-    hipFree(dev);
-    if (e != hipSuccess || rc != 0) {
-        if (host) hipHostFree(host);
-        return e != hipSuccess ? hip_fail(e, "save_audio_batch", __FILE__, __LINE__) : rc;
+    // conversion scratch (device) and its pinned host mirror are kept between calls: page-locking 46 MB per batch cost
+    // more than the copy.  One call at a time holds them.
+    static std::mutex scratch_mutex;
+    static void* s_dev = nullptr;
+    static uint8_t* s_host = nullptr;
+    static size_t s_cap = 0;
+    std::lock_guard<std::mutex> lock(scratch_mutex);
+    if (total > s_cap) {
+        if (s_dev) hipFree(s_dev);
+        if (s_host) hipHostFree(s_host);
+        s_dev = nullptr, s_host = nullptr, s_cap = 0;
+        ACE_HIP(hipMalloc(&s_dev, total));
+        const hipError_t ea = hipHostMalloc((void**)&s_host, total, hipHostMallocDefault);
+        if (ea != hipSuccess) {
+            hipFree(s_dev);
+            s_dev = nullptr;
+            return hip_fail(ea, "save_audio_batch: pinned scratch", __FILE__, __LINE__);
+        }
+        s_cap = total;
     }
+    void* dev = s_dev;
+    uint8_t* host = s_host;
+    int rc = launch_interleave(wav_dev, n_items, channels, (long)samples, dev, is_float ? 0 : 1, (hipStream_t)stream);
+    hipError_t e = rc == 0 ? hipMemcpyAsync(host, dev, total, hipMemcpyDeviceToHost, (hipStream_t)stream) : hipSuccess;
+    if (e == hipSuccess && rc == 0) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess || rc != 0) return e != hipSuccess ? hip_fail(e, "save_audio_batch", __FILE__, __LINE__) : rc;
     std::atomic<int> failed{-1};
     if (format == ACE355_AUDIO_FLAC) {
         std::vector<const int16_t*> items(n_items);
@@ -829,7 +844,6 @@ int ace355_save_audio_batch(const float* wav_dev, int n_items, int channels, int
             if (write_file(paths[i], h.data(), h.size(), host + per_item * i, per_item)) failed = (int)i;
         });
     }
-    hipHostFree(host);
     if (failed >= 0) {
         set_error(std::string("save_audio_batch: cannot write ") + paths[failed.load()]);
         return ACE355_ERR_INVALID;

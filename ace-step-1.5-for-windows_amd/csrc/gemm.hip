@@ -277,19 +277,32 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     const int m = mw0 + t * 8 + rsub;
                     hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
                 }
+                // The per-row gate lookup of short sequences is a separate loop: as a branch inside the store loop its (skipped)
+                // load still left an `s_waitcnt vmcnt(0)` at the join, and vmcnt counts stores too - every 16-byte store of the
+                // residual update waited for the previous one's acknowledgement (25-28 k cycles per tile).
+                if (!ep.g1 || two_gate) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int row = t * 8 + rsub;
-                    const int m = mw0 + row;
-                    const float4 a = *reinterpret_cast<const float4*>(stg + stage_off<128>(row, slot));
-                    float4 gt = (remA + row >= rps) ? gB : gA;
-                    if (ep.g1 && !two_gate) {  // short sequences (tiny configs): per-row lookup
-                        const float4 r2 = ldf4(ep.g2 + (long)(min(m, M - 1) / rps) * ep.g2_stride + n);
-                        gt = {g1.x + r2.x, g1.y + r2.y, g1.z + r2.z, g1.w + r2.w};
+                    for (int t = 0; t < NT; ++t) {
+                        const int row = t * 8 + rsub;
+                        const int m = mw0 + row;
+                        const float4 a = *reinterpret_cast<const float4*>(stg + stage_off<128>(row, slot));
+                        const float4 gt = (remA + row >= rps) ? gB : gA;
+                        float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
+                        if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
+                        if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
                     }
-                    float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
-                    if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
-                    if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
+                } else {  // short sequences (tiny configs): a wave's rows touch more than two sequences
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int row = t * 8 + rsub;
+                        const int m = mw0 + row;
+                        const float4 a = *reinterpret_cast<const float4*>(stg + stage_off<128>(row, slot));
+                        const float4 r2 = ldf4(ep.g2 + (long)(min(m, M - 1) / rps) * ep.g2_stride + n);
+                        const float4 gt = {g1.x + r2.x, g1.y + r2.y, g1.z + r2.z, g1.w + r2.w};
+                        float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
+                        if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
+                        if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
+                    }
                 }
             }
         }

@@ -198,9 +198,34 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                       ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + TM - 1) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
     const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NT * 32);
     if (BN == 128 && a.out_mode == 0 && full && a.wide_ok) {  // workgroup-uniform
+        // Every global load of the epilogue is requested before it is needed: the bias of both column halves and the first
+        // half's residual rows before the staging, the second half's residual rows before the first half is written.  (They
+        // used to be issued per half, each behind its own wait - eight scalar bias loads behind eight branches, then the
+        // residual rows: four L2 round trips per workgroup, most of the 5.5-7 k cycle epilogue.)
+        const int row_l = lane >> 2, c4 = lane & 3;
+        u32x4 bl[NT], bh[NT];   // bias of this lane's 8 columns per half (fp32 bits)
+        u32x4 rv[2][MT * 2];    // residual rows, double-buffered over the halves
+        const bool has_res = a.res != nullptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bl[j] = u32x4{0u, 0u, 0u, 0u};
+            bh[j] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bl[j] = ld_u32x4(a.bias + nw0 + j * 32 + c4 * 8);
+                bh[j] = ld_u32x4(a.bias + nw0 + j * 32 + c4 * 8 + 4);
+            }
+        }
+        auto res_load = [&](int j, u32x4 (&r)[MT * 2]) {
+            const long rcol = (long)b * a.res_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
+#pragma unroll
+            for (int t = 0; t < MT * 2; ++t) r[t] = ld_u32x4(a.res + rcol + (long)(mw0 + t * 16 + row_l) * a.N);
+        };
+        if (has_res) res_load(0, rv[0]);
         __syncthreads();  // every wave is done with the operand tiles: the LDS may be overwritten
         char* stg = smem + wave * (MT * 32 * 128);  // MT*32 rows x 128 B (32 floats)
-        const int row_l = lane >> 2, c4 = lane & 3;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
@@ -212,17 +237,10 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     const int row = i * 32 + lq, slot = 2 * g + half;
                     *reinterpret_cast<float4*>(stg + row * 128 + ((slot ^ (row & 7)) << 4)) = v;
                 }
-            const int n = nw0 + j * 32 + c4 * 8;
-            float bias[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias[e] = a.bias ? a.bias[n + e] : 0.f;
-            const long col = (long)b * a.y_batch_stride + n + a.y_shift;
-            const long rcol = (long)b * a.res_batch_stride + n + a.y_shift;
-            uint4 rv[MT * 2];
-            if (a.res) {
-#pragma unroll
-                for (int t = 0; t < MT * 2; ++t) rv[t] = *reinterpret_cast<const uint4*>(a.res + rcol + (long)(mw0 + t * 16 + row_l) * a.N);
-            }
+            if (has_res && j + 1 < NT) res_load(j + 1, rv[(j + 1) & 1]);
+            const long col = (long)b * a.y_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
+            const float bias[8] = {__uint_as_float(bl[j][0]), __uint_as_float(bl[j][1]), __uint_as_float(bl[j][2]), __uint_as_float(bl[j][3]),
+                                   __uint_as_float(bh[j][0]), __uint_as_float(bh[j][1]), __uint_as_float(bh[j][2]), __uint_as_float(bh[j][3])};
 #pragma unroll
             for (int t = 0; t < MT * 2; ++t) {
                 const int row = t * 16 + row_l;
@@ -230,14 +248,13 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                 const float4 hi = *reinterpret_cast<const float4*>(stg + row * 128 + (((2 * c4 + 1) ^ (row & 7)) << 4));
                 float v[8] = {lo.x + bias[0], lo.y + bias[1], lo.z + bias[2], lo.w + bias[3],
                               hi.x + bias[4], hi.y + bias[5], hi.z + bias[6], hi.w + bias[7]};
-                if (a.res) {
-                    const uint32_t* rp = reinterpret_cast<const uint32_t*>(&rv[t]);
+                if (has_res) {
+                    const u32x4 r = rv[j & 1][t];
 #pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) { v[2 * e2] += bf_lo(rp[e2]); v[2 * e2 + 1] += bf_hi(rp[e2]); }
+                    for (int e2 = 0; e2 < 4; ++e2) { v[2 * e2] += bf_lo(r[e2]); v[2 * e2 + 1] += bf_hi(r[e2]); }
                 }
-                uint4 pk;
-                pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]); pk.z = pack_bf2(v[4], v[5]); pk.w = pack_bf2(v[6], v[7]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.y) + col + (long)(mw0 + row) * a.N) = pk;
+                u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + col + (long)(mw0 + row) * a.N) = pk;
             }
         }
         probe_done();
@@ -288,7 +305,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     ConvArgs aw = a;
     {
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
+        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && al16(a.bias) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
                      (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
     }
     static int tm_env = -1, clk_env = -1;

@@ -229,6 +229,17 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 float4 g1 = {1.f, 1.f, 1.f, 1.f}, gA = g1, gB = g1, cv = {0.f, 0.f, 0.f, 0.f};
                 int remA = 0;
                 const bool two_gate = MT * 32 <= rps;  // the wave's rows touch at most two sequences
+                // the old H rows (the big, slow loads) are requested FIRST, the per-column gate / constant vectors behind
+                // them: one memory round trip per half instead of three (each gate sum used to wait for its own loads
+                // before the H loads were even issued)
+                float4 hv[NT];
+                if (ep.ksplit <= 1) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int m = mw0 + t * 8 + rsub;
+                        hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
+                    }
+                }
                 if (ep.cvec) cv = ldf4(ep.cvec + n);
                 if (ep.g1) {
                     g1 = ldf4(ep.g1 + n);
@@ -270,12 +281,6 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         if (ROWS_FULL || m < M) unsafeAtomicAdd(hq + (long)m * ldc, o);
                     }
                     continue;
-                }
-                float4 hv[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int m = mw0 + t * 8 + rsub;
-                    hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
                 }
                 // The per-row gate lookup of short sequences is a separate loop: as a branch inside the store loop its (skipped)
                 // load still left an `s_waitcnt vmcnt(0)` at the join, and vmcnt counts stores too - every 16-byte store of the

@@ -204,6 +204,9 @@ struct ConvArgs {
     int n_real;
     int wide_ok;                                                 // set by launch_conv: y / res / strides allow the 16-byte staged epilogue
     int clk_probe;                                               // ACE355_CONV_CLK=1: one workgroup records its shader-clock phases
+    // fused residual unit (Cin = N = 128, plain conv): y = res + bias2 + w2 . snake2(conv(x) + bias), w2 [N][1][N]: the k = 1
+    // conv of an OobleckResidualUnit applied to the k = 7 result while it is still in the workgroup (LDS), launch_conv decides
+    const bf16_t* w2; const float* bias2; const float* alpha2; const float* beta2;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s);

@@ -180,6 +180,89 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         }
         if (probe) p_taps += clock64() - p_mark;
     }
+    // ---------------------------------------------------------------- fused k = 1 stage of a residual unit (C = 128)
+    // The k = 7 result t = acc + bias never leaves the workgroup: snake2(t) is written to LDS as the A operand of a
+    // 128 x 128 x 128 GEMM with w2 (two 64-channel planes over the dead window / first weight buffer, w2 chunks through the
+    // second weight buffer), and the epilogue below then adds bias2 and the residual.  Two of the unit's five tensor passes
+    // (write t, read t) and one launch disappear.
+    const float* epi_bias = a.bias;
+    if constexpr (BN == 128 && TM == 128) {
+        if (a.w2) {  // workgroup-uniform
+            epi_bias = a.bias2;
+            const float* b7p = a.bias ? a.bias : a.alpha2;  // (unconditional loads: a branch per element would fence them)
+            const float b7s = a.bias ? 1.f : 0.f;
+            __syncthreads();  // every wave is done with the window and the weight tiles
+            char* A2 = smem;                      // 2 planes x 128 rows x 128 B
+            char* W2s = Wbase + BN * 128;         // second weight buffer (16 KB), beyond the planes
+            // w2 chunk 0 on its way while Snake runs
+            u32x4 rw2[WCH];
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) rw2[i] = ld_u32x4(a.w2 + (long)min(n0 + (tid >> 3) + (NTHR / 8) * i, a.N - 1) * 128 + sslot * 8);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u32x4 b4[4], e4[4], i4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = n0 + wn * (NT * 32) + j * 32 + 8 * g + 4 * half;
+                    b4[g] = ld_u32x4(b7p + c);
+                    e4[g] = ld_u32x4(a.alpha2 + c);
+                    i4[g] = ld_u32x4(a.beta2 + c);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[i][j][4 * g + e] + b7s * __uint_as_float(b4[g][e]);
+                            const float sn = __sinf(__uint_as_float(e4[g][e]) * v);
+                            t[e] = v + __uint_as_float(i4[g][e]) * sn * sn;
+                        }
+                        const int row = wm * (MT * 32) + i * 32 + lq;
+                        uint2 pk = make_uint2(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]));
+                        *reinterpret_cast<uint2*>(A2 + wn * 16384 + lds_off(row, j * 4 + g) + 8 * half) = pk;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(W2s + wst[i]) = rw2[i];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                if (c2 == 0) {
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) rw2[i] = ld_u32x4(a.w2 + (long)min(n0 + (tid >> 3) + (NTHR / 8) * i, a.N - 1) * 128 + 64 + sslot * 8);
+                }
+                const char* Ap = A2 + c2 * 16384;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    bf16x8 fa[MT], fw[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(Ap + lds_off(wm * (MT * 32) + i * 32 + lq, kk * 2 + half)));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(W2s + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);
+                }
+                if (c2 == 0) {
+                    __syncthreads();  // chunk 0 of w2 consumed by every wave
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(W2s + wst[i]) = rw2[i];
+                    __syncthreads();
+                }
+            }
+        }
+    }
     const unsigned long long p_e0 = probe ? clock64() : 0ull;
     auto probe_done = [&]() {
         if (!probe) return;
@@ -211,11 +294,11 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             bl[j] = u32x4{0u, 0u, 0u, 0u};
             bh[j] = u32x4{0u, 0u, 0u, 0u};
         }
-        if (a.bias) {
+        if (epi_bias) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                bl[j] = ld_u32x4(a.bias + nw0 + j * 32 + c4 * 8);
-                bh[j] = ld_u32x4(a.bias + nw0 + j * 32 + c4 * 8 + 4);
+                bl[j] = ld_u32x4(epi_bias + nw0 + j * 32 + c4 * 8);
+                bh[j] = ld_u32x4(epi_bias + nw0 + j * 32 + c4 * 8 + 4);
             }
         }
         auto res_load = [&](int j, u32x4 (&r)[MT * 2]) {
@@ -271,7 +354,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int n = nw0 + j * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
                 if (n >= a.N) continue;
-                float v = acc[i][j][r] + (a.bias ? a.bias[n] : 0.f);
+                float v = acc[i][j][r] + (epi_bias ? epi_bias[n] : 0.f);
                 if (a.out_mode == 0) {
                     const long flat = (long)m * a.N + n + a.y_shift;
                     if (flat < 0 || flat >= a.y_valid) continue;
@@ -302,10 +385,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil <= HALO_MAX && a.dil >= 1, "conv: window too large");
     ACE_CHECK(a.B > 0 && a.M > 0 && a.N > 0, "conv: empty problem");
     ACE_CHECK(a.x_valid ? (a.x_shift % 8 == 0 && a.x_valid % 8 == 0) : a.x_shift == 0, "conv: x_shift / x_valid must be multiples of 8 (and x_shift needs x_valid)");
+    ACE_CHECK(!a.w2 || (a.Cin == 128 && a.N == 128 && !a.x_valid && a.out_mode == 0 && a.alpha2 && a.beta2 &&
+                        (reinterpret_cast<uintptr_t>(a.alpha2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.beta2) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w2) & 15) == 0),
+              "conv: the fused k = 1 stage needs Cin = N = 128, a plain conv and 16-byte aligned vectors");
     ConvArgs aw = a;
     {
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && al16(a.bias) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
+        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && al16(a.bias) && al16(a.bias2) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
                      (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
     }
     static int tm_env = -1, clk_env = -1;

@@ -364,6 +364,7 @@ int run_conv(ace355_vae* h, const ConvArgs& a, hipStream_t s) {
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, s);
         h->flops += 2.0 * a.B * (double)a.M * (a.out_mode == 1 ? a.n_real : a.N) * a.taps * a.Cin;
+        if (a.w2) h->flops += 2.0 * a.B * (double)a.M * a.N * a.N;  // fused k = 1 stage
         h->launches++;
     }
     int rc = launch_conv(a, s);
@@ -508,7 +509,29 @@ int ace355_vae_finalize(ace355_vae* h) {
 int ace355_vae_hop(const ace355_vae* h) { return h ? h->hop : 0; }
 
 // Residual unit in place on `state` (scratch `tmp`), shared by decode and encode: x + conv_k1(snake2(conv_k7_dil(snake1(x))))
-static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t* state, bf16_t* tmp, int B, long L, int C, hipStream_t s) {
+static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t*& tmp, int B, long L, int C, hipStream_t s) {
+    static int fuse = -1;
+    if (fuse < 0) {
+        const char* e = getenv("ACE355_CONV_FUSE_RU");  // 0: two launches per unit everywhere (A/B runs)
+        fuse = e ? atoi(e) : 1;
+    }
+    if (fuse && C == 128) {
+        // C = 128: one workgroup tile spans all channels, so the k = 1 conv runs on the k = 7 result inside the same kernel
+        // (conv.hip, ConvArgs::w2).  The unit's output lands in `tmp` (neighbouring tiles still read `state`'s halo rows):
+        // the two buffers trade places.
+        ConvArgs f{};
+        f.x = state; f.x_batch_stride = L * C; f.L_in = (int)L; f.Cin = C;
+        f.w = R.c1.w; f.bias = R.c1.bias; f.alpha = R.s1.ea; f.beta = R.s1.ib;
+        f.w2 = R.c2.w; f.bias2 = R.c2.bias; f.alpha2 = R.s2.ea; f.beta2 = R.s2.ib;
+        f.res = state; f.res_batch_stride = L * C;
+        f.y = tmp; f.y_batch_stride = L * C;
+        f.B = B; f.M = (int)L; f.N = C; f.taps = 7; f.dil = R.dil; f.center = 3;
+        f.y_shift = 0; f.y_valid = L * C; f.out_mode = 0;
+        const int rcf = run_conv(h, f, s);
+        if (rcf) return rcf;
+        std::swap(state, tmp);
+        return 0;
+    }
     ConvArgs a{};
     a.x = state; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
     a.w = R.c1.w; a.bias = R.c1.bias; a.alpha = R.s1.ea; a.beta = R.s1.ib;

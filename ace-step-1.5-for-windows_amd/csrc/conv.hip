@@ -409,7 +409,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         const long wgs128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.B;
         // 8-wave tiles pay off where the tap loop dominates (Cin >= 256: +2-5 %); at Cin = 128 and for k = 1 the exposed
         // window load of the un-prefetched form costs more than the sharing saves (-5 % / -35 %)
-        const bool tall = tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 2);
+        // (the 2-tap transposed / strided convs are faster on the 4-wave tile at every stage: 1.31 / 1.34 / 1.46 ms against
+        //  1.44 / 1.50 / 1.83 ms)
+        const bool tall = tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 3);
         if (tall) {
             dim3 grid((a.M + 255) / 256, (a.N + 127) / 128, a.B);
             hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);

@@ -19,6 +19,7 @@ to a CPU implementation: a missing library or a failed HIP call raises ``Runtime
 """
 from __future__ import annotations
 
+import inspect
 import logging
 import time
 import traceback
@@ -58,6 +59,28 @@ class NativeDitMixin:
             logger.warning("[native-dit] init failed (%s: %s); PyTorch path stays active", type(exc).__name__, exc)
             self.use_native_dit, self.native_dit = False, None
             return False
+
+    def _model_honours_timesteps(self) -> bool:
+        """Whether the loaded checkpoint's own ``generate_audio`` reads an explicit ``timesteps=``: the sft and turbo models do
+        (sft/modeling_acestep_v15_base.py:1864-1875, turbo :1807-1865); the BASE model has no such parameter - it lands in
+        ``**kwargs`` and the schedule is always linspace + shift (base/modeling_acestep_v15_base.py:1812, 1864-1867).  The
+        native path must not diverge from the checkpoint it stands in for.  ``model_variant`` ("base" | "sft" | "turbo") on
+        the host overrides the signature probe (``NativeHandler`` has no reference module to probe)."""
+        variant = getattr(self, "model_variant", None)
+        if variant is not None:
+            return variant in ("sft", "turbo")
+        ga = getattr(getattr(self, "model", None), "generate_audio", None)
+        if ga is None:
+            return True
+        try:
+            return "timesteps" in inspect.signature(ga).parameters
+        except (TypeError, ValueError):
+            return True
+
+    def _is_turbo(self) -> bool:
+        """handler/init_service_catalog.py:69-73 (`is_turbo_model`): a ``config.is_turbo`` flag on the host, or
+        ``model_variant == "turbo"``."""
+        return bool(getattr(getattr(self, "config", None), "is_turbo", False)) or getattr(self, "model_variant", None) == "turbo"
 
     def _native_run_diffusion(
         self,
@@ -106,7 +129,10 @@ class NativeDitMixin:
         ts_list = None
         if timesteps is not None:
             ts_list = timesteps.tolist() if hasattr(timesteps, "tolist") else list(timesteps)
-        if bool(getattr(getattr(self, "config", None), "is_turbo", False)):
+        if ts_list is not None and not self._is_turbo() and not self._model_honours_timesteps():
+            logger.info("[native-dit] base checkpoint: explicit timesteps are ignored, as its generate_audio does")
+            ts_list = None
+        if self._is_turbo():
             # turbo checkpoints (handler init_service_catalog.py:69-73 `is_turbo_model`): the model's own generate_audio has no
             # CFG / step count, only the shift -> 8-step table (turbo modeling file :1780-1995); same native loop
             from .dit import generate_latents_turbo
@@ -237,14 +263,21 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         self.quantization = None
         self.offload_to_cpu = False
         self.current_offload_cost = 0.0
+        self.model_variant = "sft"  # which checkpoint family's generate_audio semantics apply: "base" | "sft" | "turbo"
 
     def initialize_service(self, dit_config: DitConfig, decoder_state_dict: Dict[str, torch.Tensor],
                            null_condition_emb: torch.Tensor, vae_config: Optional[VaeConfig] = None,
                            vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, device: str = "auto",
-                           use_native: bool = True):
+                           use_native: bool = True, model_variant: str = "sft"):
         """Counterpart of ``initialize_service`` (handler/init_service_orchestrator.py:15-110) for pre-loaded weights.
-        Re-entry is allowed (:30-31).  Returns ``(status_message, success)`` like the reference."""
+        Re-entry is allowed (:30-31).  Returns ``(status_message, success)`` like the reference.
+        ``model_variant`` names the checkpoint family (the reference reads it off the checkpoint directory,
+        handler/init_service_catalog.py:69-73): "base" ignores explicit ``timesteps`` like its model, "sft" honours them,
+        "turbo" selects the 8-step table sampler without CFG."""
         try:
+            if model_variant not in ("base", "sft", "turbo"):
+                raise ValueError(f"unknown model_variant '{model_variant}'")
+            self.model_variant = model_variant
             if device == "auto":
                 device = "cuda" if torch.cuda.is_available() else "cpu"
             if device == "cuda":

@@ -3,7 +3,9 @@
 Mirror of ``AceStepConditionEncoder`` (modeling_acestep_v15_base.py:1509-1554): same argument names, same outputs
 (``encoder_hidden_states`` with the valid tokens first, ``encoder_attention_mask``).  Weights come from the loaded
 ``model.encoder.state_dict()``.  Attention masks must be prefix masks (ones then zeros, what the tokenizer's right padding
-and ``pack_sequences`` produce); anything else raises ``ValueError`` so that the reference seam falls back to PyTorch.
+and ``pack_sequences`` produce); anything else raises ``ValueError``.  Installed through ``modswap.swap_in`` (an ``nn.Module``
+wrapper that keeps the reference module and runs it whenever this class raises) - the object itself is not an ``nn.Module`` and
+cannot be assigned to ``model.encoder`` directly.
 """
 from __future__ import annotations
 

@@ -11,6 +11,16 @@ from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 
+def _effective_layer_types(cfg) -> List[str]:
+    """``layer_types`` as the reference APPLIES them: with ``use_sliding_window`` off (``sliding_window`` None) the
+    sliding mask is never built (modeling_acestep_v15_base.py:1397 passes ``sliding_attn_mask=None``), so every layer
+    attends fully whatever ``layer_types`` says; the native kernels would read window 0 as a one-key band."""
+    lt = list(cfg.layer_types)
+    if not getattr(cfg, "use_sliding_window", True) or getattr(cfg, "sliding_window", None) is None:
+        return ["full_attention"] * len(lt)
+    return lt
+
+
 @dataclass
 class DitConfig:
     hidden_size: int = 2048
@@ -43,7 +53,7 @@ class DitConfig:
             num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
             rms_norm_eps=cfg.rms_norm_eps, rope_theta=float(getattr(cfg, "rope_theta", 1e6)),
             sliding_window=cfg.sliding_window or 0, patch_size=cfg.patch_size, in_channels=cfg.in_channels,
-            audio_acoustic_hidden_dim=cfg.audio_acoustic_hidden_dim, layer_types=list(cfg.layer_types),
+            audio_acoustic_hidden_dim=cfg.audio_acoustic_hidden_dim, layer_types=_effective_layer_types(cfg),
         )
 
     def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
@@ -115,7 +125,7 @@ class CondConfig:
             rope_theta=float(getattr(cfg, "rope_theta", 1e6)), sliding_window=cfg.sliding_window or 0,
             text_hidden_dim=cfg.text_hidden_dim, timbre_hidden_dim=cfg.timbre_hidden_dim,
             num_lyric_encoder_hidden_layers=cfg.num_lyric_encoder_hidden_layers,
-            num_timbre_encoder_hidden_layers=cfg.num_timbre_encoder_hidden_layers, layer_types=list(cfg.layer_types),
+            num_timbre_encoder_hidden_layers=cfg.num_timbre_encoder_hidden_layers, layer_types=_effective_layer_types(cfg),
         )
 
     def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:
@@ -176,7 +186,7 @@ class DetokConfig:
             rope_theta=float(getattr(cfg, "rope_theta", 1e6)), sliding_window=cfg.sliding_window or 0,
             pool_window_size=cfg.pool_window_size, num_attention_pooler_hidden_layers=cfg.num_attention_pooler_hidden_layers,
             audio_acoustic_hidden_dim=cfg.audio_acoustic_hidden_dim,
-            layer_types=list(cfg.layer_types)[: cfg.num_attention_pooler_hidden_layers],
+            layer_types=_effective_layer_types(cfg)[: cfg.num_attention_pooler_hidden_layers],
         )
 
     def weight_shapes(self) -> Dict[str, Tuple[int, ...]]:

@@ -23,6 +23,17 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 namespace {
+// Temporaries of the unit hooks: freed (after the stream has drained) on every exit path, early error returns included.
+struct DevTmp {
+    hipStream_t s;
+    void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    explicit DevTmp(hipStream_t s_) : s(s_) {}
+    ~DevTmp() {
+        (void)hipStreamSynchronize(s);
+        for (void* q : p) if (q) (void)hipFree(q);
+    }
+};
+
 __global__ void snake_prep_kernel(const float* __restrict__ alpha, const float* __restrict__ beta, float* __restrict__ ea,
                                   float* __restrict__ ib, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,6 +101,42 @@ int ace355_gemm_bf16_fused(const void* A, const void* W, void* out, int M, int N
     return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, out, N / 2, M, N, K, ep, (hipStream_t)stream);
 }
 
+int ace355_gemm_bf16_residual(const void* A, const void* W, float* H, int M, int N, int K, const float* g1, const float* g2,
+                              int g2_stride, int rows_per_seq, const float* cvec, int cvec_row0, void* stream) {
+    ACE_CHECK(A && W && H, "gemm_bf16_residual: null pointer");
+    GemmEpilogue ep{2, nullptr, g1, g2, g2_stride, rows_per_seq, cvec, cvec_row0};
+    return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, H, N, M, N, K, ep, (hipStream_t)stream);
+}
+
+int ace355_gemm_bf16_headnorm(const void* A, const void* W, void* out, int M, int N, int K, int q_cols, int qk_cols, const float* wq,
+                              const float* wk, float eps, int rope, int rows_per_seq, float theta, void* stream) {
+    ACE_CHECK(A && W && out && wq && wk, "gemm_bf16_headnorm: null pointer");
+    ACE_CHECK(q_cols % 128 == 0 && qk_cols % 128 == 0 && q_cols <= qk_cols && qk_cols <= N && rows_per_seq > 0, "gemm_bf16_headnorm: columns");
+    hipStream_t s = (hipStream_t)stream;
+    DevTmp t(s);
+    const bf16_t* Wuse = (const bf16_t*)W;
+    const float *cs = nullptr, *sn = nullptr;
+    if (rope) {  // the library keeps q / k projection rows in head-pair order (PACK_ROWS_HEADPAIR); v rows as they are
+        ACE_HIP(hipMalloc(&t.p[0], (size_t)N * K * 2));
+        int rc = launch_pack(W, ACE355_DTYPE_BF16, t.p[0], 1, PACK_ROWS_HEADPAIR, qk_cols, K, K, 0, 0, 0, s);
+        if (rc) return rc;
+        if (N > qk_cols) {
+            rc = launch_pack((const bf16_t*)W + (size_t)qk_cols * K, ACE355_DTYPE_BF16, t.p[0], 1, PACK_ROWS, N - qk_cols, K, K, qk_cols, 0, 0, s);
+            if (rc) return rc;
+        }
+        Wuse = (const bf16_t*)t.p[0];
+        ACE_HIP(hipMalloc(&t.p[1], (size_t)rows_per_seq * 64 * 4));
+        ACE_HIP(hipMalloc(&t.p[2], (size_t)rows_per_seq * 64 * 4));
+        rc = launch_rope_table((float*)t.p[1], (float*)t.p[2], rows_per_seq, theta, s);
+        if (rc) return rc;
+        cs = (const float*)t.p[1], sn = (const float*)t.p[2];
+    }
+    GemmEpilogue ep{4, nullptr, nullptr, nullptr, 0, rows_per_seq};
+    ep.hn_wq = wq; ep.hn_wk = wk; ep.hn_cos = cs; ep.hn_sin = sn;
+    ep.hn_q_cols = q_cols; ep.hn_qk_cols = qk_cols; ep.hn_eps = eps;
+    return launch_gemm((const bf16_t*)A, K, Wuse, K, out, N, M, N, K, ep, s);
+}
+
 int ace355_rmsnorm_mod(const float* x, const float* w, void* y, int M, int D, float eps, const float* sc1, const float* sc2,
                        const float* sh1, const float* sh2, int stride, int rows_per_seq, void* stream) {
     ACE_CHECK(x && w && y, "rmsnorm_mod: null pointer");
@@ -100,19 +147,20 @@ int ace355_headnorm_rope(void* x, int M, int ld, int col0, int heads, const floa
                          void* stream) {
     ACE_CHECK(x && w, "headnorm_rope: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    DevTmp t(s);
     float *c = nullptr, *sn = nullptr;
     if (rope) {
         ACE_CHECK(S > 0, "headnorm_rope: S");
-        ACE_HIP(hipMalloc((void**)&c, (size_t)S * 64 * 4));
-        ACE_HIP(hipMalloc((void**)&sn, (size_t)S * 64 * 4));
+        ACE_HIP(hipMalloc(&t.p[0], (size_t)S * 64 * 4));
+        ACE_HIP(hipMalloc(&t.p[1], (size_t)S * 64 * 4));
+        c = (float*)t.p[0], sn = (float*)t.p[1];
         int rc = launch_rope_table(c, sn, S, theta, s);
         if (rc) return rc;
     }
     int rc = launch_headnorm_rope((bf16_t*)x, M, ld, col0, heads, w, eps, c, sn, S, s);
+    if (rc) return rc;
     ACE_HIP(hipStreamSynchronize(s));
-    if (c) hipFree(c);
-    if (sn) hipFree(sn);
-    return rc;
+    return ACE355_OK;
 }
 
 static int attention_hook(const void* q, const void* k, const void* v, void* out, int N, int Sq, int Skv, int Hq, int Hkv, int window,
@@ -134,19 +182,21 @@ static int attention_hook(const void* q, const void* k, const void* v, void* out
                           float scale, const int32_t* kv_len_host, void* stream) {
     ACE_CHECK(q && k && v && out, "attention: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    DevTmp t(s);
     int* kvl = nullptr;
     bf16_t* vmean = nullptr;
     if (kv_len_host) {
         for (int i = 0; i < N; ++i) ACE_CHECK(kv_len_host[i] >= 0 && kv_len_host[i] <= Skv, "attention_masked: kv_len out of range");
-        ACE_HIP(hipMalloc((void**)&kvl, sizeof(int) * N));
-        ACE_HIP(hipMalloc((void**)&vmean, (size_t)N * Hkv * 128 * 2));
+        ACE_HIP(hipMalloc(&t.p[0], sizeof(int) * N));
+        ACE_HIP(hipMalloc(&t.p[1], (size_t)N * Hkv * 128 * 2));
+        kvl = (int*)t.p[0], vmean = (bf16_t*)t.p[1];
         ACE_HIP(hipMemcpy(kvl, kv_len_host, sizeof(int) * N, hipMemcpyHostToDevice));
         int rcm = launch_vmean((const bf16_t*)v, Hkv * 128, 0, N, Skv, Hkv, vmean, s);
         if (rcm) return rcm;
     }
     const int Sp = ((Skv + 63) / 64) * 64;
-    bf16_t* vt = nullptr;
-    ACE_HIP(hipMalloc((void**)&vt, (size_t)N * Hkv * 128 * Sp * 2));
+    ACE_HIP(hipMalloc(&t.p[2], (size_t)N * Hkv * 128 * Sp * 2));
+    bf16_t* vt = (bf16_t*)t.p[2];
     int rc = launch_transpose_v((const bf16_t*)v, Hkv * 128, 0, N, Skv, Hkv, vt, Sp, s);
     if (!rc) {
         AttnArgs a{};
@@ -160,9 +210,6 @@ static int attention_hook(const void* q, const void* k, const void* v, void* out
         rc = launch_attention(a, s);
     }
     hipError_t e = hipStreamSynchronize(s);
-    hipFree(vt);
-    if (kvl) hipFree(kvl);
-    if (vmean) hipFree(vmean);
     if (e != hipSuccess) return hip_fail(e, "attention sync", __FILE__, __LINE__);
     return rc;
 }
@@ -181,11 +228,13 @@ int ace355_conv1d_nlc(const void* x, const void* w, const float* bias, const flo
     ACE_CHECK(x && w && y, "conv1d_nlc: null pointer");
     ACE_CHECK(taps % 2 == 1, "conv1d_nlc: odd taps only");
     hipStream_t s = (hipStream_t)stream;
+    DevTmp t(s);
     float *ea = nullptr, *ib = nullptr;
     if (alpha) {
         ACE_CHECK(beta != nullptr, "conv1d_nlc: beta");
-        ACE_HIP(hipMalloc((void**)&ea, (size_t)Cin * 4));
-        ACE_HIP(hipMalloc((void**)&ib, (size_t)Cin * 4));
+        ACE_HIP(hipMalloc(&t.p[0], (size_t)Cin * 4));
+        ACE_HIP(hipMalloc(&t.p[1], (size_t)Cin * 4));
+        ea = (float*)t.p[0], ib = (float*)t.p[1];
         hipLaunchKernelGGL(snake_prep_kernel, dim3((Cin + 255) / 256), dim3(256), 0, s, alpha, beta, ea, ib, Cin);
     }
     ConvArgs a{};
@@ -197,8 +246,6 @@ int ace355_conv1d_nlc(const void* x, const void* w, const float* bias, const flo
     a.y_shift = 0; a.y_valid = (long)L * Cout; a.out_mode = 0;
     int rc = launch_conv(a, s);
     hipError_t e = hipStreamSynchronize(s);
-    if (ea) hipFree(ea);
-    if (ib) hipFree(ib);
     if (e != hipSuccess) return hip_fail(e, "conv1d_nlc sync", __FILE__, __LINE__);
     return rc;
 }

@@ -64,8 +64,9 @@ struct ace355_dit {
     // condition staging
     bf16_t *enc_bf = nullptr, *enc_emb = nullptr;
     long enc_cap = 0;
-    CondSlot slots[8];
+    CondSlot slots[ACE355_MAX_SLOTS];
     int* flags_dev = nullptr;
+    float* tap_dst[64] = {};  // ace355_dit_set_tap
 
     // profiling
     bool profile = false;
@@ -193,8 +194,15 @@ int ensure_rope(ace355_dit* h, int S, hipStream_t s) {
     if (S <= h->rope_S) return 0;
     int cap = 512;
     while (cap < S) cap *= 2;
-    ALLOC(h->allocs, h->rope_cos, (size_t)cap * 64);
-    ALLOC(h->allocs, h->rope_sin, (size_t)cap * 64);
+    if (h->rope_cos) {  // growing: the old tables may still be read by queued work
+        ACE_HIP(hipStreamSynchronize(s));
+        hipFree(h->rope_cos);
+        hipFree(h->rope_sin);
+        h->rope_cos = h->rope_sin = nullptr;
+        h->rope_S = 0;
+    }
+    ACE_HIP(hipMalloc((void**)&h->rope_cos, (size_t)cap * 64 * sizeof(float)));
+    ACE_HIP(hipMalloc((void**)&h->rope_sin, (size_t)cap * 64 * sizeof(float)));
     int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->cfg.rope_theta, s);
     if (rc) return rc;
     h->rope_S = cap;
@@ -267,7 +275,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
 
     int L = -1;
     for (int i = 0; i < N; ++i) {
-        ACE_CHECK(slots[i] >= 0 && slots[i] < 8 && h->slots[slots[i]].valid, "forward: condition slot not set");
+        ACE_CHECK(slots[i] >= 0 && slots[i] < ACE355_MAX_SLOTS && h->slots[slots[i]].valid, "forward: condition slot not set");
         if (L < 0) L = h->slots[slots[i]].L;
         ACE_CHECK(h->slots[slots[i]].L == L, "forward: all condition slots of one call must share L");
     }
@@ -375,6 +383,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, h->tproj + 5 * D, tstride, S};
         rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
         if (rc) return rc;
+        if (h->tap_dst[li]) ACE_HIP(hipMemcpyAsync(h->tap_dst[li], h->h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
 
     // output norm + modulation with temb (base.py:1491-1496): shift = sst[0] + temb, scale = sst[1] + temb
@@ -451,6 +460,8 @@ void ace355_dit_destroy(ace355_dit* h) {
         if (c.cross_const) hipFree(c.cross_const);
     }
     if (h->stage) hipFree(h->stage);
+    if (h->rope_cos) hipFree(h->rope_cos);
+    if (h->rope_sin) hipFree(h->rope_sin);
     if (h->enc_bf) hipFree(h->enc_bf);
     if (h->enc_emb) hipFree(h->enc_emb);
     for (auto& e : h->gemm_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -522,7 +533,7 @@ int ace355_dit_finalize(ace355_dit* h) {
 int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int rows, int L, void* stream) {
     ACE_CHECK(h && enc_dev, "set_condition: null argument");
     if (!h->finalized) { set_error("set_condition: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
-    ACE_CHECK(slot >= 0 && slot < 8, "set_condition: slot out of range");
+    ACE_CHECK(slot >= 0 && slot < ACE355_MAX_SLOTS, "set_condition: slot out of range");
     ACE_CHECK(L > 0 && (rows == L || rows == 1), "set_condition: rows must be L or 1");
     hipStream_t s = (hipStream_t)stream;
     const int D = h->D, KVD = h->KVD;
@@ -626,13 +637,18 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     if (rc) return rc;
 
     int slots[ACE355_MAX_SEQS];
+    const int32_t* cond_tab = p->cond_slots_host;  // per-item conditions (NULL: cond_slot for every item)
     int cond = p->cond_slot;
     bool switched = false;
     int apg_calls = 0;
-    std::vector<hipEvent_t> evs;
+    struct Events {  // destroyed on every exit path (a failing step used to leak them)
+        std::vector<hipEvent_t> v;
+        ~Events() { for (auto& e : v) if (e) hipEventDestroy(e); }
+    } evh;
+    std::vector<hipEvent_t>& evs = evh.v;
     if (per_step_ms_host) {
-        evs.resize(p->num_steps + 1);
-        for (auto& e : evs) hipEventCreate(&e);
+        evs.assign(p->num_steps + 1, nullptr);
+        for (auto& e : evs) ACE_HIP(hipEventCreate(&e));
         hipEventRecord(evs[0], s);
     }
     for (int i = 0; i < p->num_steps; ++i) {
@@ -640,11 +656,12 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
             switched = true;
             ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
             cond = p->non_cover_slot;
+            cond_tab = p->non_cover_slots_host;
             rc = launch_set_xin_ctx(p->ctx_non_cover_dev, h->xin, B, copies, T, Tpad, s);
             if (rc) return rc;
         }
         for (int b = 0; b < B; ++b) {
-            slots[b] = cond;
+            slots[b] = cond_tab ? cond_tab[b] : cond;
             if (do_cfg) slots[B + b] = p->null_slot;
         }
         const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
@@ -657,7 +674,8 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         StepUpdate up{nullptr, t_curr, 0.f};
         if (p->infer_method == 1) {
             up.sde_noise = p->sde_noise_dev + (size_t)i * B * T * h->OUTC;
-            up.t_next = 1.0f - (float)(i + 1) / (float)p->num_steps;  // base.py:1972
+            // base / sft: linear level (base.py:1972); turbo: the next table value (turbo.py:1980-1984)
+            up.t_next = p->sde_next_from_sched ? t_prev : 1.0f - (float)(i + 1) / (float)p->num_steps;
         }
         if (do_cfg && apply && p->use_adg)
             rc = launch_adg_step(h->vpad, (long)B * Tpad * h->OUTC, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, t_curr, dt, up, s);
@@ -672,8 +690,13 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     if (per_step_ms_host) {
         ACE_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < p->num_steps; ++i) hipEventElapsedTime(&per_step_ms_host[i], evs[i], evs[i + 1]);
-        for (auto& e : evs) hipEventDestroy(e);
     }
+    return ACE355_OK;
+}
+
+int ace355_dit_set_tap(ace355_dit* h, int layer, float* dst_dev) {
+    ACE_CHECK(h && layer >= 0 && layer < h->NL, "set_tap: layer out of range");
+    h->tap_dst[layer] = dst_dev;
     return ACE355_OK;
 }
 

@@ -125,7 +125,12 @@ class NativeDit:
                cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0, infer_method: str = "ode", use_adg: bool = False,
                cond_slot: int = SLOT_COND, null_slot: int = SLOT_NULL, cover_switch_step: Optional[int] = None,
                non_cover_slot: int = SLOT_NON_COVER, ctx_non_cover: Optional[torch.Tensor] = None,
-               return_step_ms: bool = False, sde_noise: Optional[torch.Tensor] = None):
+               return_step_ms: bool = False, sde_noise: Optional[torch.Tensor] = None,
+               cond_slots: Optional[Sequence[int]] = None, non_cover_slots: Optional[Sequence[int]] = None,
+               sde_next_from_schedule: bool = False):
+        """``cond_slots`` / ``non_cover_slots`` ([B] each): per-item condition slots inside ONE native call (the reference's
+        loop takes B distinct ``encoder_hidden_states`` rows, base.py:1905-1911); None = ``cond_slot`` for every item.
+        ``sde_next_from_schedule``: the turbo model's renoise level (next table value) instead of the base model's."""
         if infer_method not in {"ode", "sde"}:
             raise ValueError(f"Unsupported infer_method '{infer_method}'. Expected 'ode' or 'sde'.")
         B, T, _ = xt0.shape
@@ -144,10 +149,20 @@ class NativeDit:
                 raise ValueError("sde_noise must be [steps, B, T, 64]")
         else:
             sde_noise = None
+        def slot_tab(v):
+            if v is None:
+                return None
+            if len(v) != B:
+                raise ValueError("per-item slot tables must have one entry per batch item")
+            return (C.c_int32 * B)(*[int(x) for x in v])
+        ctab, nctab = slot_tab(cond_slots), slot_tab(non_cover_slots)  # kept alive until the call returns
         p = native.SampleParamsC(steps, C.cast(sched, C.POINTER(C.c_float)), float(guidance_scale), float(cfg_interval_start),
                                  float(cfg_interval_end), 0 if infer_method == "ode" else 1, 1 if use_adg else 0, cond_slot,
                                  null_slot, steps if cover_switch_step is None else int(cover_switch_step), non_cover_slot,
-                                 native.ptr(ctx_non_cover), native.ptr(sde_noise))
+                                 native.ptr(ctx_non_cover), native.ptr(sde_noise),
+                                 C.cast(ctab, C.POINTER(C.c_int32)) if ctab is not None else None,
+                                 C.cast(nctab, C.POINTER(C.c_int32)) if nctab is not None else None,
+                                 1 if sde_next_from_schedule else 0)
         out = torch.empty_like(xt0)
         ms = (C.c_float * steps)() if return_step_ms else None
         with torch.cuda.device(self.device):
@@ -156,6 +171,14 @@ class NativeDit:
         if return_step_ms:
             return out, list(ms)
         return out
+
+    # ------------------------------------------------------------------ debug taps
+    def set_tap(self, layer: int, dst: Optional[torch.Tensor]) -> None:
+        """Copy the fp32 residual stream after decoder layer ``layer`` of every following forward into ``dst``
+        ([N*S, hidden] fp32 on this device; None clears).  The caller keeps ``dst`` alive."""
+        if dst is not None:
+            assert dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous()
+        native.check(self._lib.ace355_dit_set_tap(self._h, int(layer), native.ptr(dst)), "dit_set_tap")
 
     # ------------------------------------------------------------------ profiling
     def set_profile(self, enable: bool) -> None:
@@ -175,41 +198,34 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
                      cover_noise_strength: float = 0.0, src_latents: Optional[torch.Tensor] = None,
                      encoder_hidden_states_non_cover: Optional[torch.Tensor] = None,
                      context_latents_non_cover: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
-                     sde_noise: Optional[torch.Tensor] = None) -> Dict:
+                     sde_noise: Optional[torch.Tensor] = None, sde_next_from_schedule: bool = False) -> Dict:
     """The part of ``generate_audio`` (modeling_acestep_v15_base.py:1861-1989) after ``prepare_condition``.
 
     The reference replicates ONE caption across the batch (handler/batch_prep.py:93-96), so the cross-attention
-    K/V of identical rows of ``encoder_hidden_states`` are computed once per distinct row.  Batches whose items
-    carry different conditions are not a product path of the reference handler and raise here.
+    K/V of identical rows of ``encoder_hidden_states`` are computed once per distinct row; batches whose items carry
+    different conditions (what the model's own loop accepts, base.py:1905-1911) run as ONE native call with a per-item
+    slot table.
     """
     t0 = time.time()
     B, T, _ = context_latents.shape
     enc = encoder_hidden_states
-    per_item = enc.shape[0] > 1 and not bool((enc == enc[:1]).all())
-    if not per_item and encoder_hidden_states_non_cover is not None and encoder_hidden_states_non_cover.shape[0] > 1:
-        nc = encoder_hidden_states_non_cover
-        per_item = not bool((nc == nc[:1]).all())
-    if per_item:
-        # Items with different conditions: one native call per item (the cross-K/V slots hold one condition each).
-        # The product path never needs this (one caption per batch); it keeps the generic contract of generate_audio.
-        seeds = seed if isinstance(seed, (list, tuple)) else [seed] * B
-        if noise is None:
-            noise = prepare_noise((B, T, context_latents.shape[-1] // 2), list(seeds) if isinstance(seed, (list, tuple)) else seed)
-        outs, tc = [], None
+    enc_nc = encoder_hidden_states_non_cover
+
+    def distinct(e):
+        """Slot plan for a [B or 1, L, D] condition batch: (rows to upload, per-item index into them).  The reference handler
+        replicates ONE caption across the batch (handler/batch_prep.py:93-96): identical rows share one cross-K/V slot."""
+        if e.shape[0] == 1 or bool((e == e[:1]).all()):
+            return [0], [0] * B
+        rows, idx = [], []
         for b in range(B):
-            sl = slice(b, b + 1)
-            o = generate_latents(
-                dit, null_condition_emb, enc[sl], context_latents[sl], seed=None, infer_method=infer_method, infer_steps=infer_steps,
-                diffusion_guidance_sale=diffusion_guidance_sale, cfg_interval_start=cfg_interval_start, cfg_interval_end=cfg_interval_end,
-                use_adg=use_adg, shift=shift, timesteps=timesteps, audio_cover_strength=audio_cover_strength,
-                cover_noise_strength=cover_noise_strength, src_latents=None if src_latents is None else src_latents[sl],
-                encoder_hidden_states_non_cover=None if encoder_hidden_states_non_cover is None else encoder_hidden_states_non_cover[sl],
-                context_latents_non_cover=None if context_latents_non_cover is None else context_latents_non_cover[sl],
-                noise=noise[sl], sde_noise=None if sde_noise is None else sde_noise[:, sl])
-            outs.append(o["target_latents"])
-            tc = o["time_costs"] if tc is None else {k: tc[k] + o["time_costs"][k] for k in tc}
-        tc["diffusion_per_step_time_cost"] = tc["diffusion_time_cost"] / max(1, (len(timesteps) - 1) if timesteps is not None else infer_steps)
-        return {"target_latents": torch.cat(outs, dim=0), "time_costs": tc}
+            for k, r in enumerate(rows):
+                if torch.equal(e[b], e[r]):
+                    idx.append(k)
+                    break
+            else:
+                rows.append(b)
+                idx.append(len(rows) - 1)
+        return rows, idx
     ts = schedule(infer_steps, shift, timesteps)
     steps = ts.numel() - 1
     cover_steps = int(steps * audio_cover_strength)
@@ -225,25 +241,36 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
         ts = ts[start:]
         steps = ts.numel() - 1
         cover_steps = int(steps * audio_cover_strength)
-    dit.set_condition(SLOT_COND, enc[0])
+    # slot layout of one call: [0, n_c) distinct cover / main conditions, n_c = null, then the distinct non-cover conditions
+    rows_c, idx_c = distinct(enc)
+    n_c = len(rows_c)
+    for k, r in enumerate(rows_c):
+        dit.set_condition(k, enc[r])
     do_cfg = diffusion_guidance_sale > 1.0
+    null_slot = n_c
     if do_cfg:
-        dit.set_condition(SLOT_NULL, null_condition_emb.reshape(1, -1), L=enc.shape[1])
-    ctx_nc = None
+        dit.set_condition(null_slot, null_condition_emb.reshape(1, -1), L=enc.shape[1])
+    ctx_nc, nc_slots = None, None
     if cover_steps < steps:
-        enc_nc = encoder_hidden_states_non_cover
         if enc_nc is None or context_latents_non_cover is None:
             raise ValueError("audio_cover_strength < 1 needs the non-cover conditions")
         if enc_nc.shape[1] != enc.shape[1]:
             raise NotImplementedError("ace355: cover / non-cover conditions must share the encoder length")
-        dit.set_condition(SLOT_NON_COVER, enc_nc[0])
+        rows_n, idx_n = distinct(enc_nc)
+        if n_c + 1 + len(rows_n) > native.MAX_SLOTS:
+            raise ValueError("too many distinct conditions for one call")
+        for k, r in enumerate(rows_n):
+            dit.set_condition(n_c + 1 + k, enc_nc[r])
+        nc_slots = [n_c + 1 + k for k in idx_n]
         ctx_nc = context_latents_non_cover
     t1 = time.time()
     if use_adg and B > 1:
         # the reference's adg_forward only broadcasts for batch 1 (apg_guidance.py:150-168 multiplies [n*t,1] by [n,t,c])
         raise ValueError("use_adg is only defined for batch size 1 in the reference")
     out = dit.sample(xt0, context_latents, ts, diffusion_guidance_sale, cfg_interval_start, cfg_interval_end, infer_method,
-                     use_adg, cover_switch_step=cover_steps, ctx_non_cover=ctx_nc, sde_noise=sde_noise)
+                     use_adg, cond_slot=idx_c[0], null_slot=null_slot, cover_switch_step=cover_steps,
+                     non_cover_slot=nc_slots[0] if nc_slots else 0, ctx_non_cover=ctx_nc, sde_noise=sde_noise,
+                     cond_slots=idx_c, non_cover_slots=nc_slots, sde_next_from_schedule=sde_next_from_schedule)
     torch.cuda.synchronize(dit.device)
     t2 = time.time()
     return {"target_latents": out,
@@ -289,4 +316,5 @@ def generate_latents_turbo(dit: NativeDit, encoder_hidden_states: torch.Tensor, 
                             infer_steps=len(table), diffusion_guidance_sale=1.0, shift=shift, timesteps=table + [0.0],
                             audio_cover_strength=audio_cover_strength, cover_noise_strength=cover_noise_strength, src_latents=src_latents,
                             encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
-                            context_latents_non_cover=context_latents_non_cover, noise=noise, sde_noise=sde_noise)
+                            context_latents_non_cover=context_latents_non_cover, noise=noise, sde_noise=sde_noise,
+                            sde_next_from_schedule=True)  # "sde": renoise to the next TABLE value (turbo.py:1980-1984)

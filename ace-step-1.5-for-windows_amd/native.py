@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "lib
 OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_BLOCKS = 8
+MAX_SLOTS = 32
 
 
 class DitConfigC(C.Structure):
@@ -34,7 +35,8 @@ class SampleParamsC(C.Structure):
         ("cfg_interval_start", C.c_float), ("cfg_interval_end", C.c_float), ("infer_method", C.c_int32),
         ("use_adg", C.c_int32), ("cond_slot", C.c_int32), ("null_slot", C.c_int32),
         ("cover_switch_step", C.c_int32), ("non_cover_slot", C.c_int32), ("ctx_non_cover_dev", C.c_void_p),
-        ("sde_noise_dev", C.c_void_p),
+        ("sde_noise_dev", C.c_void_p), ("cond_slots_host", C.POINTER(C.c_int32)), ("non_cover_slots_host", C.POINTER(C.c_int32)),
+        ("sde_next_from_sched", C.c_int32),
     ]
 
 
@@ -76,6 +78,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_dit_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(SampleParamsC),
                                     C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
+    "ace355_dit_set_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ace355_dit_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -116,6 +119,10 @@ SIGNATURES = {
     "ace355_gemm_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_gemm_bf16_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ace355_gemm_bf16_residual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "ace355_gemm_bf16_headnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "ace355_rmsnorm_mod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ace355_headnorm_rope": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int,

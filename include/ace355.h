@@ -40,6 +40,7 @@ extern "C" {
 
 #define ACE355_MAX_BLOCKS 8
 #define ACE355_MAX_SEQS 64
+#define ACE355_MAX_SLOTS 32 /* resident condition slots per DiT handle: 8 cover + 8 non-cover per-item conditions + null + spare */
 
 const char* ace355_last_error(void);
 int ace355_version(void);
@@ -84,7 +85,7 @@ int ace355_dit_finalize(ace355_dit* h);
  * K = k_norm(k_proj(.)), V = v_proj(.) ONCE (the reference's EncoderDecoderCache,
  * base.py:312-329, 1875) and keeps them resident until the slot is overwritten.
  * enc: dev f32 [rows, hidden]; rows == L, or rows == 1 to broadcast one row over L keys
- * (null_condition_emb.expand_as, base.py:1907).  slot in [0, 8). */
+ * (null_condition_emb.expand_as, base.py:1907).  slot in [0, ACE355_MAX_SLOTS). */
 int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int rows, int L, void* stream);
 
 /* One decoder forward = AceStepDiTModel.forward (base.py:1303-1507) with use_cache=True and
@@ -109,6 +110,13 @@ typedef struct ace355_sample_params {
     const float* ctx_non_cover_dev; /* dev f32 [B,T,128] or NULL */
     const float* sde_noise_dev;     /* "sde" only: dev f32 [num_steps,B,T,64], the per-step randn_like(x) draws of base.py:1777
                                      * (the reference draws them unseeded on the model device; the caller owns the RNG) */
+    /* Per-item conditions inside one call: the reference's loop takes B distinct encoder_hidden_states rows
+     * (base.py:1905-1911, switch :1916-1927).  host int32 [B] each, or NULL = every item uses cond_slot / non_cover_slot.
+     * All slots of one call must hold the same encoder length L. */
+    const int32_t* cond_slots_host;
+    const int32_t* non_cover_slots_host;
+    int32_t sde_next_from_sched;    /* "sde" renoise level after step i: 0 = 1 - (i+1)/num_steps (base / sft, base.py:1972);
+                                     * 1 = t_sched[i+1] (turbo model, models/turbo/modeling_acestep_v15_turbo.py:1980-1984) */
 } ace355_sample_params;
 
 /* The sampling loop of generate_audio (base.py:1913-1981): CFG doubling, steps x {decoder forward,
@@ -119,6 +127,11 @@ typedef struct ace355_sample_params {
  * per_step_ms_host (optional, [num_steps]) receives HIP-event step times. */
 int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev, int B, int T,
                       const ace355_sample_params* p, float* latents_out_dev, float* per_step_ms_host, void* stream);
+
+/* Test / debug hook: after decoder layer `layer` (0-based) of every following forward, copy the fp32 residual stream
+ * hidden_states [N*S, hidden] (the layer's output, base.py:539) to dst_dev; dst_dev NULL clears the tap.  Lets the parity
+ * tests compare the per-layer activations the golden fixtures hold, not only the final velocity. */
+int ace355_dit_set_tap(ace355_dit* h, int layer, float* dst_dev);
 
 /* Work counters for roofline accounting: algorithmic FLOPs of the last forward (SURVEY.md section 8d formula)
  * and GEMM-only HIP-event time when profiling was enabled with ace355_dit_set_profile(h, 1). */
@@ -298,6 +311,19 @@ int ace355_gemm_bf16(const void* A_dev, const void* W_dev, void* C_dev, int M, i
  * (NULL g1 -> gate 1);  mode 1: out[M,N/2] (bf16) = silu(gate) * up with W rows interleaved [32 gate | 32 up]. */
 int ace355_gemm_bf16_fused(const void* A_dev, const void* W_dev, void* out_dev, int M, int N, int K, int mode,
                            const float* g1_dev, const float* g2_dev, int g2_stride, int rows_per_seq, void* stream);
+/* Residual GEMM with the whole epilogue of the DiT's o_proj / down_proj launches (gemm.hip mode 2): H[M,N] (f32) += gate * (A W^T),
+ * gate as in ace355_gemm_bf16_fused mode 0, plus cvec[n] on rows m >= cvec_row0 (the constant cross-attention term of the CFG
+ * null branch, dit.hip forward_core).  cvec NULL: none. */
+int ace355_gemm_bf16_residual(const void* A_dev, const void* W_dev, float* H_dev, int M, int N, int K, const float* g1_dev,
+                              const float* g2_dev, int g2_stride, int rows_per_seq, const float* cvec_dev, int cvec_row0,
+                              void* stream);
+/* Projection GEMM with q / k head RMSNorm (+ RoPE when rope != 0) in its epilogue (gemm.hip mode 4; base.py:304, 338-343):
+ * columns [0, q_cols) are q heads (norm weight wq [128]), [q_cols, qk_cols) k heads (wk), the rest pass through (v).
+ * W bf16 [N,K] in the REFERENCE's row order; with rope the hook packs q / k rows into the library's head-pair order and the
+ * q / k output columns of a head come back in that order too: dims (d, d+64) in columns (2d, 2d+1).  pos = row % rows_per_seq. */
+int ace355_gemm_bf16_headnorm(const void* A_dev, const void* W_dev, void* out_bf16_dev, int M, int N, int K, int q_cols,
+                              int qk_cols, const float* wq_dev, const float* wk_dev, float eps, int rope, int rows_per_seq,
+                              float theta, void* stream);
 /* y = bf16( rmsnorm(x; w, eps) * (1 + sc) + sh ), sc[n] = sc1[n] + sc2[(m / rows_per_seq)*stride + n] (NULL -> no modulation). */
 int ace355_rmsnorm_mod(const float* x_dev, const float* w_dev, void* y_bf16_dev, int M, int D, float eps,
                        const float* sc1, const float* sc2, const float* sh1, const float* sh2, int stride,

@@ -70,8 +70,14 @@ def generate_audio(
     context_latents_non_cover: Optional[Tensor] = None,
     noise: Optional[Tensor] = None,
     trace: Optional[list] = None,
+    sde_noise: Optional[Tensor] = None,
+    sde_next_from_schedule: bool = False,
 ) -> Tensor:
-    """The sampling loop of base.py:1861-1989 given prepared conditions; returns target_latents [B,T,64]."""
+    """The sampling loop of base.py:1861-1989 given prepared conditions; returns target_latents [B,T,64].
+
+    ``sde_noise`` [steps,B,T,64] replaces the unseeded per-step ``randn_like`` draws of the "sde" branch (so that it can be
+    replayed); ``sde_next_from_schedule`` selects the TURBO model's renoise level ``t_schedule[step_idx + 1]``
+    (turbo.py:1980-1984) instead of the base model's ``1 - (step_idx + 1) / infer_steps`` (base.py:1972)."""
     dtype = context_latents.dtype
     bsz = context_latents.shape[0]
     t = schedule(infer_steps, shift, timesteps, dtype)
@@ -127,8 +133,9 @@ def generate_audio(
         if infer_method == "sde":  # base.py:1968-1973 (unseeded renoise: not reproducible)
             tb = t_curr * torch.ones((bsz,), dtype=dtype)
             clean = xt - vt * tb[:, None, None]
-            nt = 1.0 - (float(step_idx + 1) / infer_steps)
-            xt = nt * torch.randn_like(clean) + (1 - nt) * clean
+            nt = float(t_prev) if sde_next_from_schedule else 1.0 - (float(step_idx + 1) / infer_steps)
+            eps = torch.randn_like(clean) if sde_noise is None else sde_noise[step_idx].to(dtype)
+            xt = nt * eps + (1 - nt) * clean
         elif infer_method == "ode":  # base.py:1974-1979
             dt = t_curr - t_prev
             xt = xt - vt * (dt * torch.ones((bsz,), dtype=dtype))[:, None, None]
@@ -166,12 +173,16 @@ def generate_audio_turbo(cfg: DitConfig, w: Dict[str, Tensor], encoder_hidden_st
                          seed: Union[int, List[int], None] = None, shift: float = 3.0, timesteps: Optional[Sequence[float]] = None,
                          infer_method: str = "ode", audio_cover_strength: float = 1.0, cover_noise_strength: float = 0.0,
                          src_latents: Optional[Tensor] = None, encoder_hidden_states_non_cover: Optional[Tensor] = None,
-                         context_latents_non_cover: Optional[Tensor] = None, noise: Optional[Tensor] = None) -> Tensor:
+                         context_latents_non_cover: Optional[Tensor] = None, noise: Optional[Tensor] = None,
+                         sde_noise: Optional[Tensor] = None) -> Tensor:
     """Sampling loop of the turbo model (turbo.py:1780-1995) given prepared conditions: no CFG / null branch, the last step is
-    ``x0 = xt - vt * t`` (:1976-1978), i.e. the base loop on ``table + [0]`` with guidance 1 (no momentum, no interval)."""
+    ``x0 = xt - vt * t`` (:1976-1978), i.e. the base loop on ``table + [0]`` with guidance 1 (no momentum, no interval).
+    "sde" renoises to the NEXT TABLE VALUE (turbo.py:1980-1984), not to the base model's linear level; the last step's level
+    is the appended 0, which reproduces ``x0 = xt - vt * t`` for both methods."""
     table = turbo_schedule(shift, timesteps)
     return generate_audio(cfg, w, torch.zeros(1, 1, cfg.hidden_size), encoder_hidden_states, context_latents, seed=seed,
                           infer_method=infer_method, infer_steps=len(table), diffusion_guidance_sale=1.0, shift=shift,
                           timesteps=table + [0.0], audio_cover_strength=audio_cover_strength, cover_noise_strength=cover_noise_strength,
                           src_latents=src_latents, encoder_hidden_states_non_cover=encoder_hidden_states_non_cover,
-                          context_latents_non_cover=context_latents_non_cover, noise=noise)
+                          context_latents_non_cover=context_latents_non_cover, noise=noise, sde_noise=sde_noise,
+                          sde_next_from_schedule=True)

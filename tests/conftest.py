@@ -27,3 +27,25 @@ def gpu_device():
     from ace355 import native
     native.lib()
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def full_dit_seed4(gpu_device):
+    """The real architecture (24 layers, 2048 hidden, 1.575 B parameters) with weightgen seed-4 "test" weights, i.e. the
+    weights the full-size fixtures G4 / G11 / G12 / G13 were captured with; 6.3 GB of fp32 streamed tensor by tensor through
+    the C ABI once per session.  Yields (dit, cfg, null_condition_emb, weight_checksum)."""
+    import torch
+    import ace355
+    from ace355 import native, weightgen
+    from ace355.dit import NativeDit
+    cfg = ace355.DitConfig()
+    dit = NativeDit(cfg, gpu_device)
+    wsum = 0.0
+    for name, shape in cfg.weight_shapes().items():
+        wt = weightgen.make_dit_weights({name: shape}, cfg.hidden_size, seed=4, mode="test")[name]
+        wsum += float(wt.double().abs().sum())
+        native.check(dit._lib.ace355_dit_load_tensor(dit._h, name.encode(), native.ptr(wt.contiguous()), 0, wt.numel(), 0), name)
+    native.check(dit._lib.ace355_dit_finalize(dit._h), "finalize")
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=4)
+    yield dit, cfg, null, wsum
+    dit.close()

@@ -31,13 +31,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.ace355_version() >= 100
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of every struct crossing the ABI, taken from the HEADER by the C compiler, vs the ctypes mirrors."""
+    import subprocess
     from ace355 import native
-    assert ctypes.sizeof(native.DitConfigC) == 10 * 4 + 2 * 4 + 8
-    assert ctypes.sizeof(native.VaeConfigC) == 4 * 4 + 2 * 8 * 4
-    assert ctypes.sizeof(native.SampleParamsC) == 72
-    assert ctypes.sizeof(native.CondConfigC) == 10 * 4 + 8 + 2 * 4
-    assert ctypes.sizeof(native.DetokConfigC) == 9 * 4 + 4 + 8 + 2 * 4
+    structs = {"ace355_dit_config": native.DitConfigC, "ace355_vae_config": native.VaeConfigC,
+               "ace355_sample_params": native.SampleParamsC, "ace355_cond_config": native.CondConfigC,
+               "ace355_detok_config": native.DetokConfigC}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ace355.h"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _t in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(ct), cname
+        for fname, _t in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+    assert ctypes.sizeof(native.SampleParamsC) == 96
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -121,6 +121,112 @@ def test_native_run_diffusion_routes_turbo_checkpoints(monkeypatch):
     assert calls["base"]["infer_steps"] == 27
 
 
+def test_explicit_timesteps_follow_the_checkpoint_family(monkeypatch):
+    """The BASE model's generate_audio has no ``timesteps`` parameter (it lands in **kwargs; the schedule is always linspace +
+    shift, base/modeling_acestep_v15_base.py:1812, 1864-1867); sft and turbo read it (sft :1864-1875).  The native seam follows
+    the loaded checkpoint: signature probe on ``self.model.generate_audio``, or ``model_variant`` on the host."""
+    from ace355 import dit as a_dit
+    calls = {}
+
+    def fake_base(native, null, enc, ctx, **kw):
+        calls["ts"] = kw["timesteps"]
+        return {"target_latents": torch.zeros(enc.shape[0], ctx.shape[1], 64), "time_costs": {}}
+
+    monkeypatch.setattr(a_dit, "generate_latents", fake_base)
+    ts = [1.0, 0.6, 0.2, 0.0]
+
+    class BaseModel:
+        null_condition_emb = torch.zeros(1, 1, 8)
+
+        def generate_audio(self, src_latents, seed=None, shift=1.0, **kwargs):  # base-family signature
+            pass
+
+    class SftModel(BaseModel):
+        def generate_audio(self, src_latents, seed=None, shift=1.0, timesteps=None, **kwargs):  # sft-family signature
+            pass
+
+    h = _DitHost()
+    h.model = BaseModel()
+    h._native_run_diffusion(**_args(), timesteps=ts)
+    assert calls["ts"] is None
+    h.model = SftModel()
+    h._native_run_diffusion(**_args(), timesteps=torch.tensor(ts))
+    assert calls["ts"] == pytest.approx(ts)
+    h.model = BaseModel()
+    h.model_variant = "sft"  # explicit override beats the probe
+    h._native_run_diffusion(**_args(), timesteps=ts)
+    assert calls["ts"] == ts
+    nh = NativeHandler()
+    assert nh.model_variant == "sft" and nh._model_honours_timesteps()
+    nh.model_variant = "base"
+    assert not nh._model_honours_timesteps() and not nh._is_turbo()
+    nh.model_variant = "turbo"
+    assert nh._is_turbo()
+    msg, ok = NativeHandler().initialize_service(ace355.DitConfig(), {}, torch.zeros(1, 1, 8), device="cpu", model_variant="bogus")
+    assert not ok and "model_variant" in msg
+
+
+def test_from_reference_without_sliding_window_means_full_attention():
+    """use_sliding_window False / sliding_window None: the reference never builds the band mask (base.py:1397, 1431-1440 ->
+    sliding_attn_mask None = full attention) although layer_types still alternates; a window of 0 would be a one-key band."""
+    import types
+    base = dict(hidden_size=256, intermediate_size=768, num_hidden_layers=4, num_attention_heads=2, num_key_value_heads=1, head_dim=128,
+                rms_norm_eps=1e-6, rope_theta=1e6, patch_size=2, in_channels=192, audio_acoustic_hidden_dim=64,
+                layer_types=["sliding_attention", "full_attention"] * 2)
+    on = ace355.DitConfig.from_reference(types.SimpleNamespace(**base, sliding_window=128, use_sliding_window=True))
+    assert on.layer_types == base["layer_types"] and on.sliding_window == 128
+    for off in (dict(sliding_window=None, use_sliding_window=False), dict(sliding_window=None), dict(sliding_window=128, use_sliding_window=False)):
+        c = ace355.DitConfig.from_reference(types.SimpleNamespace(**base, **off))
+        assert c.layer_types == ["full_attention"] * 4, off
+
+
+def test_module_swap_on_a_real_nn_module_parent():
+    """model.encoder / model.detokenizer are registered child modules (base.py:1571-1573): a plain object cannot be assigned
+    there (TypeError) and nothing around prepare_condition catches a native failure.  NativeModuleSwap is assignable, answers
+    state_dict() with the reference's keys and falls back to the kept module when the native call raises."""
+    from ace355.modswap import NativeModuleSwap, swap_in
+
+    class Enc(torch.nn.Linear):
+        def forward(self, x, mask=None):
+            return super().forward(x)
+
+    class Parent(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = Enc(4, 3)
+
+    class FakeNative:
+        calls = 0
+
+        def __init__(self, ref):
+            self.w = ref.weight.detach().clone()
+
+        @classmethod
+        def from_reference(cls, ref, device, out_dtype):
+            return cls(ref)
+
+        def __call__(self, x, mask=None):
+            if mask is not None:
+                raise ValueError("prefix masks only")
+            FakeNative.calls += 1
+            return x @ self.w.t() * 2.0  # distinguishable from the reference path
+
+    p = Parent()
+    keys = set(p.state_dict())
+    with pytest.raises(TypeError):
+        p.encoder = FakeNative(p.encoder)  # what INTEGRATION.md used to suggest
+    ref_mod = p.encoder
+    w = swap_in(p, "encoder", FakeNative, "cpu")
+    assert isinstance(p.encoder, NativeModuleSwap) and p.encoder is w
+    assert set(p.state_dict()) == keys
+    x = torch.randn(2, 4)
+    assert torch.allclose(p.encoder(x), x @ ref_mod.weight.t() * 2.0) and FakeNative.calls == 1 and w.native_failures == 0
+    assert torch.allclose(p.encoder(x, mask=torch.ones(2)), ref_mod(x)) and w.native_failures == 1  # fell back, did not raise
+    assert p.encoder.in_features == 4  # attribute passthrough to the module it stands in for
+    w2 = swap_in(p, "encoder", FakeNative, "cpu")  # re-entry keeps the ORIGINAL module as the fallback
+    assert w2._reference is ref_mod
+
+
 def test_init_native_refuses_lora_quant_offload_and_never_raises():
     for flag in ("use_lora", "quantization", "offload_to_cpu"):
         h = _DitHost()

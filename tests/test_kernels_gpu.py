@@ -76,7 +76,72 @@ def test_gemm_residual_gate(lib, gpu_device, M, N, K, rows):
     assert _rel(out2, H + A.float() @ W.float().t()) < 2e-5
 
 
-@pytest.mark.parametrize("M,Fh,K", [(300, 768, 256), (1000, 6144, 2048)])
+# ---- the instantiations the headline runs (profiles/*_bench_kernel_stats.csv): M = 6000 = 16 x 375 token rows (192x256 persistent
+# tiles), Mc = 3000 cross-attention rows (192x128 mid tile), and the batch-1 regime M = 750 / 375 (4-wave deep-pipeline tiles,
+# split-K residuals).  Reference = plain fp32 matmul of the same bf16 operands on the GPU.
+@pytest.mark.parametrize("M,N,K,rows,cvec_row0", [
+    (6000, 2048, 2048, 375, 3000),   # o_proj: gemm_sp_kernel<2,3,4,2,0,2>-class launch (one round of 256 tiles) + constant null term
+    (6000, 2048, 6144, 375, -1),     # down_proj (K = 6144)
+    (3000, 2048, 2048, 375, -1),     # cross-attention o_proj: 192x128 mid tile, plain residual
+    (750, 2048, 2048, 375, 375),     # batch 1: split-K over blockIdx.y, fp32 atomics
+    (750, 2048, 6144, 375, -1),
+    (375, 2048, 2048, 375, -1)])
+def test_gemm_residual_metric_shapes(lib, gpu_device, M, N, K, rows, cvec_row0):
+    g = torch.Generator().manual_seed(M + K)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    W = _bf(torch.randn(N, K, generator=g) * 0.02).to(gpu_device)
+    H = torch.randn(M, N, generator=g).to(gpu_device)
+    nseq = (M + rows - 1) // rows
+    gated = cvec_row0 != -1 or K == 6144
+    g1 = torch.randn(N, generator=g).to(gpu_device)
+    g2 = torch.randn(nseq, 6, N, generator=g).to(gpu_device)
+    cvec = torch.randn(N, generator=g).to(gpu_device) if cvec_row0 >= 0 else None
+    seq = torch.arange(M, device=gpu_device) // rows
+    prod = A.float() @ W.float().t()
+    ref = H + ((g1[None] + g2[seq, 5]) * prod if gated else prod)
+    if cvec is not None:
+        ref[cvec_row0:] += cvec
+    out = H.clone()
+    _chk(lib.ace355_gemm_bf16_residual(_p(A), _p(W), _p(out), M, N, K, _p(g1) if gated else None,
+                                       g2[:, 5].data_ptr() if gated else None, 6 * N, rows, _p(cvec), max(cvec_row0, 0), None))
+    r = _rel(out - H, ref - H)  # on the UPDATE, so that H does not mask an error in it
+    print(f"residual GEMM M={M} N={N} K={K}: rel L2 of the update {r:.2e}")
+    assert r < 2e-5, r
+
+
+@pytest.mark.parametrize("M,N,K,q_cols,qk_cols,rope,rows", [
+    (6000, 4096, 2048, 2048, 3072, 1, 375),   # self-attention QKV: persistent 192x256, head-norm + RoPE on q / k, v passes through
+    (3000, 2048, 2048, 2048, 2048, 0, 375),   # cross-attention q: 192x128 mid tile, head-norm only
+    (750, 4096, 2048, 2048, 3072, 1, 375),    # batch 1: 4-wave deep-pipeline tile with the same epilogue
+    (375, 2048, 2048, 2048, 2048, 0, 375)])
+def test_gemm_headnorm_rope_metric_shapes(lib, gpu_device, M, N, K, q_cols, qk_cols, rope, rows):
+    from oracle import dit as o_dit
+    g = torch.Generator().manual_seed(M + N)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    W = _bf(torch.randn(N, K, generator=g) * 0.02).to(gpu_device)
+    wq = (1 + 0.1 * torch.randn(128, generator=g)).to(gpu_device)
+    wk = (1 + 0.1 * torch.randn(128, generator=g)).to(gpu_device)
+    y = (A.float() @ W.float().t())
+    ref = y.clone()
+    cos, sin = o_dit.rope_cos_sin(rows, 128, 1e6)
+    pos = torch.arange(M, device=gpu_device) % rows
+    cos, sin = cos.to(gpu_device)[pos][:, None], sin.to(gpu_device)[pos][:, None]  # [M,1,128]
+    for c0, c1, w in ((0, q_cols, wq), (q_cols, qk_cols, wk)):
+        if c1 == c0:
+            continue
+        h = o_dit.rms_norm(y[:, c0:c1].reshape(M, -1, 128), w, 1e-6)
+        if rope:
+            h = h * cos + o_dit.rotate_half(h) * sin
+            h = torch.stack([h[..., :64], h[..., 64:]], -1).reshape(M, -1, 128)  # library order: dims (d, d+64) adjacent
+        ref[:, c0:c1] = h.reshape(M, -1)
+    out = torch.empty(M, N, device=gpu_device, dtype=torch.bfloat16)
+    _chk(lib.ace355_gemm_bf16_headnorm(_p(A), _p(W), _p(out), M, N, K, q_cols, qk_cols, _p(wq), _p(wk), 1e-6, rope, rows, 1e6, None))
+    r_qk, r_v = _rel(out[:, :qk_cols], ref[:, :qk_cols]), (_rel(out[:, qk_cols:], ref[:, qk_cols:]) if N > qk_cols else 0.0)
+    print(f"head-norm GEMM M={M} N={N} rope={rope}: rel L2 q/k {r_qk:.2e}, v {r_v:.2e}")
+    assert r_qk < 5e-3 and r_v < 4e-3, (r_qk, r_v)  # one or two bf16 roundings (2^-9 each)
+
+
+@pytest.mark.parametrize("M,Fh,K", [(300, 768, 256), (1000, 6144, 2048), (6000, 6144, 2048), (750, 6144, 2048)])
 def test_gemm_swiglu(lib, gpu_device, M, Fh, K):
     g = torch.Generator().manual_seed(9)
     A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
@@ -136,7 +201,12 @@ def test_headnorm_rope(lib, gpu_device, N, S, heads, rope):
 
 @pytest.mark.parametrize("N,Sq,Skv,Hq,Hkv,window", [
     (2, 375, 375, 16, 8, -1), (2, 375, 375, 16, 8, 128), (1, 300, 300, 2, 1, 16), (2, 375, 769, 16, 8, -1),
-    (1, 20, 33, 2, 1, -1), (1, 1500, 1500, 4, 2, 128), (1, 129, 129, 2, 2, 128), (1, 64, 1, 2, 1, -1)])
+    (1, 20, 33, 2, 1, -1), (1, 1500, 1500, 4, 2, 128), (1, 129, 129, 2, 2, 128), (1, 64, 1, 2, 1, -1),
+    # attn3_kernel<8> (256-query blocks; chosen when Sq >= 1024 and heads x ceil(Sq / 256) >= 512): configs[2]'s self-attention,
+    # full and banded, a ragged last query block (1500 = 5 x 256 + 220) and its cross-attention shape (769 keys)
+    (6, 1500, 1500, 16, 8, -1), (6, 1500, 1500, 16, 8, 128), (6, 1500, 769, 16, 8, -1),
+    # the metric's attn3_kernel<4> launches at N = 16
+    (16, 375, 375, 16, 8, -1), (16, 375, 375, 16, 8, 128), (8, 375, 769, 16, 8, -1)])
 def test_attention(lib, gpu_device, N, Sq, Skv, Hq, Hkv, window):
     from oracle import dit as o_dit
     g = torch.Generator().manual_seed(Sq + Skv + Hq)

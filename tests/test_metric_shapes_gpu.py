@@ -1,0 +1,128 @@
+"""GPU parity AT THE SHAPES THE HEADLINE RUNS (BASELINE.json metric: 30 s, batch 8, CFG => N = 16 sequences, M = 6000 token rows,
+Mc = 3000 cross-attention rows) and at configs[2] (120 s, S = 1500), against vectors captured from the imported reference
+(tests/golden/make_golden.py g11 / g12 / g13, full-size architecture, fp32 CPU).  These are the launches bench.py times:
+192x256 persistent tiles, the 192x128 mid tile, the residual / SwiGLU / head-norm epilogues at M = 6000, attn3_kernel<4> at
+N = 16 and attn3_kernel<8> at S = 1500.  Inputs are regenerated from seeds (CPU generators) and pinned by checksums.
+
+Gates are 2-3x the values measured on MI355X (printed by every test; DESIGN.md section 3 lists them).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _inputs(B, T, seed0=1000, ctx_seed=45):
+    """Same construction as make_golden.metric_inputs (prepare_noise per-item CPU generators, base.py:1733-1770)."""
+    from ace355.dit import prepare_noise
+    x = prepare_noise((B, T, 64), [seed0 + i for i in range(B)])
+    g = torch.Generator().manual_seed(ctx_seed)
+    ctx1 = torch.cat([0.5 * torch.randn(1, T, 64, generator=g), torch.ones(1, T, 64)], -1)
+    return x, ctx1
+
+
+def _close(a, b):
+    return abs(a - b) <= 1e-9 * abs(b)
+
+
+def test_metric_shape_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
+    """G11: AceStepDiTModel.forward (base.py:1303-1507) at N = 16 (8 conditional + 8 null_condition_emb.expand_as, :1905-1911),
+    T = 750, L = 769: velocity of all 16 sequences + residual-stream taps after layers 0 and 23."""
+    G = np.load(f"{golden_dir}/g11_metric_forward.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    assert abs(wsum - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    x8, ctx1 = _inputs(B, T)
+    assert _close(float(x8.double().abs().sum()), float(G["x_sum"])) and _close(float(ctx1.double().abs().sum()), float(G["ctx_sum"]))
+    x = torch.cat([x8, x8], 0)
+    ctx = ctx1.expand(2 * B, -1, -1).contiguous()
+    dit.set_condition(0, enc[0])
+    dit.set_condition(1, null.reshape(1, -1), L=enc.shape[1])
+    S, N = T // 2, 2 * B
+    taps = {li: torch.empty(N * S, cfg.hidden_size, device=gpu_device) for li in (0, 23)}
+    for li, buf in taps.items():
+        dit.set_tap(li, buf)
+    try:
+        t = [float(G["t"])] * N
+        v = dit.forward(x, ctx, t, t, [0] * B + [1] * B)
+        torch.cuda.synchronize()
+    finally:
+        for li in taps:
+            dit.set_tap(li, None)
+    ref = torch.from_numpy(G["v"])
+    seqs, stride = G["tap_seqs"].tolist(), int(G["tap_stride"])
+    r = _rel(v, ref)
+    r_c, r_u = _rel(v[:B], ref[:B]), _rel(v[B:], ref[B:])
+    r0 = _rel(taps[0].view(N, S, -1)[seqs][:, ::stride], torch.from_numpy(G["l0_out"]))
+    r23 = _rel(taps[23].view(N, S, -1)[seqs][:, ::stride], torch.from_numpy(G["l23_out"]))
+    print(f"metric-shape forward (N=16, T=750): rel L2 vs reference fp32 = {r:.3e} (cond {r_c:.3e}, null {r_u:.3e}); "
+          f"taps layer 0 {r0:.3e}, layer 23 {r23:.3e}")
+    assert torch.isfinite(v).all()
+    assert r < 1.5e-2 and r_c < 1.5e-2 and r_u < 1.5e-2, (r, r_c, r_u)
+    assert r0 < 6e-3 and r23 < 1.5e-2, (r0, r23)
+
+
+def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
+    """G12: generate_audio (base.py:1783-1989) at the metric batch - 8 songs x 30 s, CFG 7 + APG, 3 steps - through
+    ace355_dit_sample: the exact launch sequence bench.py times (shared timestep row, null-branch shortcut, 192x256 tiles)."""
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g12_metric_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    assert abs(wsum - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    _, ctx1 = _inputs(B, T)
+    assert _close(float(ctx1.double().abs().sum()), float(G["ctx_sum"]))
+    out = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G["seeds"].tolist(),
+                           infer_steps=int(G["steps"]), diffusion_guidance_sale=float(G["guidance"]))["target_latents"]
+    ref = torch.from_numpy(G["out"])
+    r = _rel(out, ref)
+    per = [_rel(out[i], ref[i]) for i in range(B)]
+    print(f"metric-batch sampler (B=8, 3 steps, CFG 7 + APG): rel L2 vs reference fp32 = {r:.3e}; per item max {max(per):.3e}")
+    assert r < 1e-2 and max(per) < 1.5e-2, (r, per)
+
+
+def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, full_dit_seed4):
+    """G13 / BASELINE configs[2] (120 s, T = 3000, S = 1500): a CFG pair vs the reference (attn3_kernel<4>: 32 (seq, head) pairs do
+    not fill the chip with 256-row blocks), then the same pair inside a batch of N = 16, where launch_attention switches to
+    attn3_kernel<8> and the GEMMs to M = 24000 rows: the two runs must agree and both match the reference."""
+    G = np.load(f"{golden_dir}/g13_120s_forward.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    assert abs(wsum - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    T = 3000
+    x1, ctx1 = _inputs(1, T, seed0=2000, ctx_seed=46)
+    assert _close(float(x1.double().abs().sum()), float(G["x_sum"])) and _close(float(ctx1.double().abs().sum()), float(G["ctx_sum"]))
+    dit.set_condition(0, enc[0])
+    dit.set_condition(1, null.reshape(1, -1), L=enc.shape[1])
+    t = float(G["t"])
+    ref = torch.from_numpy(G["v"])
+    S = T // 2
+    tap = torch.empty(2 * S, cfg.hidden_size, device=gpu_device)
+    dit.set_tap(23, tap)
+    try:
+        v2 = dit.forward(torch.cat([x1, x1]), ctx1.expand(2, -1, -1).contiguous(), [t, t], [t, t], [0, 1])
+        torch.cuda.synchronize()
+    finally:
+        dit.set_tap(23, None)
+    r2 = _rel(v2, ref)
+    r23 = _rel(tap.view(2, S, -1)[:, ::100], torch.from_numpy(G["l23_out"]))
+    # batch of 16: item 3 (cond) and item 11 (null) carry the golden pair, the rest other seeds
+    xo, _ = _inputs(8, T, seed0=3000, ctx_seed=46)
+    xo[3] = x1[0]
+    v16 = dit.forward(torch.cat([xo, xo]), ctx1.expand(16, -1, -1).contiguous(), [t] * 16, [t] * 16, [0] * 8 + [1] * 8)
+    pair = torch.stack([v16[3], v16[11]])
+    r16, rx = _rel(pair, ref), _rel(pair, v2)
+    print(f"120 s forward: N=2 vs reference {r2:.3e} (layer-23 tap {r23:.3e}); inside N=16 (attn3_kernel<8>) vs reference {r16:.3e}, "
+          f"vs the N=2 run {rx:.3e}")
+    assert torch.isfinite(v16).all()
+    assert r2 < 1.5e-2 and r16 < 1.5e-2 and r23 < 1.5e-2, (r2, r16, r23)
+    assert rx < 8e-3, rx
+    assert _rel(v16[2], v16[3]) > 0.3  # other seeds really are other songs

@@ -5,7 +5,10 @@ One "step" = one pass of the hot path over one batch of synthetic input on every
   RCCL broadcast of the conditioning bundle (N > 1) -> cross-K/V build for the cond / null slots ->
   27-step flow-matching sampler with CFG 7.0 + APG (2B sequences per DiT forward) -> Oobleck decode to
   48 kHz stereo fp32 -> peak normalise.   Workload at N=1: 30 s audio, 27 steps, batch 8 (the metric's config).
-Scaling is weak: every rank runs the reference's per-call cap of 8 songs (handler/service_generate_request.py:12).
+Scaling: weak by default - every rank runs the reference's per-call cap of 8 songs (handler/service_generate_request.py:12);
+`--scaling strong` splits ONE global batch of `--batch` songs over the ranks in contiguous slices (8/4/2/1 songs
+per rank at 1/2/4/8 GPUs).  `python bench.py --gpus N` with N > 1 outside torchrun re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU over RCCL).
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job songs/s with inputs resident
 in HBM, plus `roofline` (dominant kernel = the bf16 MFMA GEMM, HIP-event timed) and `cpu_baseline`
@@ -41,7 +44,30 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (smoke/debug only; result is not a benchmark)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch songs on EVERY rank; strong: --batch songs in total, split over the ranks (SURVEY 8e)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective check WITHOUT a GPU: ranks over gloo on CPU tensors run broadcast -> (scatter) -> barrier "
+                         "-> MAX-reduce and rank 0 prints a line marked dry_run (not a measurement; tests/test_dist_cpu.py drives it)")
+    ap.add_argument("--lm-hints", action="store_true",
+                    help="per-item LM hints [G,T,64] produced on rank 0 and SCATTERED to their owners each pass (think-mode conditioning)")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) started as a plain process: launch N ranks of this same command, one per GPU, over
+    RCCL - the command line the driver itself uses for N > 1 - and pass its output through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL / cross-process device memory on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def synth_weights_gpu(shapes, hidden, device, seed, kind):
@@ -193,7 +219,21 @@ def cpu_baseline(args, dcfg, vcfg, sd, vsd, enc_cpu, null_cpu, ctx_cpu, T, L):
             t_dec = time.perf_counter() - t0
         vae_song_s = t_dec * (T / vae_T)
     song_s = dit_song_s + vae_song_s
+    # BASELINE.json configs[0] (the reference's CPU-runnable case: 10 s audio, 10 steps, batch 1, DiT-only, CFG 7 + APG) run IN FULL
+    # through the oracle's sampler: a measured end-to-end CPU number next to the extrapolated one
+    cfg0 = None
+    if not args.tiny and os.environ.get("ACE355_BENCH_CFG0", "1") != "0":
+        T0, steps0 = 250, 10
+        ctx0 = ctx_cpu[:1, :T0].contiguous() if ctx_cpu.shape[1] >= T0 else ctx_cpu[:1].repeat(1, -(-T0 // ctx_cpu.shape[1]), 1)[:, :T0].contiguous()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            o_sampler.generate_audio(o_cfg, w, null_cpu.reshape(1, 1, -1), enc_cpu[None], ctx0, seed=[1000], infer_steps=steps0,
+                                     diffusion_guidance_sale=args.guidance)
+            c0 = time.perf_counter() - t0
+        cfg0 = {"config": "configs[0]: 10 s audio, 10 steps, batch 1, DiT-only, CFG on", "seconds": c0, "songs_per_s": 1.0 / c0,
+                "tflops": 2 * steps0 * dit_flops_per_forward_per_seq(dcfg, (T0 + 1) // 2, L) / 1e12 / c0, "measured": "in full"}
     return {
+        "config0_full_run": cfg0,
         "value": 1.0 / song_s, "unit": "songs/s", "cores": threads, "kind": "port",
         "sample": (f"oracle (fp32 torch restatement of the reference CPU path) on {threads} host threads: 1 cold + {n_steady} steady "
                    f"DiT forwards at N=2 (CFG of 1 song), T={T}, L={L} ({t_first:.2f}s / {t_step:.2f}s per step) extrapolated to "
@@ -202,11 +242,67 @@ def cpu_baseline(args, dcfg, vcfg, sd, vsd, enc_cpu, null_cpu, ctx_cpu, T, L):
     }
 
 
+def dry_run(args, rank, world):
+    """The multi-rank control flow of main() with the compute replaced by a memcpy: same sharding, same collectives in the same
+    order, same barrier / MAX-over-ranks timing, same rank-0 JSON line - on CPU tensors over gloo.  Exists so that the
+    `--gpus N` launcher and the collective sequence can be exercised where there is no GPU; it measures nothing."""
+    import torch.distributed as dist
+    from ace355 import dist as a_dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    dev = torch.device("cpu")
+    G = args.batch * world if args.scaling == "weak" else args.batch
+    s0, s1 = a_dist.shard_range(G, world, rank)
+    B, T, L, D = s1 - s0, int(round(args.duration * 25)), args.enc_len, 64
+    g = torch.Generator().manual_seed(99)
+    enc = torch.randn(L, D, generator=g)
+    ctx = torch.randn(T, 128, generator=g)
+    hints = torch.randn(G, T, 64, generator=g)
+    ok = True
+
+    def one_pass():
+        nonlocal ok
+        b = a_dist.broadcast_conditioning({"enc": enc, "ctx": ctx} if rank == 0 else {"enc": None, "ctx": None}, src=0,
+                                          capacity_bytes=8 << 20, device=dev)
+        ok = ok and torch.equal(b["enc"], enc) and torch.equal(b["ctx"], ctx)
+        if args.lm_hints:
+            mine = a_dist.scatter_lm_hints(hints if rank == 0 else None, G, T, 64, src=0, device=dev)
+            ok = ok and torch.equal(mine, hints[s0:s1])
+        return b["ctx"][None].expand(max(B, 1), -1, -1).clone()
+
+    for _ in range(args.warmup):
+        one_pass()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0, 0.0 if ok else 1.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher + collectives only)", "dry_run": True, "value": G * args.steps / float(tt[0]),
+                          "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
+                          "collectives_ok": bool(tt[1] == 0), "config": {"global_batch": G, "batch_rank0": B, "parallelism": f"dp{world}"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus = {world}", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the native HIP path has no CPU fallback")
     # ACE355_BENCH_BACKEND=gloo: functional check of the multi-rank flow on a box with fewer GPUs than ranks (ranks share
@@ -228,7 +324,13 @@ def main():
     from ace355.vae import peak_normalize
 
     dcfg, vcfg, dit, vae, sd, vsd = build_models(args, device)
-    B, L = args.batch, args.enc_len
+    L = args.enc_len
+    # songs of this rank: weak = --batch on every rank; strong = contiguous slice of ONE global batch
+    G = args.batch * world if args.scaling == "weak" else args.batch
+    s0, s1 = a_dist.shard_range(G, world, rank)
+    B = s1 - s0
+    if B == 0:
+        raise SystemExit(f"bench.py: rank {rank} owns no song (global batch {G} over {world} ranks)")
     T = int(round(args.duration * 25))
     S = (T + 1) // 2
     D = dcfg.hidden_size
@@ -244,7 +346,10 @@ def main():
         null = torch.empty(D, device=device)
         ctx_shared = torch.empty(T, 128, device=device)
     ts = schedule(args.infer_steps, 1.0)
-    seeds = [1000 + rank * B + i for i in range(B)]
+    seeds = [1000 + s0 + i for i in range(B)]   # the rank's slice of the request's seed list (a_dist.shard_seeds)
+    hints_all = None
+    if args.lm_hints and rank == 0:
+        hints_all = 0.5 * torch.randn(G, T, 64, generator=g).to(device)
     noise = prepare_noise((B, T, 64), seeds).to(device)  # CPU generator (reference CPU stream), uploaded once
 
     last_bundle = {}
@@ -253,13 +358,19 @@ def main():
         # collective=False (the rank-0-only profiled pass after the timed region) must not enter a broadcast the other
         # ranks never join: it reuses the bundle of the last timed pass
         if world > 1 and collective:
-            bundle = a_dist.broadcast_conditioning({"enc": enc, "null": null, "ctx": ctx_shared}, src=0)
+            bundle = a_dist.broadcast_conditioning({"enc": enc, "null": null, "ctx": ctx_shared} if rank == 0 else
+                                                   {"enc": None, "null": None, "ctx": None}, src=0, device=device)
             last_bundle.update(bundle)
         elif world > 1:
             bundle = last_bundle
         else:
             bundle = {"enc": enc, "null": null, "ctx": ctx_shared}
         ctx = bundle["ctx"][None].expand(B, -1, -1).contiguous()
+        if args.lm_hints:  # per-item hints replace the source latents (base.py:1646-1649): scattered, not broadcast
+            mine = a_dist.scatter_lm_hints(hints_all, G, T, 64, src=0, device=device) if (world > 1 and collective) else \
+                (last_bundle["hints"] if world > 1 else hints_all[s0:s1])
+            last_bundle["hints"] = mine
+            ctx = torch.cat([mine, ctx[..., 64:]], -1).contiguous()
         dit.set_condition(SLOT_COND, bundle["enc"])
         dit.set_condition(SLOT_NULL, bundle["null"].reshape(1, -1), L=L)
         lat = dit.sample(noise, ctx, ts, guidance_scale=args.guidance)
@@ -288,18 +399,18 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(out).all(), "non-finite output"
 
-    songs = world * B * args.steps
+    songs = G * args.steps
     value = songs / elapsed
     result = {
-        "metric": "songs/sec (30 s audio @ 27 DiT steps, CFG 7.0 + APG, batch 8 per GPU, DiT + VAE decode)" if not args.no_vae
-        else "songs/sec (DiT-only)",
+        "metric": (f"songs/sec ({args.duration:g} s audio @ {args.infer_steps} DiT steps, CFG {args.guidance:g} + APG, batch {args.batch} "
+                   + ("per GPU" if args.scaling == "weak" else "in total") + (", DiT + VAE decode)" if not args.no_vae else ", DiT-only)")),
         "value": value, "unit": "songs/s", "rtf": value * args.duration, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"acestep-5Hz base DiT (24L/2048d, 1.575B params, random init) + Oobleck decoder, {args.duration:g} s audio "
                                f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward), L={L}, "
-                               f"batch {B}/GPU" + (", DiT-only" if args.no_vae else ""),
-                   "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "global_batch": world * B,
+                               f"batch {B}/GPU" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
+                   "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "global_batch": G,
                    "parallelism": f"dp{world}", "tiny": bool(args.tiny)},
     }
 
@@ -325,9 +436,19 @@ def main():
             vae.set_profile(False)
             result["roofline"]["vae_conv_tflops"] = vp["conv_flops"] / (vp["conv_ms"] * 1e-3) / 1e12 if vp["conv_ms"] > 0 else 0.0
             result["roofline"]["vae_conv_ms_per_pass"] = vp["conv_ms"]
-        alg = B * (2 * args.infer_steps * dit_flops_per_forward_per_seq(dcfg, S, L) + (0 if args.no_vae else T * vae_flops_per_frame(vcfg)))
+        tr = result["roofline"]["traffic"]
+        # HBM-side GB/s of the dominant kernel = PMC bytes per launch (committed profile of this command) / live launch time
+        result["roofline"]["hbm_gbps"] = (tr / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9) if tr else None
+        do_cfg = args.guidance > 1.0
+        alg = B * ((2 if do_cfg else 1) * args.infer_steps * dit_flops_per_forward_per_seq(dcfg, S, L) + (0 if args.no_vae else T * vae_flops_per_frame(vcfg)))
         result["algorithmic_tflop_per_step"] = alg / 1e12
+        # SURVEY 8d counts the un-shortcut algorithm (CFG null branch cross-attention included); the path EXECUTES less: the
+        # null branch's cross-attention is the exact constant it is.  Both rates are reported (this rank's songs / wall time).
         result["achieved_tflops_whole_path"] = alg / 1e12 / (elapsed / args.steps)
+        executed = p["gemm_flops"] + p["attn_flops"] + (vp["conv_flops"] if vae is not None else 0.0)
+        result["executed_tflop_per_step"] = executed / 1e12
+        result["achieved_tflops_executed"] = executed / 1e12 / (elapsed / args.steps)
+        result["null_branch_shortcut_tflop_saved"] = (alg - executed) / 1e12
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(args, dcfg, vcfg, sd, vsd, enc.cpu(), null.cpu(), ctx_shared.cpu()[None], T, L)

@@ -76,10 +76,11 @@ def test_condition_encoder_vs_reference_golden(gpu_device, golden_dir, case):
     ref_h, ref_m = T(G[f"{case}_h"]), T(G[f"{case}_m"])
     assert h.shape == ref_h.shape and torch.equal(m.cpu().long(), ref_m)
     # reference fp32 CPU vs bf16 kernels, 2 + 2 layers: 2e-2 relative L2 over all rows; valid rows alone as well
-    assert _rel(h.cpu(), ref_h) < 2e-2, _rel(h.cpu(), ref_h)
     vm = ref_m.bool()
-    assert _rel(h.cpu()[vm], ref_h[vm]) < 2e-2
-    assert _rel(h.cpu()[~vm], ref_h[~vm]) < 3e-2   # padding rows (incl. uniform-attention rows and the zero timbre rows)
+    ra, rv, rp = _rel(h.cpu(), ref_h), _rel(h.cpu()[vm], ref_h[vm]), _rel(h.cpu()[~vm], ref_h[~vm])
+    print(f"condition encoder case {case}: rel L2 vs reference fp32 all rows {ra:.3e}, valid {rv:.3e}, padding {rp:.3e}")
+    # gates = 2.5-3x the measured 3.3e-3 - 3.8e-3 (padding rows incl. uniform-attention rows and the zero timbre rows)
+    assert ra < 1e-2 and rv < 1e-2 and rp < 1e-2, (ra, rv, rp)
 
 
 def test_condition_encoder_full_size_vs_oracle(gpu_device):
@@ -105,7 +106,8 @@ def test_condition_encoder_full_size_vs_oracle(gpu_device):
     h, m = enc(text, tmask, lyric, lmask, refer, order)
     assert torch.equal(m.cpu(), ref_m)
     r = _rel(h.cpu(), ref_h)
-    assert r < 3e-2, r   # 12 bf16 layers vs fp32 (the 24-layer DiT forward measures 6e-3 under a 3e-2 gate)
+    print(f"condition encoder full size: rel L2 vs fp32 oracle {r:.3e}")
+    assert r < 3e-2, r   # measured 1.2e-2: 12 bf16 layers with PLAIN residuals (the DiT's gated ones accumulate less)
     # and its output drives the DiT's condition slot unchanged
     assert h.dtype == torch.float32 and h.is_contiguous() and h.shape == (B, Ll + 2 + Lt, cfg.hidden_size)
 
@@ -158,7 +160,8 @@ def test_request_chain_cond_encoder_to_sampler_to_vae(gpu_device):
     dit.load_state_dict(dw)
     n_lat = generate_latents(dit, null, n_enc, ctx, **kw)["target_latents"]
     r = _rel(n_lat.cpu(), o_lat)
-    assert r < 6e-2, r   # same gate as the tiny sampler golden test
+    print(f"encoder -> sampler chain: latents rel L2 vs the oracle chain {r:.3e}")
+    assert r < 2e-2, r
     vcfg = ace355.VaeConfig()
     vw = weightgen.make_vae_weights(vcfg.weight_shapes(), seed=34, mode="init")
     vae = NativeVae(vcfg, gpu_device)
@@ -166,4 +169,5 @@ def test_request_chain_cond_encoder_to_sampler_to_vae(gpu_device):
     wav = vae.decode(n_lat[:, :24].transpose(1, 2).contiguous()).cpu()
     wref = o_vae.decode(o_vae.VaeConfig(), vw, o_lat[:, :24].transpose(1, 2).contiguous())
     snr = float(10 * torch.log10(wref.pow(2).sum() / (wav - wref).pow(2).sum()))
-    assert snr > 20.0, snr
+    print(f"encoder -> sampler -> decoder chain: waveform SNR vs the oracle chain {snr:.1f} dB")
+    assert snr > 25.0, snr

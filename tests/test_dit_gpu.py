@@ -2,8 +2,9 @@
 imported reference (tests/golden/make_golden.py) and against the oracle on fresh seeded inputs.
 
 Tolerance model: weights/activations are bf16 on the MFMA path (the reference's own CUDA dtype,
-handler/init_service_orchestrator.py:51), the golden vectors are the reference's fp32 CPU path.  Measured bf16
-drift of one forward is ~0.5-1% relative L2; the bars below are 2-3x that and are asserted, not just printed.
+handler/init_service_orchestrator.py:51), the golden vectors are the reference's fp32 CPU path.  Every gate below is
+2-3x the value MEASURED on MI355X (round 2, gpurun_out/r02_pytest1.log; the measured value is quoted next to each gate and
+printed by the test), so a kernel regression of 3x fails.
 """
 import numpy as np
 import pytest
@@ -45,8 +46,8 @@ def test_tiny_forward_vs_reference_golden(gpu_device, golden_dir, case):
     ref = torch.from_numpy(G[f"{case}_v"])
     r = _rel(v, ref)
     print(f"tiny forward case {case}: rel L2 vs reference fp32 = {r:.3e}")
-    assert r < 2e-2, r
-    assert float((v.cpu() - ref).abs().max()) < 0.1 * float(ref.abs().max())
+    assert r < 8e-3, r  # measured 3.1e-3 (all three cases)
+    assert float((v.cpu() - ref).abs().max()) < 0.05 * float(ref.abs().max())
 
 
 def test_tiny_forward_matches_oracle_with_bf16_weights(gpu_device):
@@ -69,12 +70,12 @@ def test_tiny_forward_matches_oracle_with_bf16_weights(gpu_device):
     ref = o_dit.dit_forward(o_cfg, wb, x, torch.tensor(t), torch.tensor(tr), enc, ctx)
     r = _rel(v, ref)
     print(f"tiny forward vs oracle (bf16 weights): rel L2 = {r:.3e}")
-    assert r < 1.5e-2, r
+    assert r < 6e-3, r  # measured 2.1e-3
 
 
 @pytest.mark.parametrize("name", ["cfg7_shift1", "cfg1_shift3", "cfg7_interval", "sft_timesteps"])
 def test_tiny_sampler_vs_reference_golden(gpu_device, golden_dir, name):
-    """27 chained steps with CFG 7 + APG amplify rounding; bar: 6% relative L2 on the final latents."""
+    """27 chained steps with CFG 7 + APG; measured 0.7e-3 - 1.7e-3 relative L2 on the final latents, gate 5e-3."""
     from ace355 import weightgen
     from ace355.dit import generate_latents
     G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
@@ -92,7 +93,7 @@ def test_tiny_sampler_vs_reference_golden(gpu_device, golden_dir, name):
     r = _rel(out["target_latents"], ref)
     print(f"tiny sampler {name}: rel L2 vs reference fp32 = {r:.3e}")
     assert set(out["time_costs"]) == {"encoder_time_cost", "diffusion_time_cost", "diffusion_per_step_time_cost", "total_time_cost"}
-    assert r < 6e-2, r
+    assert r < 5e-3, r
 
 
 def test_tiny_sampler_cover_switch(gpu_device, golden_dir):
@@ -110,7 +111,7 @@ def test_tiny_sampler_cover_switch(gpu_device, golden_dir):
     outs = [o["target_latents"].cpu()]
     r = _rel(torch.cat(outs), t["out"])
     print(f"cover switch: rel L2 vs reference fp32 = {r:.3e}")
-    assert r < 6e-2, r
+    assert r < 4e-3, r  # measured 1.25e-3
 
 
 def test_full_size_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -140,15 +141,15 @@ def test_full_size_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_
           f"per-seq {[_rel(v[i], ref[i]) for i in range(2)]}")
     # gates = 2-3x the measured values (5.8e-3 on v in round 1; taps measured in round 2)
     assert r < 1.5e-2, r
-    assert r0 < 6e-3 and r23 < 1.5e-2, (r0, r23)
+    assert r0 < 1e-2 and r23 < 1.2e-2, (r0, r23)  # measured 3.8e-3 / 4.1e-3
     assert not torch.isnan(v).any()
 
 
 def test_baseline_config0_full_size_sampler_and_decode_vs_oracle(gpu_device):
     """BASELINE.json configs[0]: acestep-5Hz DiT-only... 10 s audio, 10 steps, batch 1 - the reference's CPU-runnable case -
     at the real architecture (random init, bf16-representable weights on both sides), CFG 7 + APG, then decoded.
-    Stated tolerance (north_star: 'within a stated fp tolerance on the decoded waveform'): latents rel-L2 <= 5e-2,
-    waveform SNR >= 20 dB vs the fp32 oracle chain."""
+    Stated tolerance (north_star: 'within a stated fp tolerance on the decoded waveform'): latents rel-L2 <= 6e-3 (measured
+    2.2e-3), waveform SNR >= 31 dB vs the fp32 oracle chain (measured 36.8 dB; 6 dB = 2x in amplitude)."""
     import time
     import ace355
     from ace355 import weightgen
@@ -173,7 +174,7 @@ def test_baseline_config0_full_size_sampler_and_decode_vs_oracle(gpu_device):
     cpu_s = time.time() - t0
     r = _rel(lat, ref)
     print(f"config0 full-size sampler: latents rel L2 {r:.3e} (GPU {out['time_costs']['diffusion_time_cost']:.3f}s, CPU oracle {cpu_s:.1f}s)")
-    assert r < 5e-2, r
+    assert r < 6e-3, r
     vcfg = ace355.VaeConfig()
     vw = weightgen.make_vae_weights(vcfg.weight_shapes(), seed=7, mode="init")
     vae = NativeVae(vcfg, gpu_device)
@@ -183,7 +184,7 @@ def test_baseline_config0_full_size_sampler_and_decode_vs_oracle(gpu_device):
     wref = o_vae.decode(o_vae.VaeConfig(), vw, ref[:, :Tv].transpose(1, 2).contiguous())
     snr = float(10 * torch.log10(wref.pow(2).sum() / (wav - wref).pow(2).sum()))
     print(f"config0 decoded waveform (native latents -> native VAE vs oracle latents -> oracle VAE): SNR {snr:.1f} dB")
-    assert snr > 20.0, snr
+    assert snr > 31.0, snr
 
 
 def test_adg_and_sde_branches_vs_oracle(gpu_device):
@@ -202,7 +203,7 @@ def test_adg_and_sde_branches_vs_oracle(gpu_device):
     out = generate_latents(dit, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, use_adg=True)["target_latents"]
     r = _rel(out, ref)
     print(f"ADG sampler: rel L2 {r:.3e}")
-    assert r < 5e-2, r
+    assert r < 5e-3, r  # measured 1.8e-3
     with pytest.raises(ValueError, match="batch size 1"):
         generate_latents(dit, null, enc.expand(2, -1, -1), ctx.expand(2, -1, -1).contiguous(), seed=[1, 2], infer_steps=2, use_adg=True)
     # SDE: the oracle draws randn_like(x) once per step from the global CPU generator; replay the same draws natively
@@ -214,7 +215,7 @@ def test_adg_and_sde_branches_vs_oracle(gpu_device):
                            sde_noise=noise)["target_latents"]
     r = _rel(out, ref)
     print(f"SDE sampler: rel L2 {r:.3e}")
-    assert r < 5e-2, r
+    assert r < 7e-3, r  # measured 2.6e-3
 
 
 def test_null_branch_shortcut_equals_generic_path(gpu_device):
@@ -236,7 +237,7 @@ def test_null_branch_shortcut_equals_generic_path(gpu_device):
     assert torch.equal(v_short[:2], v_gen[:2])             # conditional half is untouched by the shortcut
     r = _rel(v_short[2:], v_gen[2:])
     print(f"null-branch shortcut vs generic attention: rel L2 {r:.2e}")
-    assert r < 5e-3, r
+    assert r < 1e-3, r  # measured 0.0 (bit-identical at this shape)
     # a non-suffix layout must fall back to the generic path and still be right
     v_mixed = dit.forward(x, ctx, t, t, [1, 0, 1, 0])
     assert _rel(v_mixed[0], dit.forward(x[:1], ctx[:1], t[:1], t[:1], [2])[0]) < 5e-3
@@ -286,7 +287,7 @@ def test_full_size_properties_batch_invariance_and_determinism(gpu_device):
     solo = generate_latents(dit, null, enc1, ctx1, seed=[1001], **kw)["target_latents"]
     r = _rel(a[1:2], solo)
     print(f"batch invariance at the metric shape: item 1 of 3 vs alone, rel L2 {r:.3e}")
-    assert r < 5e-3, r
+    assert r < 5e-3, r  # measured 1.8e-3
     # different seeds really give different songs (guards against a broadcast bug hiding behind the checks above)
     assert _rel(a[0:1], a[1:2]) > 0.5
 
@@ -310,7 +311,7 @@ def test_turbo_sampler_vs_reference_golden(gpu_device, golden_dir, name):
                                  sde_noise=t(f"{name}_sde_noise") if name.startswith("sde") else None)["target_latents"]
     r = _rel(out, t(f"{name}_out"))
     print(f"turbo sampler {name}: rel L2 vs the turbo reference (fp32 CPU) = {r:.3e}")
-    assert r < 1e-2, r
+    assert r < (4e-3 if name.startswith("sde") else 2.5e-3), r  # measured 0.8e-3 (ode), 1.5e-3 (sde)
 
 
 def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_path):
@@ -346,4 +347,4 @@ def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_pat
     ref = torch.from_numpy(np.load(f"{golden_dir}/g2_tiny_forward.npz")["a_v"])
     r1, r0, rx = _rel(outs["1"], ref), _rel(outs["0"], ref), _rel(outs["1"], outs["0"])
     print(f"head epilogue: fused vs reference {r1:.3e}, two-kernel vs reference {r0:.3e}, fused vs two-kernel {rx:.3e}")
-    assert r1 < 2e-2 and r0 < 2e-2 and rx < 1e-2, (r1, r0, rx)
+    assert r1 < 8e-3 and r0 < 8e-3 and rx < 2.5e-3, (r1, r0, rx)  # measured 3.1e-3, 3.1e-3, 7.8e-4

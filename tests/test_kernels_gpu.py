@@ -106,7 +106,7 @@ def test_gemm_residual_metric_shapes(lib, gpu_device, M, N, K, rows, cvec_row0):
                                        g2[:, 5].data_ptr() if gated else None, 6 * N, rows, _p(cvec), max(cvec_row0, 0), None))
     r = _rel(out - H, ref - H)  # on the UPDATE, so that H does not mask an error in it
     print(f"residual GEMM M={M} N={N} K={K}: rel L2 of the update {r:.2e}")
-    assert r < 2e-5, r
+    assert r < 2.5e-6, r  # measured 3.8e-7 - 8.6e-7 (fp32 accumulation order only; the split-K atomics included)
 
 
 @pytest.mark.parametrize("M,N,K,q_cols,qk_cols,rope,rows", [

@@ -25,7 +25,8 @@ def test_detokenizer_vs_reference_golden(gpu_device, golden_dir):
     ref = torch.from_numpy(G["y"])
     assert y.shape == ref.shape
     r = _rel(y.cpu(), ref)
-    assert r < 2e-2, r   # reference fp32 CPU vs bf16 kernels, 2 layers
+    print(f"detokenizer (tiny) vs reference fp32: rel L2 {r:.3e}")
+    assert r < 1.5e-2, r   # reference fp32 CPU vs bf16 kernels, 2 layers
 
 
 def test_detokenizer_full_size_vs_oracle_and_code_path(gpu_device):
@@ -50,7 +51,8 @@ def test_detokenizer_full_size_vs_oracle_and_code_path(gpu_device):
     ref = o_detok.detokenizer(o_detok.DetokConfig(), w, q)
     assert y.shape == (1, 250, 64) == tuple(ref.shape)
     r = _rel(y.cpu(), ref)
-    assert r < 2e-2, r
+    print(f"detokenizer (full size) vs fp32 oracle: rel L2 {r:.3e}")
+    assert r < 1.5e-2, r   # measured 5.6e-3
     assert decode_audio_codes_to_latents("no codes here", det, pw, pb) is None
     with pytest.raises(ValueError):
         det(torch.zeros(1, 4, cfg.hidden_size), attention_mask=torch.ones(1, 4))

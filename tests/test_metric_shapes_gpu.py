@@ -66,7 +66,7 @@ def test_metric_shape_forward_vs_reference_golden(gpu_device, golden_dir, full_d
           f"taps layer 0 {r0:.3e}, layer 23 {r23:.3e}")
     assert torch.isfinite(v).all()
     assert r < 1.5e-2 and r_c < 1.5e-2 and r_u < 1.5e-2, (r, r_c, r_u)
-    assert r0 < 6e-3 and r23 < 1.5e-2, (r0, r23)
+    assert r0 < 1e-2 and r23 < 1.2e-2, (r0, r23)  # measured: v 5.8e-3 (cond 6.2e-3, null 5.1e-3), taps 3.8e-3 / 4.1e-3
 
 
 def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -86,7 +86,7 @@ def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_d
     r = _rel(out, ref)
     per = [_rel(out[i], ref[i]) for i in range(B)]
     print(f"metric-batch sampler (B=8, 3 steps, CFG 7 + APG): rel L2 vs reference fp32 = {r:.3e}; per item max {max(per):.3e}")
-    assert r < 1e-2 and max(per) < 1.5e-2, (r, per)
+    assert r < 1e-2 and max(per) < 1.2e-2, (r, per)  # measured 4.0e-3 / 4.0e-3
 
 
 def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, full_dit_seed4):
@@ -123,6 +123,6 @@ def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, fu
     print(f"120 s forward: N=2 vs reference {r2:.3e} (layer-23 tap {r23:.3e}); inside N=16 (attn3_kernel<8>) vs reference {r16:.3e}, "
           f"vs the N=2 run {rx:.3e}")
     assert torch.isfinite(v16).all()
-    assert r2 < 1.5e-2 and r16 < 1.5e-2 and r23 < 1.5e-2, (r2, r16, r23)
-    assert rx < 8e-3, rx
+    assert r2 < 1.5e-2 and r16 < 1.5e-2 and r23 < 1.2e-2, (r2, r16, r23)  # measured 5.9e-3, 5.9e-3, 4.2e-3
+    assert rx < 2e-3, rx  # measured 0.0: the same arithmetic per wave whatever the block / tile shape
     assert _rel(v16[2], v16[3]) > 0.3  # other seeds really are other songs

@@ -292,6 +292,323 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
     if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_attn_probe[5] = clock64() - t_entry; }
 }
 
+// ------------------------------------------------------------------------------------------------ GQA-shared kernel
+// attn3_kernel stages every K / V^T tile once per (q-block, Q HEAD): with Hq = 2 Hkv each tile is DMA'd twice, and at the
+// metric shape (Sq = 375 -> 12 wave tiles of 32 rows per (sequence, head), 3072 wave tiles per launch) its two 4-wave
+// workgroups per CU give 2048 wave slots: 1.5 rounds, the second one half empty, and every workgroup pays the cold-start
+// prologue again.  Here one workgroup owns (sequence, KV head, q-block of 32*NWH rows) and computes BOTH q heads of the group
+// off one K / V^T tile: 2*NWH waves (waves [0, NWH) head 2g, waves [NWH, 2*NWH) head 2g+1).  NWH = 6 -> 12 waves, THREE per
+// SIMD, 192 query rows: 2 x 8 x 16 = 256 workgroups at the metric = one per CU, one round, half the K / V traffic.
+// Three waves per SIMD leave 168 VGPRs, which the 32-register Q fragment set of attn3_kernel does not fit beside O (64),
+// S (32) and a useful batch of K fragments: Q lives in LDS instead (each wave DMAs its own 32 rows into a private 8 KB
+// slice once) and its fragments are re-read per tile in the same batches as the K fragments; K / V^T fragments are read in
+// batches of 8 (half of a tile's contraction) instead of 16.  LDS: 2 x 32 KB K / V^T stages + 2*NWH x 8 KB of Q = 160 KB
+// at NWH = 6.  Tile images, swizzles, the row permutation, softmax and epilogue are attn3_kernel's.
+template <int NWH>
+__global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(AttnArgs a, float scale_log2, float defer_thr) {
+    constexpr int NW = 2 * NWH;
+    constexpr int QB = NWH * 32;
+    constexpr int BUF = 32768;                  // K tile 16 KB | V^T tile 16 KB
+    constexpr int NPI = (32 + NW - 1) / NW;     // DMA pieces per wave per tile (32 pieces of 1 KB)
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF + NW * 8192];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroup -> (q-block, KV head, sequence).  Block b runs on XCD b % 8 (observed; speed only): the KV head picks the XCD, so
+    // that every workgroup reading one head's K / V^T - the q-blocks of a sequence, and for cross-attention every sequence
+    // that attends the same condition slot - shares ONE private L2 (self-attention at the metric: 98 -> 74 MB per launch
+    // leave the L2s; cross-attention: the 0.4 MB of a head's keys are fetched once per launch instead of once per workgroup).
+    int qb, hkv, n;
+    {
+        const int nqb = (a.Sq + QB - 1) / QB;
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        if ((a.Hkv & 7) == 0) {
+            const int hg = a.Hkv >> 3;
+            hkv = xcd + 8 * (j % hg);
+            const int rest = j / hg;
+            qb = rest % nqb;
+            n = rest / nqb;
+        } else {  // generic order (grid is padded to a multiple of 8 by the launcher: surplus ids leave)
+            hkv = id % a.Hkv;
+            const int rest = id / a.Hkv;
+            qb = rest % nqb;
+            n = rest / nqb;
+        }
+        if (n >= a.N) return;
+    }
+    const unsigned long long t_entry = a.clk_probe ? clock64() : 0ull;
+    const int hw = wave / NWH, wr = wave - hw * NWH;   // q head inside the group, 32-row tile inside the block
+    const int h = hkv * 2 + hw;
+    const int q0 = qb * QB;
+    const int lq = lane & 31, half = lane >> 5;
+    const int qw0 = q0 + wr * 32;
+    const int qrow = qw0 + lq;
+    const int win = a.window < 0 ? (1 << 28) : a.window;
+    const bool wave_live = qw0 < a.Sq;
+    const int skv = a.kv_len ? a.kv_len[n] : a.Skv;
+
+    int kt_lo = 0, kt_hi = (skv + KB - 1) / KB;
+    if (a.window >= 0) {
+        kt_lo = max(0, q0 - a.window) / KB;
+        kt_hi = min(kt_hi, (min(skv - 1, q0 + QB - 1 + a.window)) / KB + 1);
+    }
+    const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
+    const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
+
+    // DMA piece p = wave + NW*i (p < 32): p < 16 = K rows 4p..4p+3, else V^T rows 8(p-16)..+7 (see attn3_kernel)
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    unsigned p_voff[NPI], p_voff_tail[NPI];
+    const int tail_key0 = ((a.Skv - 1) / KB) * KB;
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        const int p = wave + NW * i;
+        if (p < 16) {
+            const int key = 4 * p + (lane >> 4);
+            const int j = (lane & 15) ^ (key & 15);
+            p_voff[i] = (unsigned)(key * a.k_row_stride + j * 8) * 2u;
+            p_voff_tail[i] = (unsigned)((min(tail_key0 + key, a.Skv - 1) - tail_key0) * a.k_row_stride + j * 8) * 2u;
+        } else {
+            const int d = 8 * (p - 16) + (lane >> 3);
+            const int jv = (lane & 7) ^ ((d >> 1) & 7);
+            p_voff[i] = p_voff_tail[i] = (unsigned)(d * a.vt_ld + jv * 8) * 2u;
+        }
+    }
+    auto issue_piece = [&](int kt, int i) {  // this wave's i-th DMA instruction of tile kt
+        const int key0 = kt * KB;
+        const unsigned bb = lds0 + (unsigned)(kt & 1) * BUF;
+        const bf16_t* kb_s = kbase + (long)key0 * a.k_row_stride;  // uniform
+        const bf16_t* vb_s = vbase + key0;
+        const bool tail = key0 + KB > a.Skv;
+        const int p = wave + NW * i;  // wave-uniform
+        if (p < 16) attn_glds16(tail ? p_voff_tail[i] : p_voff[i], kb_s, bb + (unsigned)p * 1024u);
+        else if (p < 32) attn_glds16(p_voff[i], vb_s, bb + (unsigned)p * 1024u);
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) issue_piece(kt, i);
+    };
+
+    // this wave's 32 Q rows -> its private slice (full 256-byte lines, XOR-swizzled chunks), once
+    const unsigned qbuf = lds0 + 2u * BUF + (unsigned)wave * 8192u;
+    {
+        const bf16_t* qsrc = a.q + (long)n * a.q_seq_stride + h * 128;  // uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row_l = 4 * i + (lane >> 4);
+            const int j = (lane & 15) ^ (row_l & 15);
+            const unsigned voff = (unsigned)(min(qw0 + row_l, a.Sq - 1) * a.q_row_stride + j * 8) * 2u;
+            attn_glds16(voff, qsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(qbuf + (unsigned)i * 1024u)));
+        }
+    }
+    if (kt_lo < kt_hi) issue(kt_lo);
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int prow = pi23(lq);
+    const int k_row_off = prow * 256, k_swz = prow & 15;
+    const int v_row_off = prow * 128, v_swz = (prow >> 1) & 7;
+    const char* qs = smem + 2 * BUF + wave * 8192 + lq * 256;
+    const int q_swz = lq & 15;
+
+    const bool probe = a.clk_probe && blockIdx.x == 0 && tid == 0;
+    unsigned long long pc0 = 0, pw0 = 0, pbar = 0;
+    if (probe) { pc0 = clock64(); pw0 = wall_clock64(); }
+    // ACE355_ATTN_CLK bits 1..3 (diagnostic ablations, results are WRONG): 2 = softmax arithmetic off (P = S), 4 = no barrier /
+    // DMA after the first tile, 8 = K / Q / V^T fragments read once and reused
+    const bool ab_nosm = (a.clk_probe & 2) != 0, ab_nosync = (a.clk_probe & 4) != 0;
+
+    for (int kt = kt_lo; kt < kt_hi; ++kt) {
+        const int key0 = kt * KB;
+        unsigned long long pb0 = 0;
+        if (probe) pb0 = clock64();
+        if (!ab_nosync || kt == kt_lo) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (and, first time, its Q rows)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                      // tile kt complete in LDS; every wave is done with tile kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (probe) pbar += clock64() - pb0;
+        }
+        // The next tile's DMA is NOT issued here: an LDS-DMA instruction takes 60-185 cycles to issue, and with every wave doing
+        // it right behind the barrier the matrix pipe sat idle (ablation: 6.4 k -> 4.0 k cycles per tile without barrier + DMA).
+        // The pieces ride between the Q K^T batches below (safe any time after the barrier: the target stage was last read in
+        // tile kt-1); waves that skip this tile issue theirs at once.
+        const bool prefetch = (kt + 1 < kt_hi) && !ab_nosync;
+
+        const char* Ks = smem + (ab_nosync ? (kt_lo & 1) : (kt & 1)) * BUF;
+        const char* Vs = Ks + 16384;
+        const bool in_band = (key0 - (qw0 + 31) <= win) && (qw0 - (key0 + KB - 1) <= win);
+        if (!wave_live || !in_band) {
+            if (prefetch) issue(kt + 1);
+            continue;
+        }
+        // The 20 fragment addresses of a tile ((slot ^ swizzle) << 4 cannot fold into an immediate) are loop invariant and hipcc
+        // hoists them all: 20 VGPRs that at a 168-register budget spill.  Re-materialised per tile (1 VALU each) instead: the
+        // swizzle terms go through an opaque asm so that nothing derived from them can leave the loop.
+        // (slot ^ swz) << 4 with slot = even | half  ==  (even << 4) ^ ((half ^ swz) << 4): one XOR with a constant per fragment
+        int kx = (half ^ k_swz) << 4, qx = (half ^ q_swz) << 4, vx = (half ^ v_swz) << 4;
+        asm volatile("" : "+v"(kx), "+v"(qx), "+v"(vx));
+
+        // ---- S^T = K Q^T, contraction in batches of KSB 16-wide steps: 2*KSB K fragments + KSB Q fragments per batch
+        // (KSB = 2: 24 fragment registers beside O (64) and S (32) at three waves per SIMD, and four batches to hang the DMA on)
+        constexpr int KSB = 2;
+        f32x16 s[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t2][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 8 / KSB; ++kb) {
+            bf16x8 fk[2 * KSB], fq[KSB];
+#pragma unroll
+            for (int u = 0; u < KSB; ++u) {
+                const int ks = kb * KSB + u;
+                fq[u] = as_bf16x8(*reinterpret_cast<const uint4*>(qs + ((ks * 32) ^ qx)));
+                fk[u] = as_bf16x8(*reinterpret_cast<const uint4*>(Ks + k_row_off + ((ks * 32) ^ kx)));
+                fk[KSB + u] = as_bf16x8(*reinterpret_cast<const uint4*>(Ks + 8192 + k_row_off + ((ks * 32) ^ kx)));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one batch of reads, then its MFMAs
+#pragma unroll
+            for (int u = 0; u < KSB; ++u) {
+                s[0] = mfma32(fk[u], fq[u], s[0]);
+                s[1] = mfma32(fk[KSB + u], fq[u], s[1]);
+            }
+            if (kb < NPI) {  // one or two DMA instructions of the next tile behind this batch's MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                if (prefetch) {
+                    issue_piece(kt + 1, kb);
+                    if (kb + 4 < NPI) issue_piece(kt + 1, kb + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        static_assert(NPI <= 2 * (8 / KSB), "at most two DMA pieces per Q K^T batch");
+        __builtin_amdgcn_sched_barrier(0);
+        // first half of the V^T fragments (keys 0..31 of the tile) requested before the softmax arithmetic
+        bf16x8 fv[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                fv[t * 4 + dt] = as_bf16x8(*reinterpret_cast<const uint4*>(Vs + dt * 4096 + v_row_off + ((t * 32) ^ vx)));
+        const bool interior = (key0 + KB <= skv) && (qw0 + 31 - key0 <= win) && (key0 + KB - 1 - qw0 <= win);
+        if (!interior) {
+            const int kb0 = key0 + 8 * half;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb0 + t2 * 32 + 16 * (r >> 3) + (r & 7);
+                    const bool ok = (key < skv) & ((unsigned)(qrow - key + win) <= (unsigned)(2 * win));
+                    s[t2][r] = ok ? s[t2][r] : -INFINITY;
+                }
+        }
+        if (ab_nosm) {  // ablation: no max / exp / sum
+            l_run = 1.f;
+            m_run = 0.f;
+        } else {
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_tile = mx * scale_log2;
+        const bool move = __any(m_tile - m_run > defer_thr);
+        const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = move ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t2][r], scale_log2, -m_use));
+                s[t2][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        if (move && __any(alpha != 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        }
+        // ---- O^T += V^T P^T: keys 0..31 with the fragments already here, the second half's reads issued under those MFMAs
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 pb;
+                pb.x = pack_bf2(s[t2][8 * t + 0], s[t2][8 * t + 1]);
+                pb.y = pack_bf2(s[t2][8 * t + 2], s[t2][8 * t + 3]);
+                pb.z = pack_bf2(s[t2][8 * t + 4], s[t2][8 * t + 5]);
+                pb.w = pack_bf2(s[t2][8 * t + 6], s[t2][8 * t + 7]);
+                pf[t] = as_bf16x8(pb);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(fv[t * 4 + dt], pf[t], o[dt]);
+            if (t2 == 0) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        fv[t * 4 + dt] = as_bf16x8(*reinterpret_cast<const uint4*>(Vs + dt * 4096 + v_row_off + ((64 + t * 32) ^ vx)));
+            }
+        }
+    }
+
+    if (probe) {
+        g_attn_probe[0] = clock64() - pc0;
+        g_attn_probe[1] = wall_clock64() - pw0;
+        g_attn_probe[2] = pbar;
+        g_attn_probe[3] = (unsigned long long)(kt_hi - kt_lo);
+        g_attn_probe[4] = pc0 - t_entry;
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qrow < a.Sq && l_tot == 0.f) {
+        bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 8 * half;
+        const bf16_t* vm = a.vmean + ((long)n * a.Hkv + hkv) * 128 + 8 * half;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(op + c * 16) = *reinterpret_cast<const uint4*>(vm + c * 16);
+    } else if (qrow < a.Sq) {
+        bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 8 * half;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint4 pk;
+                pk.x = pack_bf2(o[dt][8 * g + 0] * inv, o[dt][8 * g + 1] * inv);
+                pk.y = pack_bf2(o[dt][8 * g + 2] * inv, o[dt][8 * g + 3] * inv);
+                pk.z = pack_bf2(o[dt][8 * g + 4] * inv, o[dt][8 * g + 5] * inv);
+                pk.w = pack_bf2(o[dt][8 * g + 6] * inv, o[dt][8 * g + 7] * inv);
+                *reinterpret_cast<uint4*>(op + dt * 32 + 16 * g) = pk;
+            }
+    }
+    if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_attn_probe[5] = clock64() - t_entry; }
+}
+
+// A ROTATED variant of this kernel was built and measured in round 2 and removed again (numbers in DESIGN.md section 5):
+// wave group g = wave / 4 ran its tile loop rotated by g segments around the per-tile barrier (group 0: QK SM PV, group 1:
+// PV' QK SM, group 2: SM' PV' QK) so that two waves of a SIMD always fed the matrix pipe while the third did softmax arithmetic.
+// It needs tiles k-1 and k live with k+1, k+2 in flight, i.e. four stages, which beside 96 KB of Q only fit as 32-key tiles -
+// and at 32 keys the per-tile fixed cost (24 instead of 20 fragment reads per 32 keys, twice the barriers, max / ballot / branch
+// logic per tile) ate the gain: 3.7 k cycles per 32-key tile against 5.9 k per 64-key tile here (self-attention 34.9 vs 29.7 us,
+// cross-attention 44.6 vs 36.7 us).  Static or rotating s_setprio per wave group moved the wait between waves, not the total.
+// Ablations of THIS kernel (ACE355_ATTN_CLK bits): softmax arithmetic off 6.4 k -> 5.6 k cycles per tile, barrier + DMA off 4.0 k,
+// both off 3.4 k (MFMA issue floor 3.1 k): what is left on the table is the drain / refill of the three in-phase waves of a
+// SIMD at every barrier, which only a deeper K / V^T ring (more LDS than 160 KB allows beside Q) would hide.
+
 }  // namespace
 
 int launch_attention(const AttnArgs& a, hipStream_t s) {
@@ -310,6 +627,38 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     static int nw_env = -1, clk = -1;
     if (nw_env < 0) { const char* e = getenv("ACE355_ATTN_NW"); nw_env = e ? atoi(e) : 0; }
     if (clk < 0) { const char* e = getenv("ACE355_ATTN_CLK"); clk = e ? atoi(e) : 0; }
+    // GQA-shared kernel (Hq = 2 Hkv): one workgroup per (sequence, KV head, 32*NWH query rows), both q heads off one K / V^T
+    // tile.  NWH = the largest of {6, 4, 3} whose grid still gives every CU a workgroup (ACE355_ATTN_GQA=0: attn3_kernel only,
+    // =3/4/6 pins NWH); attn3_kernel keeps the small problems (fewer than 128 such workgroups) and other group sizes.
+    static int gqa_env = -2;
+    if (gqa_env == -2) { const char* e = getenv("ACE355_ATTN_GQA"); gqa_env = e ? atoi(e) : -1; }
+    if (a.Hq == 2 * a.Hkv && gqa_env != 0) {
+        auto units = [&](int nwh) { return (long)a.N * a.Hkv * ((a.Sq + 32 * nwh - 1) / (32 * nwh)); };
+        int nwh = 0;
+        if (gqa_env == 3 || gqa_env == 4 || gqa_env == 6) nwh = gqa_env;
+        else if (units(6) >= 224) nwh = 6;
+        else if (units(4) >= 224) nwh = 4;
+        else if (units(3) >= 128) nwh = 3;
+        if (nwh) {
+            AttnArgs ap = a;
+            ap.clk_probe = clk;  // bit 0: probe + print; bits 1..3: ablations (attn_gqa_kernel)
+            const long total = units(nwh);
+            const dim3 grid((unsigned)((total + 7) / 8 * 8));  // 1-D: the kernel decodes (q-block, KV head, sequence) XCD-aware
+            if (nwh == 6) hipLaunchKernelGGL(attn_gqa_kernel<6>, grid, dim3(768), 0, s, ap, scale_log2, thr);
+            else if (nwh == 4) hipLaunchKernelGGL(attn_gqa_kernel<4>, grid, dim3(512), 0, s, ap, scale_log2, thr);
+            else hipLaunchKernelGGL(attn_gqa_kernel<3>, grid, dim3(384), 0, s, ap, scale_log2, thr);
+            ACE_LAUNCH_CHECK();
+            if (clk) {
+                unsigned long long hh[8] = {0};
+                ACE_HIP(hipStreamSynchronize(s));
+                ACE_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_attn_probe), sizeof(hh)));
+                if (hh[1]) fprintf(stderr, "[ace355 attn-gqa clk] NWH=%d N=%d Sq=%d Skv=%d win=%d flags=%d: %.3f GHz, loop %.0f cycles (%.2f us), %.0f cycles/tile, wait+barrier %.0f cycles/tile; prologue %.0f cycles\n",
+                                   nwh, a.N, a.Sq, a.Skv, a.window, clk, (double)hh[0] / ((double)hh[1] * 10.0), (double)hh[0], (double)hh[1] * 0.01,
+                                   (double)hh[0] / (double)hh[3], (double)hh[2] / (double)hh[3], (double)hh[4]);
+            }
+            return 0;
+        }
+    }
     const long heads = (long)a.Hq * a.N;
     int nw = (a.Sq >= 1024 && heads * ((a.Sq + 255) / 256) >= 512) ? 8 : 4;
     if (nw_env == 4 || nw_env == 8) nw = nw_env;

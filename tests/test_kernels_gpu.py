@@ -202,11 +202,14 @@ def test_headnorm_rope(lib, gpu_device, N, S, heads, rope):
 @pytest.mark.parametrize("N,Sq,Skv,Hq,Hkv,window", [
     (2, 375, 375, 16, 8, -1), (2, 375, 375, 16, 8, 128), (1, 300, 300, 2, 1, 16), (2, 375, 769, 16, 8, -1),
     (1, 20, 33, 2, 1, -1), (1, 1500, 1500, 4, 2, 128), (1, 129, 129, 2, 2, 128), (1, 64, 1, 2, 1, -1),
-    # attn3_kernel<8> (256-query blocks; chosen when Sq >= 1024 and heads x ceil(Sq / 256) >= 512): configs[2]'s self-attention,
-    # full and banded, a ragged last query block (1500 = 5 x 256 + 220) and its cross-attention shape (769 keys)
+    # Hq = 2 Hkv takes attn_gqa_kernel<NWH> once its grid fills the chip (launch_attention): NWH = 6 (12 waves, 192-row blocks:
+    # configs[2]'s self-attention, full and banded, with a ragged last block 1500 = 7 x 192 + 156, and its cross-attention
+    # shape), the metric's launches at N = 16 (NWH = 6: 375 = 192 + 183) and the metric's cross-attention at Nc = 8 (NWH = 3)
     (6, 1500, 1500, 16, 8, -1), (6, 1500, 1500, 16, 8, 128), (6, 1500, 769, 16, 8, -1),
-    # the metric's attn3_kernel<4> launches at N = 16
-    (16, 375, 375, 16, 8, -1), (16, 375, 375, 16, 8, 128), (8, 375, 769, 16, 8, -1)])
+    (16, 375, 375, 16, 8, -1), (16, 375, 375, 16, 8, 128), (8, 375, 769, 16, 8, -1), (16, 375, 769, 16, 8, -1),
+    (12, 375, 375, 16, 8, 128),   # NWH = 4 (8 waves, 128-row blocks)
+    # other group sizes stay on attn3_kernel: <8> (256-query blocks; Sq >= 1024 and heads x ceil(Sq / 256) >= 512) and <4>
+    (6, 1500, 1500, 16, 16, -1), (6, 1500, 1500, 16, 16, 128), (4, 375, 375, 8, 8, 128)])
 def test_attention(lib, gpu_device, N, Sq, Skv, Hq, Hkv, window):
     from oracle import dit as o_dit
     g = torch.Generator().manual_seed(Sq + Skv + Hq)

@@ -3,6 +3,7 @@
 // (generate_audio, base.py:1913-1981).  Host-side orchestration only; kernels live in gemm/attn/elementwise.hip.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <set>
@@ -67,6 +68,15 @@ struct ace355_dit {
     CondSlot slots[ACE355_MAX_SLOTS];
     int* flags_dev = nullptr;
     float* tap_dst[64] = {};  // ace355_dit_set_tap
+    // hipGraph replay of the sampler loop (ace355_dit_set_graph): the captured launch sequence of one whole call, keyed by
+    // everything a kernel argument was computed from
+    bool graph_mode = false;
+    std::string graph_key;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;      // capture / replay stream (the caller's may be the legacy default stream, which
+    hipEvent_t graph_in = nullptr, graph_out = nullptr;  // cannot be captured): ordered against the caller's by two events
+    long ws_epoch = 0, cond_epoch = 0;   // bumped when workspace / condition-slot memory moves or changes shape
+    long graph_replays = 0, graph_captures = 0;
 
     // profiling
     bool profile = false;
@@ -205,6 +215,7 @@ int ensure_rope(ace355_dit* h, int S, hipStream_t s) {
     ACE_HIP(hipMalloc((void**)&h->rope_sin, (size_t)cap * 64 * sizeof(float)));
     int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->cfg.rope_theta, s);
     if (rc) return rc;
+    h->ws_epoch++;
     h->rope_S = cap;
     return 0;
 }
@@ -238,6 +249,7 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
     ALLOC(h->ws_allocs, h->avg, (size_t)capN * capT * h->OUTC);
     h->ws_N = capN;
     h->ws_T = capT;
+    h->ws_epoch++;
     return 0;
 }
 
@@ -396,6 +408,56 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     return rc;
 }
 
+// The sampling loop of generate_audio (base.py:1913-1981) as a launch sequence on stream s: steps x {timestep embedding,
+// decoder forward, guidance + update}.  Pure enqueue (no synchronisation, no allocation): runs eagerly or under stream capture.
+int run_sampler_steps(ace355_dit* h, const ace355_sample_params* p, int B, int T, hipStream_t s, std::vector<hipEvent_t>* evs) {
+    const bool do_cfg = p->guidance_scale > 1.0f;
+    const int copies = do_cfg ? 2 : 1, N = B * copies;
+    const int Tpad = 2 * ((T + 1) / 2);
+    int rc;
+    int slots[ACE355_MAX_SEQS];
+    const int32_t* cond_tab = p->cond_slots_host;  // per-item conditions (NULL: cond_slot for every item)
+    int cond = p->cond_slot;
+    bool switched = false;
+    int apg_calls = 0;
+    for (int i = 0; i < p->num_steps; ++i) {
+        if (i >= p->cover_switch_step && !switched) {  // base.py:1916-1927
+            switched = true;
+            ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
+            cond = p->non_cover_slot;
+            cond_tab = p->non_cover_slots_host;
+            rc = launch_set_xin_ctx(p->ctx_non_cover_dev, h->xin, B, copies, T, Tpad, s);
+            if (rc) return rc;
+        }
+        for (int b = 0; b < B; ++b) {
+            slots[b] = cond_tab ? cond_tab[b] : cond;
+            if (do_cfg) slots[B + b] = p->null_slot;
+        }
+        const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
+        rc = time_embed(h, &t_curr, &t_curr, 1, s);
+        if (rc) return rc;
+        rc = forward_core(h, N, T, slots, 1, s);
+        if (rc) return rc;
+        const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
+        const float dt = t_curr - t_prev;
+        StepUpdate up{nullptr, t_curr, 0.f};
+        if (p->infer_method == 1) {
+            up.sde_noise = p->sde_noise_dev + (size_t)i * B * T * h->OUTC;
+            // base / sft: linear level (base.py:1972); turbo: the next table value (turbo.py:1980-1984)
+            up.t_next = p->sde_next_from_sched ? t_prev : 1.0f - (float)(i + 1) / (float)p->num_steps;
+        }
+        if (do_cfg && apply && p->use_adg)
+            rc = launch_adg_step(h->vpad, (long)B * Tpad * h->OUTC, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, t_curr, dt, up, s);
+        else
+            rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
+                                  apply, do_cfg ? 1 : 0, apg_calls == 0 ? 1 : 0, up, s);
+        if (rc) return rc;
+        if (do_cfg && apply && !p->use_adg) ++apg_calls;
+        if (evs) hipEventRecord((*evs)[i + 1], s);
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -445,6 +507,7 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->sst_out, 2 * D);
     ALLOC(h->allocs, h->flags_dev, 4);
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
+    if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
     *out = h;
     return ACE355_OK;
 }
@@ -459,6 +522,10 @@ void ace355_dit_destroy(ace355_dit* h) {
         if (c.vt) hipFree(c.vt);
         if (c.cross_const) hipFree(c.cross_const);
     }
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph_stream) hipStreamDestroy(h->graph_stream);
+    if (h->graph_in) hipEventDestroy(h->graph_in);
+    if (h->graph_out) hipEventDestroy(h->graph_out);
     if (h->stage) hipFree(h->stage);
     if (h->rope_cos) hipFree(h->rope_cos);
     if (h->rope_sin) hipFree(h->rope_sin);
@@ -554,8 +621,12 @@ int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int 
         ACE_HIP(hipMalloc((void**)&cs.kv, (size_t)h->NL * L * 2 * KVD * 2 + 256));
         ACE_HIP(hipMalloc((void**)&cs.vt, (size_t)h->NL * h->KVH * 128 * Lpad * 2 + 256));
         cs.cap = L;
+        h->cond_epoch++;
     }
-    if (!cs.cross_const) ACE_HIP(hipMalloc((void**)&cs.cross_const, (size_t)h->NL * D * 4 + 256));
+    if (!cs.cross_const) {
+        ACE_HIP(hipMalloc((void**)&cs.cross_const, (size_t)h->NL * D * 4 + 256));
+        h->cond_epoch++;
+    }
     cs.valid = false;
     int rc = launch_f32_to_bf16(enc_dev, h->enc_bf, (long)rows * D, s);
     if (rc) return rc;
@@ -590,6 +661,7 @@ int ace355_dit_set_condition(ace355_dit* h, int slot, const float* enc_dev, int 
             if (rc) return rc;
         }
     }
+    if (cs.broadcast != (rows == 1) || cs.L != L) h->cond_epoch++;  // launch shapes of later forwards change
     cs.broadcast = rows == 1;
     cs.L = L;
     cs.Lpad = Lpad;
@@ -636,11 +708,6 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     rc = launch_set_xin_latent(h->xt, h->xin, B, copies, T, Tpad, s);
     if (rc) return rc;
 
-    int slots[ACE355_MAX_SEQS];
-    const int32_t* cond_tab = p->cond_slots_host;  // per-item conditions (NULL: cond_slot for every item)
-    int cond = p->cond_slot;
-    bool switched = false;
-    int apg_calls = 0;
     struct Events {  // destroyed on every exit path (a failing step used to leak them)
         std::vector<hipEvent_t> v;
         ~Events() { for (auto& e : v) if (e) hipEventDestroy(e); }
@@ -651,46 +718,92 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         for (auto& e : evs) ACE_HIP(hipEventCreate(&e));
         hipEventRecord(evs[0], s);
     }
-    for (int i = 0; i < p->num_steps; ++i) {
-        if (i >= p->cover_switch_step && !switched) {  // base.py:1916-1927
-            switched = true;
-            ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
-            cond = p->non_cover_slot;
-            cond_tab = p->non_cover_slots_host;
-            rc = launch_set_xin_ctx(p->ctx_non_cover_dev, h->xin, B, copies, T, Tpad, s);
-            if (rc) return rc;
+    // hipGraph replay: the loop below is a fixed launch sequence for fixed (shapes, schedule, knobs, slot layout, buffers):
+    // captured once, replayed for every later call with the same key (the latent / context inputs were copied into the
+    // handle's own buffers above, the result is copied out below, so caller pointers are not part of the graph)
+    bool done = false;
+    if (h->graph_mode && !per_step_ms_host && !h->profile) {
+        bool taps = false;
+        for (int l = 0; l < h->NL; ++l) taps = taps || h->tap_dst[l] != nullptr;
+        if (!taps) {
+            std::string key((const char*)p->t_sched_host, (size_t)(p->num_steps + 1) * sizeof(float));
+            auto add = [&](const void* q, size_t n) { key.append((const char*)q, n); };
+            const long scal[] = {B, T, p->num_steps, p->infer_method, p->use_adg, p->cond_slot, p->null_slot, p->cover_switch_step,
+                                 p->non_cover_slot, p->sde_next_from_sched, h->ws_epoch, h->cond_epoch,
+                                 (long)(uintptr_t)p->ctx_non_cover_dev, (long)(uintptr_t)p->sde_noise_dev};
+            add(scal, sizeof(scal));
+            const float fl[] = {p->guidance_scale, p->cfg_interval_start, p->cfg_interval_end};
+            add(fl, sizeof(fl));
+            if (p->cond_slots_host) add(p->cond_slots_host, sizeof(int32_t) * B);
+            key.push_back('|');
+            if (p->non_cover_slots_host) add(p->non_cover_slots_host, sizeof(int32_t) * B);
+            if (!h->graph_stream) {
+                ACE_HIP(hipStreamCreateWithFlags(&h->graph_stream, hipStreamNonBlocking));
+                ACE_HIP(hipEventCreateWithFlags(&h->graph_in, hipEventDisableTiming));
+                ACE_HIP(hipEventCreateWithFlags(&h->graph_out, hipEventDisableTiming));
+            }
+            hipStream_t gs = h->graph_stream;
+            ACE_HIP(hipEventRecord(h->graph_in, s));            // the input copies above
+            ACE_HIP(hipStreamWaitEvent(gs, h->graph_in, 0));
+            if (h->graph_exec && key == h->graph_key) {
+                ACE_HIP(hipGraphLaunch(h->graph_exec, gs));
+                h->graph_replays++;
+                done = true;
+            } else {
+                if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    rc = run_sampler_steps(h, p, B, T, gs, nullptr);
+                    const hipError_t e = hipStreamEndCapture(gs, &g);
+                    if (rc) { if (g) hipGraphDestroy(g); return rc; }
+                    if (e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                        h->graph_key = key;
+                        h->graph_captures++;
+                        hipGraphDestroy(g);
+                        ACE_HIP(hipGraphLaunch(h->graph_exec, gs));
+                        done = true;
+                    } else {
+                        if (g) hipGraphDestroy(g);
+                        h->graph_exec = nullptr;
+                        (void)hipGetLastError();  // capture / instantiate refused: run eagerly below
+                    }
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
         }
-        for (int b = 0; b < B; ++b) {
-            slots[b] = cond_tab ? cond_tab[b] : cond;
-            if (do_cfg) slots[B + b] = p->null_slot;
-        }
-        const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
-        rc = time_embed(h, &t_curr, &t_curr, 1, s);
+    }
+    if (done) {  // the output copy below (and whatever the caller enqueues next) waits for the replay
+        ACE_HIP(hipEventRecord(h->graph_out, h->graph_stream));
+        ACE_HIP(hipStreamWaitEvent(s, h->graph_out, 0));
+    } else {
+        rc = run_sampler_steps(h, p, B, T, s, per_step_ms_host ? &evs : nullptr);
         if (rc) return rc;
-        rc = forward_core(h, N, T, slots, 1, s);
-        if (rc) return rc;
-        const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
-        const float dt = t_curr - t_prev;
-        StepUpdate up{nullptr, t_curr, 0.f};
-        if (p->infer_method == 1) {
-            up.sde_noise = p->sde_noise_dev + (size_t)i * B * T * h->OUTC;
-            // base / sft: linear level (base.py:1972); turbo: the next table value (turbo.py:1980-1984)
-            up.t_next = p->sde_next_from_sched ? t_prev : 1.0f - (float)(i + 1) / (float)p->num_steps;
-        }
-        if (do_cfg && apply && p->use_adg)
-            rc = launch_adg_step(h->vpad, (long)B * Tpad * h->OUTC, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, t_curr, dt, up, s);
-        else
-            rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
-                                  apply, do_cfg ? 1 : 0, apg_calls == 0 ? 1 : 0, up, s);
-        if (rc) return rc;
-        if (do_cfg && apply && !p->use_adg) ++apg_calls;
-        if (per_step_ms_host) hipEventRecord(evs[i + 1], s);
     }
     ACE_HIP(hipMemcpyAsync(latents_out_dev, h->xt, lat_bytes, hipMemcpyDeviceToDevice, s));
     if (per_step_ms_host) {
         ACE_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < p->num_steps; ++i) hipEventElapsedTime(&per_step_ms_host[i], evs[i], evs[i + 1]);
     }
+    return ACE355_OK;
+}
+
+int ace355_dit_set_graph(ace355_dit* h, int enable) {
+    ACE_CHECK(h, "set_graph: null handle");
+    h->graph_mode = enable != 0;
+    if (!h->graph_mode && h->graph_exec) {
+        hipDeviceSynchronize();
+        hipGraphExecDestroy(h->graph_exec);
+        h->graph_exec = nullptr;
+        h->graph_key.clear();
+    }
+    return ACE355_OK;
+}
+
+int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays) {
+    ACE_CHECK(h, "graph_stats: null handle");
+    if (captures) *captures = h->graph_captures;
+    if (replays) *replays = h->graph_replays;
     return ACE355_OK;
 }
 

@@ -172,6 +172,16 @@ class NativeDit:
             return out, list(ms)
         return out
 
+    # ------------------------------------------------------------------ hipGraph replay of the sampler loop
+    def set_graph(self, enable: bool) -> None:
+        """Capture the sampler's launch sequence once per (shapes, schedule, knobs, slots, stream) and replay it afterwards."""
+        native.check(self._lib.ace355_dit_set_graph(self._h, 1 if enable else 0), "dit_set_graph")
+
+    def graph_stats(self):
+        c, r = C.c_int64(), C.c_int64()
+        native.check(self._lib.ace355_dit_graph_stats(self._h, C.byref(c), C.byref(r)), "dit_graph_stats")
+        return {"captures": c.value, "replays": r.value}
+
     # ------------------------------------------------------------------ debug taps
     def set_tap(self, layer: int, dst: Optional[torch.Tensor]) -> None:
         """Copy the fp32 residual stream after decoder layer ``layer`` of every following forward into ``dst``

@@ -79,6 +79,8 @@ SIGNATURES = {
     "ace355_dit_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(SampleParamsC),
                                     C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
     "ace355_dit_set_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ace355_dit_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "ace355_dit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ace355_dit_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

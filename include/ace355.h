@@ -128,6 +128,13 @@ typedef struct ace355_sample_params {
 int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev, int B, int T,
                       const ace355_sample_params* p, float* latents_out_dev, float* per_step_ms_host, void* stream);
 
+/* hipGraph replay of the sampling loop: with enable != 0, ace355_dit_sample captures its launch
+ * sequence (steps x ~360 kernels) into a graph on first use and replays it for every later call with the same shapes, schedule,
+ * knobs, slot layout and stream; any change re-captures.  Results are identical to the eager path (same kernels, same order).
+ * Off by default; ACE355_SAMPLE_GRAPH=1 in the environment turns it on at handle creation.  graph_stats: captures / replays so far. */
+int ace355_dit_set_graph(ace355_dit* h, int enable);
+int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
+
 /* Test / debug hook: after decoder layer `layer` (0-based) of every following forward, copy the fp32 residual stream
  * hidden_states [N*S, hidden] (the layer's output, base.py:539) to dst_dev; dst_dev NULL clears the tap.  Lets the parity
  * tests compare the per-layer activations the golden fixtures hold, not only the final velocity. */

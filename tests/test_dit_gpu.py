@@ -348,3 +348,76 @@ def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_pat
     r1, r0, rx = _rel(outs["1"], ref), _rel(outs["0"], ref), _rel(outs["1"], outs["0"])
     print(f"head epilogue: fused vs reference {r1:.3e}, two-kernel vs reference {r0:.3e}, fused vs two-kernel {rx:.3e}")
     assert r1 < 8e-3 and r0 < 8e-3 and rx < 2.5e-3, (r1, r0, rx)  # measured 3.1e-3, 3.1e-3, 7.8e-4
+
+
+def test_torch_library_ops_match_direct_calls(gpu_device):
+    """torch.ops.ace355.dit_sample / vae_decode / peak_normalize are the same native calls in dispatcher-visible form."""
+    import ace355
+    from ace355 import ops, weightgen
+    from ace355.dit import prepare_noise, schedule
+    from ace355.vae import NativeVae
+    cfg, w, dit = _make(TINY, 5, gpu_device)
+    g = torch.Generator().manual_seed(12)
+    B, T, L = 2, 40, 9
+    enc = torch.randn(L, cfg.hidden_size, generator=g)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=5)
+    ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1).to(gpu_device)
+    dit.set_condition(0, enc)
+    dit.set_condition(1, null.reshape(1, -1), L=L)
+    xt0 = prepare_noise((B, T, 64), [3, 4]).to(gpu_device)
+    ts = schedule(5, 2.0)
+    ref = dit.sample(xt0, ctx, ts, 6.0)
+    k = ops.register_handle(dit)
+    out = torch.ops.ace355.dit_sample(k, xt0, ctx, ts, 6.0)
+    assert torch.equal(out, ref)
+    vkw = dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6))
+    vcfg = ace355.VaeConfig(**vkw)
+    vae = NativeVae(vcfg, gpu_device)
+    vae.load_state_dict(weightgen.make_vae_weights(vcfg.weight_shapes(), seed=5, mode="test"))
+    z = out.transpose(1, 2).contiguous()
+    kv = ops.register_handle(vae)
+    wav = torch.ops.ace355.vae_decode(kv, z, vae.hop)
+    assert torch.equal(wav, vae.decode(z)) and tuple(wav.shape) == (B, 2, vae.hop * T)
+    big = wav * 7.0
+    pn = torch.ops.ace355.peak_normalize(big)
+    assert float(pn.abs().max()) <= 1.0 + 1e-6 and torch.equal(big, wav * 7.0)  # functional: the input is not modified
+    ops.release_handle(k)
+    ops.release_handle(kv)
+
+
+def test_hipgraph_replay_of_the_sampler_equals_eager(gpu_device):
+    """ace355_dit_set_graph: the sampler's launch sequence captured once and replayed - same kernels in the same order, so the
+    latents are bit-identical to the eager path; a changed knob or shape re-captures; conditions may be re-uploaded between
+    replays (slot memory is reused in place)."""
+    from ace355 import weightgen
+    from ace355.dit import prepare_noise, schedule
+    cfg, w, dit = _make(TINY, 9, gpu_device)
+    g = torch.Generator().manual_seed(3)
+    B, T, L = 3, 54, 21
+    enc = torch.randn(L, cfg.hidden_size, generator=g)
+    enc2 = torch.randn(L, cfg.hidden_size, generator=g)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=9)
+    ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1).to(gpu_device)
+    dit.set_condition(0, enc)
+    dit.set_condition(1, null.reshape(1, -1), L=L)
+    x0 = prepare_noise((B, T, 64), [1, 2, 3]).to(gpu_device)
+    x1 = prepare_noise((B, T, 64), [4, 5, 6]).to(gpu_device)
+    ts = schedule(6, 3.0)
+    eager = [dit.sample(x, ctx, ts, 5.0) for x in (x0, x1)]
+    dit.set_graph(True)
+    try:
+        got = [dit.sample(x, ctx, ts, 5.0) for x in (x0, x1, x0)]
+        st = dit.graph_stats()
+        assert st == {"captures": 1, "replays": 2}, st
+        assert torch.equal(got[0], eager[0]) and torch.equal(got[1], eager[1]) and torch.equal(got[2], eager[0])
+        dit.set_condition(0, enc2)                       # new caption, same slot memory: replay stays valid
+        e2 = dit.sample(x0, ctx, ts, 5.0)
+        assert dit.graph_stats()["captures"] == 1 and not torch.equal(e2, eager[0])
+        dit.set_graph(False)
+        assert torch.equal(dit.sample(x0, ctx, ts, 5.0), e2)
+        dit.set_graph(True)
+        dit.sample(x0, ctx, ts, 3.0)                     # other guidance: new key
+        dit.sample(x0[:2], ctx[:2], ts, 3.0)             # other batch
+        assert dit.graph_stats()["captures"] == 3
+    finally:
+        dit.set_graph(False)

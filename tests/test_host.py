@@ -308,3 +308,28 @@ def test_flop_model_matches_survey():
     assert abs(f / 1e12 - 1.136) < 0.002  # SURVEY 8d / BASELINE.md section 4
     assert abs(bench.vae_flops_per_frame(ace355.VaeConfig()) / 1e9 - 4.874) < 0.002
     assert abs(bench.dit_flops_per_forward_per_seq(ace355.DitConfig(), 125, L) / 1e12 - 0.375) < 0.001
+
+
+def test_torch_library_ops_are_registered_with_fake_impls():
+    """north_star: "via PyTorch-ROCm custom ops".  torch.ops.ace355.* exist, propagate shapes under FakeTensorMode without a GPU
+    or a library call, and have NO CPU kernel (a CPU tensor is refused, never silently computed elsewhere)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from ace355 import ops
+    for name in ("dit_forward", "dit_sample", "vae_decode", "vae_encode", "peak_normalize"):
+        assert hasattr(torch.ops.ace355, name), name
+    with FakeTensorMode():
+        z = torch.empty(3, 64, 100, device="cuda")
+        w = torch.ops.ace355.vae_decode(5, z, 1920)
+        assert tuple(w.shape) == (3, 2, 192000) and w.dtype == torch.float32 and w.device.type == "cuda"
+        a = torch.empty(2, 2, 1920 * 7, device="cuda")
+        assert tuple(torch.ops.ace355.vae_encode(5, a, 1920).shape) == (2, 64, 7)
+        xt, ctx = torch.empty(2, 50, 64, device="cuda"), torch.empty(2, 50, 128, device="cuda")
+        assert tuple(torch.ops.ace355.dit_sample(7, xt, ctx, torch.empty(28)).shape) == (2, 50, 64)
+        assert tuple(torch.ops.ace355.dit_forward(7, xt, ctx, [0.5, 0.5], [0.5, 0.5], [0, 1]).shape) == (2, 50, 64)
+    with pytest.raises(NotImplementedError):
+        torch.ops.ace355.peak_normalize(torch.zeros(1, 2, 4))
+    k = ops.register_handle(object())
+    assert ops.register_handle(ops._HANDLES[k]) == k
+    ops.release_handle(k)
+    with pytest.raises(RuntimeError, match="unknown native handle"):
+        ops._get(k)

@@ -137,6 +137,36 @@ int ace355_gemm_bf16_headnorm(const void* A, const void* W, void* out, int M, in
     return launch_gemm((const bf16_t*)A, K, Wuse, K, out, N, M, N, K, ep, s);
 }
 
+int ace355_mx_quantize(const void* x_bf16, int M, int K, void* q_out, uint32_t* scales_out, int rows_pad, void* stream) {
+    ACE_CHECK(x_bf16 && q_out && scales_out, "mx_quantize: null pointer");
+    return launch_mx_quant((const bf16_t*)x_bf16, K, M, K, (uint8_t*)q_out, scales_out, rows_pad, (hipStream_t)stream);
+}
+
+int ace355_mx_rows_pad(int rows) { return mx_rows_pad(rows); }
+
+int ace355_gemm_mxfp8(const void* A, const void* W, void* out, int M, int N, int K, int mode, const float* g1, const float* g2,
+                      int g2_stride, int rows_per_seq, void* stream) {
+    ACE_CHECK(A && W && out, "gemm_mxfp8: null pointer");
+    ACE_CHECK(mode == 0 || mode == 2 || mode == 3, "gemm_mxfp8: mode 0 (bf16 store), 2 (residual), 3 (SwiGLU)");
+    ACE_CHECK(gemm_mx_supported(M, N, K, mode), "gemm_mxfp8: K % 128 == 0, N % 256 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    DevTmp t(s);
+    const int pa = mx_rows_pad(M), pw = mx_rows_pad(N);
+    ACE_HIP(hipMalloc(&t.p[0], (size_t)M * K));
+    ACE_HIP(hipMalloc(&t.p[1], (size_t)N * K));
+    ACE_HIP(hipMalloc(&t.p[2], (size_t)(K / 128) * pa * 4));
+    ACE_HIP(hipMalloc(&t.p[3], (size_t)(K / 128) * pw * 4));
+    ACE_HIP(hipMemsetAsync(t.p[2], 0, (size_t)(K / 128) * pa * 4, s));
+    ACE_HIP(hipMemsetAsync(t.p[3], 0, (size_t)(K / 128) * pw * 4, s));
+    int rc = launch_mx_quant((const bf16_t*)A, K, M, K, (uint8_t*)t.p[0], (uint32_t*)t.p[2], pa, s);
+    if (rc) return rc;
+    rc = launch_mx_quant((const bf16_t*)W, K, N, K, (uint8_t*)t.p[1], (uint32_t*)t.p[3], pw, s);
+    if (rc) return rc;
+    GemmEpilogue ep{mode, nullptr, g1, g2, g2_stride, rows_per_seq};
+    return launch_gemm_mx((const uint8_t*)t.p[0], (const uint32_t*)t.p[2], pa, (const uint8_t*)t.p[1], (const uint32_t*)t.p[3], pw, out,
+                          mode == 3 ? N / 2 : N, M, N, K, ep, s);
+}
+
 int ace355_rmsnorm_mod(const float* x, const float* w, void* y, int M, int D, float eps, const float* sc1, const float* sc2,
                        const float* sh1, const float* sh2, int stride, int rows_per_seq, void* stream) {
     ACE_CHECK(x && w && y, "rmsnorm_mod: null pointer");

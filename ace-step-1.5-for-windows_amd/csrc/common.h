@@ -104,9 +104,22 @@ struct GemmEpilogue {
     const float *hn_wq, *hn_wk, *hn_cos, *hn_sin;
     int hn_q_cols, hn_qk_cols;
     float hn_eps;
+    // MX-scaled fp8 operands (OCP MXFP8: e4m3 elements, one E8M0 scale per 32 consecutive K elements of a row; mx_quant_kernel).
+    // Non-null: A and W point at fp8 bytes ([M, K] / [N, K] row-major, K % 128 == 0; lda / ldw in BYTES / 2, launch_gemm_mx does
+    // that), the scales are uint32 [K / 128][rows_padded]: byte b of word [kt][r] = scale of row r, K elements 128 kt + 32 b .. + 31.
+    const uint32_t* mx_sa; const uint32_t* mx_sw;
+    int mx_sa_ld, mx_sw_ld;   // padded row counts of the two scale arrays (words per K step)
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
+// MXFP8 operands: Aq / Wq fp8 e4m3 [M, K] / [N, K] (row stride = K bytes), scales as GemmEpilogue::mx_sa / mx_sw describe; same
+// epilogues (modes 0, 2, 3, 4).  Only shapes that take the 8-wave 192x256 tile (launch_gemm_mx checks); K % 128 == 0.
+int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8_t* Wq, const uint32_t* sw, int sw_ld, void* C, int ldc,
+                   int M, int N, int K, const GemmEpilogue& ep, hipStream_t s);
+bool gemm_mx_supported(int M, int N, int K, int mode);
+// x bf16 [M, K] (row stride ld) -> q fp8 e4m3 [M, K] + scales uint32 [K / 128][rows_pad] (rows_pad >= M, multiple of 4)
+int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t* scales, int rows_pad, hipStream_t s);
+inline int mx_rows_pad(int rows) { return ((rows + 255) / 256) * 256 + 256; }
 
 struct AttnArgs {
     const bf16_t* q; long q_seq_stride; int q_row_stride;           // q[n][s][h*128 + d]

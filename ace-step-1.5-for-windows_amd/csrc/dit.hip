@@ -18,9 +18,15 @@ using namespace ace355;
 
 namespace {
 
+struct MxW {  // MXFP8 copy of one packed projection (ace355_dit_set_precision): fp8 e4m3 [N, K] + E8M0 block scales [K/128][pad]
+    uint8_t* q = nullptr;
+    uint32_t* sc = nullptr;
+    int pad = 0;
+};
 struct LayerW {
     bf16_t *wqkv, *wo, *wq_c, *wkv_c, *wo_c, *wgu, *wdown;
     float *n_sa, *n_ca, *n_mlp, *qn_s, *kn_s, *qn_c, *kn_c, *sst;
+    MxW mx_qkv, mx_o, mx_gu, mx_down;
 };
 struct TimeEmbedW {
     bf16_t *l1, *l2, *tp;
@@ -77,6 +83,13 @@ struct ace355_dit {
     hipEvent_t graph_in = nullptr, graph_out = nullptr;  // cannot be captured): ordered against the caller's by two events
     long ws_epoch = 0, cond_epoch = 0;   // bumped when workspace / condition-slot memory moves or changes shape
     long graph_replays = 0, graph_captures = 0;
+    // MXFP8 mode (BASELINE configs[4] "fp8 MFMA"): the four big projections of every layer run on v_mfma_scale_f32_32x32x64_f8f6f4
+    int precision = 0;                 // ACE355_PRECISION_*
+    std::vector<void*> mx_allocs;      // weight copies
+    uint8_t* xq = nullptr;             // activation operand of the current MX GEMM, fp8 [M, max(D, F)]
+    uint32_t* xs = nullptr;            // its scales [max(D, F) / 128][xs_pad]
+    int xs_pad = 0;
+    int mx_min_rows = 1536;            // below this many token rows the 192x256 tile does not fill the chip: bf16 kernels
 
     // profiling
     bool profile = false;
@@ -200,6 +213,24 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
     return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
 }
 
+// The same projection on the MXFP8 path: the bf16 activation operand is block-quantised (mx_quant_kernel) into the handle's scratch,
+// then the MX GEMM runs against the layer's fp8 weight copy with the bf16 kernel's epilogue.  Caller checked mx_usable().
+int gemm_mx(ace355_dit* h, const bf16_t* A, int lda, const MxW& W, void* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
+            hipStream_t s) {
+    int rc = launch_mx_quant(A, lda, M, K, h->xq, h->xs, h->xs_pad, s);
+    if (rc) return rc;
+    EvScope ev(h, &h->gemm_ev, s);
+    if (h->profile) {
+        h->gemm_flops += 2.0 * M * N * K;
+        h->gemm_launches++;
+    }
+    return launch_gemm_mx(h->xq, h->xs, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, ep, s);
+}
+bool mx_usable(const ace355_dit* h, const MxW& W, int M, int N, int K, int mode, int q_cols = 0, int qk_cols = 0) {
+    return h->precision == ACE355_PRECISION_MXFP8 && W.q && M >= h->mx_min_rows && gemm_mx_supported(M, N, K, mode) &&
+           (mode != 4 || (q_cols % 256 == 0 && qk_cols % 256 == 0));
+}
+
 int ensure_rope(ace355_dit* h, int S, hipStream_t s) {
     if (S <= h->rope_S) return 0;
     int cap = 512;
@@ -247,6 +278,13 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
     ALLOC(h->ws_allocs, h->gs, (size_t)capN * h->NL * 4 * D);
     ALLOC(h->ws_allocs, h->xt, (size_t)capN * capT * h->OUTC);
     ALLOC(h->ws_allocs, h->avg, (size_t)capN * capT * h->OUTC);
+    {
+        const long KX = D > h->F ? D : h->F;
+        h->xs_pad = mx_rows_pad((int)M);
+        ALLOC(h->ws_allocs, h->xq, (size_t)M * KX + 256);
+        ALLOC(h->ws_allocs, h->xs, (size_t)(KX / 128 + 1) * h->xs_pad);
+        ACE_HIP(hipMemsetAsync(h->xs, 0, (size_t)(KX / 128 + 1) * h->xs_pad * sizeof(uint32_t), s));
+    }
     h->ws_N = capN;
     h->ws_T = capT;
     h->ws_epoch++;
@@ -322,7 +360,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};
         ep.hn_wq = W.qn_s, ep.hn_wk = W.kn_s, ep.hn_cos = h->rope_cos, ep.hn_sin = h->rope_sin;
         ep.hn_q_cols = QD, ep.hn_qk_cols = QD + KVD, ep.hn_eps = eps;
-        rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
+        if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
+        else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
         if (rc) return rc;
         rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
         if (rc) return rc;
@@ -350,7 +389,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             if (rc) return rc;
         }
         ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S, cconst ? cconst + (size_t)li * D : nullptr, Mc};
-        rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
+        if (mx_usable(h, W.mx_o, M, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
+        else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
 
         // ---- cross attention (base.py:515-526): un-modulated norm, plain residual, cached K/V, no RoPE
@@ -390,10 +430,12 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
                                gs_stride, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{3, nullptr, nullptr, nullptr, 0, 0};
-        rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
+        if (mx_usable(h, W.mx_gu, M, 2 * F, D, 3)) rc = gemm_mx(h, h->xn, D, W.mx_gu, h->act, F, M, 2 * F, D, ep, s);
+        else rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, h->tproj + 5 * D, tstride, S};
-        rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
+        if (mx_usable(h, W.mx_down, M, D, F, 2)) rc = gemm_mx(h, h->act, F, W.mx_down, h->h, D, M, D, F, ep, s);
+        else rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
         if (rc) return rc;
         if (h->tap_dst[li]) ACE_HIP(hipMemcpyAsync(h->tap_dst[li], h->h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
@@ -517,6 +559,7 @@ void ace355_dit_destroy(ace355_dit* h) {
     hipDeviceSynchronize();
     for (void* p : h->allocs) hipFree(p);
     for (void* p : h->ws_allocs) hipFree(p);
+    for (void* p : h->mx_allocs) hipFree(p);
     for (CondSlot& c : h->slots) {
         if (c.kv) hipFree(c.kv);
         if (c.vt) hipFree(c.vt);
@@ -785,6 +828,36 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         ACE_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < p->num_steps; ++i) hipEventElapsedTime(&per_step_ms_host[i], evs[i], evs[i + 1]);
     }
+    return ACE355_OK;
+}
+
+int ace355_dit_set_precision(ace355_dit* h, int precision) {
+    ACE_CHECK(h, "set_precision: null handle");
+    ACE_CHECK(precision == ACE355_PRECISION_BF16 || precision == ACE355_PRECISION_MXFP8, "set_precision: unknown precision");
+    if (!h->finalized) { set_error("set_precision: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
+    ACE_HIP(hipDeviceSynchronize());
+    if (precision == ACE355_PRECISION_MXFP8 && h->mx_allocs.empty()) {
+        // block-quantise the four big packed projections of every layer once (rows keep their packed order: head-pair q / k rows,
+        // [32 gate | 32 up] interleave - quantisation is per row, so the packing commutes with it)
+        auto make = [&](const bf16_t* w, int N, int K, MxW* out) -> int {
+            if (K % 128 != 0 || N % 256 != 0) return 0;  // tiny configurations: this projection stays bf16
+            out->pad = mx_rows_pad(N);
+            ALLOC(h->mx_allocs, out->q, (size_t)N * K + 256);
+            ALLOC(h->mx_allocs, out->sc, (size_t)(K / 128) * out->pad);
+            ACE_HIP(hipMemset(out->sc, 0, (size_t)(K / 128) * out->pad * sizeof(uint32_t)));
+            return launch_mx_quant(w, K, N, K, out->q, out->sc, out->pad, nullptr);
+        };
+        for (LayerW& L : h->layers) {
+            int rc = make(L.wqkv, h->QD + 2 * h->KVD, h->D, &L.mx_qkv);
+            if (!rc) rc = make(L.wo, h->D, h->QD, &L.mx_o);
+            if (!rc) rc = make(L.wgu, 2 * h->F, h->D, &L.mx_gu);
+            if (!rc) rc = make(L.wdown, h->D, h->F, &L.mx_down);
+            if (rc) return rc;
+        }
+        ACE_HIP(hipDeviceSynchronize());
+    }
+    h->precision = precision;
+    h->ws_epoch++;  // a captured sampler graph holds the other precision's launches
     return ACE355_OK;
 }
 

@@ -242,6 +242,63 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// OCP MXFP8 quantiser: x bf16 [M, K] -> q fp8 e4m3 [M, K] + one E8M0 scale per 32 consecutive K elements of a row.
+// Shared exponent (OCP Microscaling v1.0, 6.3): e = floor(log2(max|v|)) - emax(e4m3 = 8); elements = round-to-nearest-even of v * 2^-e,
+// saturated to +-448.  Scale bytes are stored as uint32 [K / 128][rows_pad]: byte b of word [kt][row] = block 4 kt + b (what one K step
+// of the MX GEMM consumes per row).  One wave per row: lane j owns block j of each 2048-column span (64 bytes in, 32 bytes out).
+__global__ __launch_bounds__(256) void mx_quant_kernel(const bf16_t* __restrict__ x, long ld, int M, int K, uint8_t* __restrict__ q,
+                                                       uint32_t* __restrict__ scales, int rows_pad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    for (int k0 = 0; k0 < K; k0 += 2048) {
+        const int col = k0 + lane * 32;
+        const bool act = col < K;
+        uint4 in[4];
+        float v[32];
+        float amax = 0.f;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) in[i] = *reinterpret_cast<const uint4*>(x + (long)row * ld + col + i * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w[4] = {in[i].x, in[i].y, in[i].z, in[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[i * 8 + 2 * e] = bf_lo(w[e]);
+                    v[i * 8 + 2 * e + 1] = bf_hi(w[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 32; ++e) amax = fmaxf(amax, fabsf(v[e]));
+        }
+        // floor(log2(amax)) from the exponent field (bf16 inputs have no fp32 subnormals worth modelling: amax < 2^-126 -> scale 2^-127)
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);          // biased exponent of amax
+        int sb = ex - 8;                                                       // biased E8M0 = floor(log2 amax) - 8 + 127
+        sb = sb < 0 ? 0 : (sb > 254 ? 254 : sb);
+        const float inv = __uint_as_float((uint32_t)(254 - sb) << 23);        // 2^-(sb - 127)
+        if (act) {
+            uint32_t out[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float a0 = fminf(fmaxf(v[4 * e + 0] * inv, -448.f), 448.f), a1 = fminf(fmaxf(v[4 * e + 1] * inv, -448.f), 448.f);
+                float a2 = fminf(fmaxf(v[4 * e + 2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(v[4 * e + 3] * inv, -448.f), 448.f);
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+                out[e] = (uint32_t)pk;
+            }
+            uint8_t* qp = q + (long)row * K + col;
+            *reinterpret_cast<uint4*>(qp) = make_uint4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<uint4*>(qp + 16) = make_uint4(out[4], out[5], out[6], out[7]);
+        }
+        // four neighbouring lanes = the four blocks of one 128-column K step
+        uint32_t wv = (uint32_t)sb << (8 * (lane & 3));
+        wv |= __shfl_xor(wv, 1, 64);
+        wv |= __shfl_xor(wv, 2, 64);
+        if (act && (lane & 3) == 0) scales[(long)(col >> 7) * rows_pad + row] = wv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // TimestepEmbedding.timestep_embedding (base.py:225-246): out[m][0:128] = cos(t*1000*f_k), [128:256] = sin(..)
 __global__ void sinusoid_kernel(TVals tv, int n, float* __restrict__ out) {
     const int m = blockIdx.x, k = threadIdx.x;  // 128 threads
@@ -708,6 +765,14 @@ int launch_transpose_v(const bf16_t* x, int ld, int col0, int N, int S, int head
 }
 
 // Qwen3RotaryEmbedding (default rope): inv_freq = theta^(-2k/128) in fp32, angle = pos * inv_freq in fp32.
+int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t* scales, int rows_pad, hipStream_t s) {
+    ACE_CHECK(K % 128 == 0 && ld % 8 == 0 && rows_pad >= M, "mx_quant: K % 128, 16-byte rows, rows_pad >= M");
+    ACE_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 15) == 0, "mx_quant: 16-byte aligned buffers");
+    hipLaunchKernelGGL(mx_quant_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ld, M, K, q, scales, rows_pad);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s) {
     std::vector<float> c((size_t)S * 64), sn((size_t)S * 64);
     float inv[64];

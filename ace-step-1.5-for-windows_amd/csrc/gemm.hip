@@ -484,6 +484,19 @@ __device__ __forceinline__ void glds16_sv(unsigned voff, const void* sbase, unsi
                  : "v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory");
 }
+// One MX-scaled fp8 MFMA over 64 K elements: (x0 | x1) = the two 16-byte fragments a lane holds for one operand (slots 2kk, 2kk+1),
+// sa / sb = the lane's scale words, OPSEL = the byte of them that belongs to this MFMA's k-block (tools/probe/mx_probe.py).
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <int OPSEL>
+__device__ __forceinline__ f32x16 mfma_mx(bf16x8 a0, bf16x8 a1, bf16x8 b0, bf16x8 b1, f32x16 c, unsigned sa, unsigned sb) {
+    const i32x4_t A0 = __builtin_bit_cast(i32x4_t, a0), A1 = __builtin_bit_cast(i32x4_t, a1);
+    const i32x4_t B0 = __builtin_bit_cast(i32x4_t, b0), B1 = __builtin_bit_cast(i32x4_t, b1);
+    const i32x8_t A = {A0[0], A0[1], A0[2], A0[3], A1[0], A1[1], A1[2], A1[3]};
+    const i32x8_t B = {B0[0], B0[1], B0[2], B0[3], B1[0], B1[1], B1[2], B1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 0, 0, OPSEL, (int)sa, OPSEL, (int)sb);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -503,7 +516,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // gridDim/8: no s_endpgm store drain, no workgroup re-dispatch and no kernarg reload between the tiles of a multi-round GEMM.
 // NS = LDS stages (2: product default, one K step of DMA cover; 3-4: small-M launches with one workgroup per CU, where
 // nothing else hides the HBM latency of the weight stream: NS-1 tiles stay in flight behind a counted vmcnt).
-template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0, int NS = 2>
+// FP8 = 1: MX-scaled fp8 operands (v_mfma_scale_f32_32x32x64_f8f6f4).  A K step is 128 fp8 elements = the same 128 bytes per row,
+// so the LDS images, DMA pieces and fragment reads are byte-identical to the bf16 kernel; the two bf16 MFMAs over the fragments
+// of slots (2 kk, 2 kk + 1) become ONE scaled MFMA over both (lane half h holds k = 16h..16h+15 and 32+16h..+15 of the 64: exactly
+// those two 16-byte slots; tools/probe/mx_probe.py established the layout).  Scales ride as one extra 1 KB DMA piece per operand per
+// K step (waves 0 / 1) behind the tiles: word [row] = the four E8M0 bytes of this K step; the upper lane half shifts its word by 8
+// so that op_sel 0 / 2 picks block (0 | 1) / (2 | 3).
+template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0, int NS = 2, int FP8 = 0>
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A0, int lda, const bf16_t* __restrict__ W0,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
@@ -513,7 +532,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     static_assert(MODE != 3 || NTW == 2, "SwiGLU pairs two column tiles per wave");
     constexpr int NW = 2 * WNW;                 // waves per workgroup
     constexpr int W_BYTES = BNv * 128;
-    constexpr int STAGE = A_BYTES + W_BYTES;
+    constexpr int SC_BYTES = FP8 ? 2048 : 0;    // MX scales of a K step: 1 KB (256 rows x 4 B) per operand
+    constexpr int STAGE = A_BYTES + W_BYTES + SC_BYTES;
+    static_assert(!FP8 || (NS == 2 && BMv <= 256 && WNW * NTW * 32 <= 256 && 2 * WNW >= 2), "MX path: 2 stages, tiles up to 256 rows");
     constexpr int AJ = BMv / (8 * NW);          // A DMA pieces per wave per tile (8 rows each)
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
@@ -573,14 +594,37 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     if (nk <= 0) return;
     const bf16_t* A = A0 + kt0 * BK;
     const bf16_t* W = W0 + kt0 * BK;
+    const int frow = lane & 31, fhalf = lane >> 5;
+    // MX scales: wave 0 stages the A rows' words of K step kt (rows m0 .. m0+255 of scale row kt, 16 bytes per lane), wave 1 the W rows'
+    const unsigned sc_voff = (unsigned)lane * 16u;
+    const unsigned sc_lds = (unsigned)(uintptr_t)smem + A_BYTES + W_BYTES + (wave == 1 ? 1024u : 0u);
+    auto issue_scales = [&](int kt) {
+        if constexpr (FP8) {
+            if (wave < 2) {
+                const uint32_t* src = wave == 0 ? ep.mx_sa + (long)(kt0 + kt) * ep.mx_sa_ld + m0 : ep.mx_sw + (long)(kt0 + kt) * ep.mx_sw_ld + n0;
+                glds16_sv(sc_voff, src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sc_lds + (unsigned)(kt % NS) * STAGE)));
+            }
+        }
+    };
     auto issue = [&](int kt) {
         const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
 #pragma unroll
         for (int j = 0; j < AJ; ++j) glds16_sv(a_voff[j], A + kt * BK, sb + j * (NW * 1024));
 #pragma unroll
         for (int j = 0; j < WJ; ++j) glds16_sv(w_voff[j], W + kt * BK, sb + A_BYTES + j * (NW * 1024));
+        issue_scales(kt);
     };
-    const int frow = lane & 31, fhalf = lane >> 5;
+    // this lane's scale words of a stage (row of each of its A / W tiles), pre-shifted for the upper lane half
+    unsigned sca[MT], scw[NTW];
+    auto load_scales = [&](const char* st) {
+        if constexpr (FP8) {
+            const char* sc = st + A_BYTES + W_BYTES;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sca[i] = *reinterpret_cast<const unsigned*>(sc + (wm * (MT * 32) + i * 32 + frow) * 4) >> (8 * fhalf);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) scw[j] = *reinterpret_cast<const unsigned*>(sc + 1024 + (wn * (NTW * 32) + j * 32 + frow) * 4) >> (8 * fhalf);
+        }
+    };
     // per-lane fragment byte offsets inside a stage for kk = 0 (the kk term only flips slot bits: see lds_off)
     int a_off[MT], w_off[NTW];
 #pragma unroll
@@ -604,7 +648,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     issue(0);
     if (NS == 2) {
         if (nk > 1) issue(1);
-        if (nk > 1) wait_vmcnt<AJ + WJ>(); else wait_vmcnt<0>();
+        if (nk > 1) {
+            if (FP8 && wave < 2) wait_vmcnt<AJ + WJ + 1>(); else wait_vmcnt<AJ + WJ>();  // (waves 0 / 1 carry one scale piece per K step)
+        } else wait_vmcnt<0>();
     } else {
         // deep pipeline: all NS stages primed when the K range is long enough (else plain drain: short ranges are rare here)
         if (nk >= NS) {
@@ -618,6 +664,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     }
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, pa, pw);
+    load_scales(smem);
 
     // ---- ILV: explicit instruction interleave.  An LDS-DMA piece costs 60-185 cycles to ISSUE (TA queue); seven of them
     // back to back right after the barrier stall the in-order wave before its first MFMA.  Here every MFMA is followed
@@ -683,13 +730,87 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        auto kstep_mx = [&](int kt, auto more_c, auto dma_c) {
+            constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
+            constexpr int NX = MT * NTW;  // scaled MFMAs per half K-step (64 cycles each: the same pipe time as the 2 NX bf16 ones)
+            const char* st = smem + (kt % NS) * STAGE;
+            // first half: k 0..63 of the step = the P fragments (both slots of each operand), k-blocks 0 | 1 -> op_sel 0
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                const int i = m / NTW, j = m % NTW;
+                acc[i][j] = mfma_mx<0>(pw[0][j], pw[1][j], pa[0][i], pa[1][i], acc[i][j], scw[j], sca[i]);
+#pragma unroll
+                for (int f = 2 * m; f < 2 * m + 2; ++f)
+                    if (f < NF) frag_store(qa, qw, f, *frag_ptr(st, 2, f));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            static_assert(!FP8 || NF <= 2 * NX, "two fragment reads per scaled MFMA cover the Q set");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (more) {
+                wait_vmcnt<0>();  // NS == 2: tile kt+1 (and its scale piece) landed
+                __builtin_amdgcn_s_barrier();
+            }
+            const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
+            const char* stn = smem + ((kt + 1) % NS) * STAGE;
+            const bf16_t* a_k2 = A + (kt + NS) * BK;
+            const bf16_t* w_k2 = W + (kt + NS) * BK;
+            unsigned nsa[MT], nsw[NTW];
+            // second half: k 64..127 = the Q fragments, k-blocks 2 | 3 -> op_sel 2; two DMA pieces per MFMA slot first, then the next
+            // step's P fragments and scale words
+            constexpr int ND = AJ + WJ;                  // tile pieces of this wave (+ one scale piece on waves 0 / 1)
+            constexpr int DS = (ND + 1 + 1) / 2;         // MFMA slots that carry DMA
+            static_assert(!FP8 || DS < NX, "DMA pieces must leave MFMA slots for the fragment reads");
+            constexpr int RS = NX - DS > 0 ? NX - DS : 1;  // (only meaningful for the FP8 instantiations)
+            constexpr int PER = (NF + RS - 1) / RS;
+#pragma unroll
+            for (int m = 0; m < NX; ++m) {
+                const int i = m / NTW, j = m % NTW;
+                acc[i][j] = mfma_mx<2>(qw[0][j], qw[1][j], qa[0][i], qa[1][i], acc[i][j], scw[j], sca[i]);
+                if (dma) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int pc = 2 * m + q;
+                        if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
+                        else if (pc < ND) glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
+                        else if (pc == ND) issue_scales(kt + NS);
+                    }
+                }
+                if (more && m >= DS) {
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) {
+                        const int f = (m - DS) * PER + q;
+                        if (f < NF) frag_store(pa, pw, f, *frag_ptr(stn, 0, f));
+                    }
+                    if (m == NX - 1) {
+                        const char* sc = stn + A_BYTES + W_BYTES;
+#pragma unroll
+                        for (int i2 = 0; i2 < MT; ++i2) nsa[i2] = *reinterpret_cast<const unsigned*>(sc + (wm * (MT * 32) + i2 * 32 + frow) * 4) >> (8 * fhalf);
+#pragma unroll
+                        for (int j2 = 0; j2 < NTW; ++j2) nsw[j2] = *reinterpret_cast<const unsigned*>(sc + 1024 + (wn * (NTW * 32) + j2 * 32 + frow) * 4) >> (8 * fhalf);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+#pragma unroll
+                for (int i2 = 0; i2 < MT; ++i2) sca[i2] = nsa[i2];
+#pragma unroll
+                for (int j2 = 0; j2 < NTW; ++j2) scw[j2] = nsw[j2];
+            }
+        };
         {
             using T = std::integral_constant<bool, true>;
             using F = std::integral_constant<bool, false>;
             int kt = 0;
+            if constexpr (FP8) {
+                for (; kt + NS < nk; ++kt) kstep_mx(kt, T{}, T{});
+                for (; kt + 1 < nk; ++kt) kstep_mx(kt, T{}, F{});
+                kstep_mx(kt, F{}, F{});
+            } else {
             for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{});     // steady state: branch-free
             for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{});       // the last NS-1 K steps but one: nothing left to prefetch
             kstep(kt, F{}, F{});                                 // last K step
+            }
         }
         if (probe) {
             g_clk_probe[0] = clock64() - c0;
@@ -893,6 +1014,73 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
                           (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2],
                           (double)h[5], (double)h[3], (double)h[4]);
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ MXFP8 entry
+bool gemm_mx_supported(int M, int N, int K, int mode) {
+    return (mode == 0 || mode == 2 || mode == 3 || mode == 4) && M >= 1 && K % 128 == 0 && N % 256 == 0 && K >= 256;
+}
+
+template <int MODE>
+static void launch_mx_mode(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int Kh,
+                           const GemmEpilogue& ep, int tiles_n, int nwg) {
+    static int group_m = -1, pers = 1;
+    if (group_m < 0) {
+        pers = env_int("ACE355_GEMM_PERS", 1);
+        group_m = env_int("ACE355_GEMM_GROUPM", 4);
+    }
+    const int tiles_m = nwg / tiles_n;
+    int xcd_m = 8;
+    double best = 1e30;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+        const int xn = 8 / xm;
+        if (xm > tiles_m || xn > tiles_n) continue;
+        const double cost = (double)xn * M + (double)xm * N;
+        if (cost < best) { best = cost; xcd_m = xm; }
+    }
+    const int xcd_n = 8 / xcd_m;
+    const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
+    // (the persistent residual variant does not fit 256 VGPRs with the scale registers: 60 spilled; its launches are one round anyway)
+    if (pers && region > 32 && MODE != 2)
+        hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1, 2, 1>), dim3(8 * 32), dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, Kh, ep, tiles_n, nwg,
+                           group_m, xcd_m);
+    else
+        hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 0, 2, 1>), dim3(8 * region), dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, Kh, ep, tiles_n,
+                           nwg, group_m, xcd_m);
+}
+
+int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8_t* Wq, const uint32_t* sw, int sw_ld, void* C, int ldc,
+                   int M, int N, int K, const GemmEpilogue& ep_in, hipStream_t s) {
+    ACE_CHECK(Aq && Wq && sa && sw && C, "gemm_mx: null pointer");
+    ACE_CHECK(gemm_mx_supported(M, N, K, ep_in.mode), "gemm_mx: unsupported shape / mode (K % 128, N % 256, modes 0 2 3 4)");
+    ACE_CHECK(sa_ld >= ((M + 191) / 192) * 192 + 64 && sw_ld >= N && (sa_ld % 4) == 0 && (sw_ld % 4) == 0, "gemm_mx: scale arrays must be padded (mx_rows_pad)");
+    ACE_CHECK((long)M * K < (1L << 32) && (long)N * K < (1L << 32), "gemm_mx: operands must each be smaller than 4 GB");
+    GemmEpilogue ep = ep_in;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int per16 = (ep.mode == 0 || ep.mode == 3 || ep.mode == 4) ? 8 : 4;
+    ep.wide_ok = al16(C) && (ldc % per16) == 0 && al16(ep.bias) && al16(ep.g1) && al16(ep.g2) && al16(ep.cvec) && (ep.g2_stride % 4) == 0;
+    ACE_CHECK(ep.wide_ok, "gemm_mx: output / vectors must be 16-byte aligned");
+    ACE_CHECK(al16(Aq) && al16(Wq) && al16(sa) && al16(sw), "gemm_mx: operands must be 16-byte aligned");
+    ep.clk_probe = 0;
+    ep.ksplit = 1;
+    ep.mx_sa = sa; ep.mx_sw = sw; ep.mx_sa_ld = sa_ld; ep.mx_sw_ld = sw_ld;
+    if (ep.mode == 4)
+        ACE_CHECK(ep.hn_wq && ep.hn_wk && (!ep.hn_cos == !ep.hn_sin) && ep.rows_per_seq > 0 && ep.hn_q_cols % 256 == 0 && ep.hn_qk_cols % 256 == 0 &&
+                  ep.hn_qk_cols <= N && !ep.bias, "gemm_mx: head epilogue arguments");
+    const int tiles_n = N / 256, tiles_m = (M + 191) / 192, nwg = tiles_m * tiles_n;
+    // the kernel addresses rows in units of 2 bytes (its bf16 heritage): an fp8 row of K bytes is K / 2 such units, a K step of 128
+    // fp8 elements is its 64-unit step
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(Aq);
+    const bf16_t* W = reinterpret_cast<const bf16_t*>(Wq);
+    const int Kh = K / 2;
+    switch (ep.mode) {
+        case 0: launch_mx_mode<0>(s, A, Kh, W, Kh, C, ldc, M, N, Kh, ep, tiles_n, nwg); break;
+        case 2: launch_mx_mode<2>(s, A, Kh, W, Kh, C, ldc, M, N, Kh, ep, tiles_n, nwg); break;
+        case 3: launch_mx_mode<3>(s, A, Kh, W, Kh, C, ldc, M, N, Kh, ep, tiles_n, nwg); break;
+        default: launch_mx_mode<4>(s, A, Kh, W, Kh, C, ldc, M, N, Kh, ep, tiles_n, nwg); break;
+    }
+    ACE_LAUNCH_CHECK();
     return 0;
 }
 

@@ -172,6 +172,16 @@ class NativeDit:
             return out, list(ms)
         return out
 
+    # ------------------------------------------------------------------ precision of the four big projections
+    def set_precision(self, precision: str) -> None:
+        """"bf16" (default, the reference GPU path's dtype) or "mxfp8" (OCP MXFP8 operands on the scaled fp8 MFMA; BASELINE
+        configs[4]; the reference's knob is torchao `fp8_weight_only` / `w8a8_dynamic`, init_service_loader.py:89-113)."""
+        code = {"bf16": 0, "mxfp8": 1}.get(precision)
+        if code is None:
+            raise ValueError(f"unknown precision '{precision}' (bf16 | mxfp8)")
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_set_precision(self._h, code), "dit_set_precision")
+
     # ------------------------------------------------------------------ hipGraph replay of the sampler loop
     def set_graph(self, enable: bool) -> None:
         """Capture the sampler's launch sequence once per (shapes, schedule, knobs, slots, stream) and replay it afterwards."""

@@ -79,6 +79,7 @@ SIGNATURES = {
     "ace355_dit_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(SampleParamsC),
                                     C.c_void_p, C.POINTER(C.c_float), C.c_void_p]),
     "ace355_dit_set_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ace355_dit_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ace355_dit_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
@@ -125,6 +126,10 @@ SIGNATURES = {
                                             C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "ace355_gemm_bf16_headnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "ace355_mx_quantize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ace355_mx_rows_pad": (C.c_int, [C.c_int]),
+    "ace355_gemm_mxfp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_void_p]),
     "ace355_rmsnorm_mod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ace355_headnorm_rope": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int,

@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (smoke/debug only; result is not a benchmark)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE configs[4] precision: the four big projections on MXFP8 MFMA (not the headline metric, whose dtype is bf16)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch songs on EVERY rank; strong: --batch songs in total, split over the ranks (SURVEY 8e)")
     ap.add_argument("--dry-run", action="store_true",
@@ -109,6 +111,8 @@ def build_models(args, device):
     for name, shape, w in synth_weights_gpu(dcfg.weight_shapes(), dcfg.hidden_size, device, 1234, "dit"):
         sd[name] = w
     dit.load_state_dict(sd)
+    if getattr(args, "fp8", False):
+        dit.set_precision("mxfp8")
     vae = None
     vsd = {}
     if not args.no_vae:
@@ -406,7 +410,7 @@ def main():
                    + ("per GPU" if args.scaling == "weak" else "in total") + (", DiT + VAE decode)" if not args.no_vae else ", DiT-only)")),
         "value": value, "unit": "songs/s", "rtf": value * args.duration, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": "mxfp8 (four big projections) + bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"acestep-5Hz base DiT (24L/2048d, 1.575B params, random init) + Oobleck decoder, {args.duration:g} s audio "
                                f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward), L={L}, "
                                f"batch {B}/GPU" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),

@@ -128,6 +128,15 @@ typedef struct ace355_sample_params {
 int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev, int B, int T,
                       const ace355_sample_params* p, float* latents_out_dev, float* per_step_ms_host, void* stream);
 
+/* Compute precision of the four big projections of every layer (QKV, o_proj, gate|up, down).  BF16 (default) = the reference GPU
+ * path's dtype.  MXFP8 = BASELINE configs[4] "fp8 MFMA": OCP MXFP8 operands (e4m3, one E8M0 scale per 32 K elements; weights
+ * quantised once here, activations per launch) on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate, same epilogues; launches with
+ * fewer than 1536 token rows keep the bf16 kernels.  The reference's counterpart is torchao fp8 on the DiT Linears
+ * (handler/init_service_loader.py:89-113; absent here: parity unpinned, tolerance stated in DESIGN.md).  Call after finalize. */
+#define ACE355_PRECISION_BF16 0
+#define ACE355_PRECISION_MXFP8 1
+int ace355_dit_set_precision(ace355_dit* h, int precision);
+
 /* hipGraph replay of the sampling loop: with enable != 0, ace355_dit_sample captures its launch
  * sequence (steps x ~360 kernels) into a graph on first use and replays it for every later call with the same shapes, schedule,
  * knobs, slot layout and stream; any change re-captures.  Results are identical to the eager path (same kernels, same order).
@@ -331,6 +340,16 @@ int ace355_gemm_bf16_residual(const void* A_dev, const void* W_dev, float* H_dev
 int ace355_gemm_bf16_headnorm(const void* A_dev, const void* W_dev, void* out_bf16_dev, int M, int N, int K, int q_cols,
                               int qk_cols, const float* wq_dev, const float* wk_dev, float eps, int rope, int rows_per_seq,
                               float theta, void* stream);
+/* OCP MXFP8 (gfx950 v_mfma_scale_f32_32x32x64_f8f6f4; BASELINE configs[4] "fp8 MFMA"; the reference's counterpart is torchao
+ * fp8 on the DiT Linears, handler/init_service_loader.py:89-113).  mx_quantize: x bf16 [M,K] -> q fp8 e4m3 [M,K] + E8M0 block scales
+ * (one per 32 consecutive K elements of a row) as uint32 [K/128][rows_pad]: byte b of word [kt][row] = block 4 kt + b;
+ * rows_pad = ace355_mx_rows_pad(M).  gemm_mxfp8 (test hook): quantises both bf16 operands and runs the MX GEMM with the bf16 kernel's
+ * epilogues: mode 0 out bf16 [M,N]; mode 2 H f32 [M,N] += gate * (A W^T) as ace355_gemm_bf16_fused mode 0; mode 3 SwiGLU -> bf16 [M,N/2].
+ * K % 128 == 0, N % 256 == 0. */
+int ace355_mx_quantize(const void* x_bf16_dev, int M, int K, void* q_out_dev, uint32_t* scales_out_dev, int rows_pad, void* stream);
+int ace355_mx_rows_pad(int rows);
+int ace355_gemm_mxfp8(const void* A_bf16_dev, const void* W_bf16_dev, void* out_dev, int M, int N, int K, int mode, const float* g1_dev,
+                      const float* g2_dev, int g2_stride, int rows_per_seq, void* stream);
 /* y = bf16( rmsnorm(x; w, eps) * (1 + sc) + sh ), sc[n] = sc1[n] + sc2[(m / rows_per_seq)*stride + n] (NULL -> no modulation). */
 int ace355_rmsnorm_mod(const float* x_dev, const float* w_dev, void* y_bf16_dev, int M, int D, float eps,
                        const float* sc1, const float* sc2, const float* sh1, const float* sh2, int stride,

@@ -1,0 +1,134 @@
+"""GPU: the MXFP8 path (BASELINE configs[4] "fp8 MFMA"): quantiser bit-exact against the OCP MX restatement in oracle/mx.py,
+the MX GEMM (v_mfma_scale_f32_32x32x64_f8f6f4) against an fp32 matmul of the DEQUANTISED operands (isolates the kernel: the products are
+exact, only the fp32 summation order differs), and the quantisation error itself against the bf16 operands, stated not hidden."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def lib(gpu_device):
+    from ace355 import native
+    return native.lib()
+
+
+def _chk(rc):
+    from ace355 import native
+    native.check(rc, "test")
+    torch.cuda.synchronize()
+
+
+def _p(t):
+    from ace355 import native
+    return native.ptr(t)
+
+
+@pytest.mark.parametrize("M,K", [(5, 128), (300, 2048), (64, 6144), (1000, 384)])
+def test_mx_quantizer_bit_exact(lib, gpu_device, M, K):
+    from oracle import mx as o_mx
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g) * torch.exp(2.0 * torch.randn(M, 1, generator=g))).to(torch.bfloat16)
+    x[0, :32] = 0                      # an all-zero block
+    x[min(1, M - 1), 40] = 3.0e4       # a block whose max saturates neighbours' dynamic range
+    if M > 2:
+        x[2, 64:96] = 448.0 * 2.0 ** -3   # exactly representable edge values
+    rows_pad = int(lib.ace355_mx_rows_pad(M))
+    q = torch.zeros(M, K, dtype=torch.uint8, device=gpu_device)
+    sc = torch.zeros(K // 128, rows_pad, dtype=torch.int32, device=gpu_device)
+    _chk(lib.ace355_mx_quantize(_p(x.to(gpu_device)), M, K, _p(q), _p(sc), rows_pad, None))
+    q_ref, sb_ref = o_mx.mx_quantize(x)
+    assert torch.equal(q.cpu(), q_ref.view(torch.uint8))
+    want = o_mx.pack_scales(sb_ref, rows_pad)
+    got = sc.cpu().to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(got[:, :M], want[:, :M])
+    # the round trip is the expected MX error: relative 2^-4 per element at worst, ~2.5e-2 rms
+    r = _rel(o_mx.mx_dequantize(q_ref, sb_ref), x)
+    assert r < 6e-2, r
+
+
+@pytest.mark.parametrize("M,N,K,mode", [
+    (6000, 4096, 2048, 0), (6000, 2048, 6144, 2), (6000, 2048, 2048, 2), (6000, 12288, 2048, 3),   # the four big projections at the metric
+    (192, 256, 256, 0), (1000, 512, 384, 0), (375, 2048, 2048, 2)])
+def test_gemm_mxfp8_vs_dequantised_reference(lib, gpu_device, M, N, K, mode):
+    from oracle import mx as o_mx
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    A = (torch.randn(M, K, generator=g) * torch.exp(0.5 * torch.randn(M, 1, generator=g))).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.02 + torch.arange(N)[:, None] * 1e-5).to(torch.bfloat16)   # asymmetric (transpose-detecting)
+    Ad, Wd = A.to(gpu_device), W.to(gpu_device)
+    qa, sa = o_mx.mx_quantize(A)
+    qw, sw = o_mx.mx_quantize(W)
+    Adq, Wdq = o_mx.mx_dequantize(qa, sa).to(gpu_device), o_mx.mx_dequantize(qw, sw).to(gpu_device)
+    prod = Adq @ Wdq.t()                               # what the hardware computes, up to fp32 summation order
+    prod_bf16 = Ad.float() @ Wd.float().t()            # what the bf16 GEMM computes
+    if mode == 0:
+        out = torch.empty(M, N, device=gpu_device, dtype=torch.bfloat16)
+        _chk(lib.ace355_gemm_mxfp8(_p(Ad), _p(Wd), _p(out), M, N, K, 0, None, None, 0, 0, None))
+        r, rq = _rel(out, prod), _rel(prod, prod_bf16)
+        assert r < 4e-3, r                             # bf16 output rounding only
+    elif mode == 2:
+        rows = 375
+        H = torch.randn(M, N, generator=g).to(gpu_device)
+        g1 = torch.randn(N, generator=g).to(gpu_device)
+        g2 = torch.randn((M + rows - 1) // rows, N, generator=g).to(gpu_device)
+        seq = torch.arange(M, device=gpu_device) // rows
+        out = H.clone()
+        _chk(lib.ace355_gemm_mxfp8(_p(Ad), _p(Wd), _p(out), M, N, K, 2, _p(g1), _p(g2), N, rows, None))
+        r, rq = _rel(out - H, (g1[None] + g2[seq]) * prod), _rel(prod, prod_bf16)
+        assert r < 3e-5, r                             # exact products; fp32 summation order vs the library matmul (measured 1.4e-5 at K = 6144)
+    else:
+        Fh = N // 2
+        Wg, Wu = W[:Fh], W[Fh:]
+        Wp = torch.stack([Wg.view(Fh // 32, 32, K), Wu.view(Fh // 32, 32, K)], dim=1).reshape(N, K).contiguous()   # [32 gate | 32 up]
+        qwp, swp = o_mx.mx_quantize(Wp)
+        Wpd = o_mx.mx_dequantize(qwp, swp).to(gpu_device).view(Fh // 32, 2, 32, K)
+        gate, up = Adq @ Wpd[:, 0].reshape(Fh, K).t(), Adq @ Wpd[:, 1].reshape(Fh, K).t()
+        ref = F.silu(gate) * up
+        out = torch.empty(M, Fh, device=gpu_device, dtype=torch.bfloat16)
+        _chk(lib.ace355_gemm_mxfp8(_p(Ad), _p(Wp.to(gpu_device)), _p(out), M, N, K, 3, None, None, 0, 0, None))
+        r = _rel(out, ref)
+        rq = _rel(ref, F.silu(Ad.float() @ Wg.to(gpu_device).float().t()) * (Ad.float() @ Wu.to(gpu_device).float().t()))
+        assert r < 4e-3, r
+    print(f"MX GEMM M={M} N={N} K={K} mode={mode}: kernel vs dequantised reference {r:.2e}; MXFP8 quantisation error of the product {rq:.2e}")
+    assert rq < 6e-2, rq
+
+
+def test_mxfp8_forward_and_sampler_at_the_metric_shape(gpu_device, golden_dir, full_dit_seed4):
+    """BASELINE configs[4] precision at the metric shape: the four big projections of all 24 layers on MXFP8 MFMA, against the SAME
+    reference vectors as the bf16 path (G11 forward N = 16, G12 batch-8 CFG + APG sampler).  Stated tolerance of this mode:
+    velocity / latents relative L2 <= 8e-2 vs the reference's fp32 CPU path (measured: see the printed values; the bf16 path measures
+    5.8e-3 / 4.0e-3).  torchao, the reference's fp8 backend, is absent: nothing else can pin this mode."""
+    import numpy as np
+    from ace355.dit import generate_latents, prepare_noise
+    dit, cfg, null, wsum = full_dit_seed4
+    G = np.load(f"{golden_dir}/g11_metric_forward.npz")
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    x8 = prepare_noise((B, T, 64), [1000 + i for i in range(B)])
+    g = torch.Generator().manual_seed(45)
+    ctx1 = torch.cat([0.5 * torch.randn(1, T, 64, generator=g), torch.ones(1, T, 64)], -1)
+    dit.set_condition(0, enc[0])
+    dit.set_condition(1, null.reshape(1, -1), L=enc.shape[1])
+    t = [float(G["t"])] * (2 * B)
+    args = (torch.cat([x8, x8]), ctx1.expand(2 * B, -1, -1).contiguous(), t, t, [0] * B + [1] * B)
+    v_bf16 = dit.forward(*args)
+    dit.set_precision("mxfp8")
+    try:
+        v = dit.forward(*args)
+        ref = torch.from_numpy(G["v"])
+        r, rb = _rel(v.cpu(), ref), _rel(v.cpu(), v_bf16.cpu())
+        G12 = np.load(f"{golden_dir}/g12_metric_sampler.npz")
+        out = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G12["seeds"].tolist(),
+                               infer_steps=int(G12["steps"]), diffusion_guidance_sale=float(G12["guidance"]))["target_latents"]
+        rs = _rel(out.cpu(), torch.from_numpy(G12["out"]))
+    finally:
+        dit.set_precision("bf16")
+    print(f"MXFP8 DiT at the metric shape: forward rel L2 vs reference fp32 {r:.3e} (vs the bf16 path {rb:.3e}); 3-step CFG sampler {rs:.3e}")
+    assert torch.isfinite(v).all() and not torch.equal(v, v_bf16)   # the mode is really on
+    assert r < 8e-2 and rs < 8e-2, (r, rs)
+    assert _rel(dit.forward(*args).cpu(), v_bf16.cpu()) == 0.0     # and really off again

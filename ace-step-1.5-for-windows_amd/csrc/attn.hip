@@ -581,6 +581,42 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
         const bf16_t* vm = a.vmean + ((long)n * a.Hkv + hkv) * 128 + 8 * half;
 #pragma unroll
         for (int c = 0; c < 8; ++c) *reinterpret_cast<uint4*>(op + c * 16) = *reinterpret_cast<const uint4*>(vm + c * 16);
+    } else if (a.out_q) {
+        // MXFP8 output: block dt of this head = columns 32 dt .. +31 = this lane's 16 values (g = 0, 1) + its partner's (lane ^ 32);
+        // the values quantised are the bf16-rounded outputs, so this equals attention -> mx_quant_kernel bit for bit.  Every lane
+        // runs the shuffles; rows past the end just do not store.
+        const long grow = (long)n * a.Sq + qrow;
+        uint8_t* oq = a.out_q + grow * (a.Hq * 128) + h * 128 + 8 * half;
+        uint32_t word = 0;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float f[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const uint32_t pk = pack_bf2(o[dt][e] * inv, o[dt][e + 1] * inv);
+                f[e] = bf_lo(pk), f[e + 1] = bf_hi(pk);
+                amax = fmaxf(amax, fmaxf(fabsf(f[e]), fabsf(f[e + 1])));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            int sbe = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+            sbe = sbe < 0 ? 0 : (sbe > 254 ? 254 : sbe);
+            const float sinv = __uint_as_float((uint32_t)(254 - sbe) << 23);
+            word |= (uint32_t)sbe << (8 * dt);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint32_t w[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float a0 = fminf(fmaxf(f[8 * g + 4 * e + 0] * sinv, -448.f), 448.f), a1 = fminf(fmaxf(f[8 * g + 4 * e + 1] * sinv, -448.f), 448.f);
+                    const float a2 = fminf(fmaxf(f[8 * g + 4 * e + 2] * sinv, -448.f), 448.f), a3 = fminf(fmaxf(f[8 * g + 4 * e + 3] * sinv, -448.f), 448.f);
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+                    w[e] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+                }
+                if (qrow < a.Sq) *reinterpret_cast<uint2*>(oq + dt * 32 + 16 * g) = make_uint2(w[0], w[1]);
+            }
+        }
+        if (qrow < a.Sq && half == 0) a.out_scales[(long)h * a.out_pad + grow] = word;
     } else if (qrow < a.Sq) {
         bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 8 * half;
 #pragma unroll
@@ -611,6 +647,19 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
 
 }  // namespace
 
+static int gqa_nwh(const AttnArgs& a) {  // which attn_gqa_kernel instantiation launch_attention picks (0: attn3_kernel)
+    static int gqa_env = -2;
+    if (gqa_env == -2) { const char* e = getenv("ACE355_ATTN_GQA"); gqa_env = e ? atoi(e) : -1; }
+    if (a.Hq != 2 * a.Hkv || gqa_env == 0) return 0;
+    auto units = [&](int nwh) { return (long)a.N * a.Hkv * ((a.Sq + 32 * nwh - 1) / (32 * nwh)); };
+    if (gqa_env == 3 || gqa_env == 4 || gqa_env == 6) return gqa_env;
+    if (units(6) >= 224) return 6;
+    if (units(4) >= 224) return 4;
+    if (units(3) >= 128) return 3;
+    return 0;
+}
+bool attention_mx_out_ok(const AttnArgs& a) { return gqa_nwh(a) != 0 && !a.kv_len; }
+
 int launch_attention(const AttnArgs& a, hipStream_t s) {
     ACE_CHECK(a.N > 0 && a.Sq > 0 && a.Skv > 0, "attention: empty problem");
     ACE_CHECK(!a.use_tab || a.N <= 64, "attention: at most 64 sequences with pointer tables");
@@ -630,15 +679,10 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     // GQA-shared kernel (Hq = 2 Hkv): one workgroup per (sequence, KV head, 32*NWH query rows), both q heads off one K / V^T
     // tile.  NWH = the largest of {6, 4, 3} whose grid still gives every CU a workgroup (ACE355_ATTN_GQA=0: attn3_kernel only,
     // =3/4/6 pins NWH); attn3_kernel keeps the small problems (fewer than 128 such workgroups) and other group sizes.
-    static int gqa_env = -2;
-    if (gqa_env == -2) { const char* e = getenv("ACE355_ATTN_GQA"); gqa_env = e ? atoi(e) : -1; }
-    if (a.Hq == 2 * a.Hkv && gqa_env != 0) {
+    ACE_CHECK(!a.out_q || (attention_mx_out_ok(a) && a.out_scales && a.o_seq_stride == (long)a.Sq * a.Hq * 128), "attention: MXFP8 output needs the GQA kernel and a dense [N*Sq, Hq*128] output");
+    {
         auto units = [&](int nwh) { return (long)a.N * a.Hkv * ((a.Sq + 32 * nwh - 1) / (32 * nwh)); };
-        int nwh = 0;
-        if (gqa_env == 3 || gqa_env == 4 || gqa_env == 6) nwh = gqa_env;
-        else if (units(6) >= 224) nwh = 6;
-        else if (units(4) >= 224) nwh = 4;
-        else if (units(3) >= 128) nwh = 3;
+        const int nwh = gqa_nwh(a);
         if (nwh) {
             AttnArgs ap = a;
             ap.clk_probe = clk;  // bit 0: probe + print; bits 1..3: ablations (attn_gqa_kernel)

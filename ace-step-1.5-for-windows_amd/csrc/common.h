@@ -109,6 +109,9 @@ struct GemmEpilogue {
     // that), the scales are uint32 [K / 128][rows_padded]: byte b of word [kt][r] = scale of row r, K elements 128 kt + 32 b .. + 31.
     const uint32_t* mx_sa; const uint32_t* mx_sw;
     int mx_sa_ld, mx_sw_ld;   // padded row counts of the two scale arrays (words per K step)
+    // mode 3 only: the SwiGLU output leaves as MXFP8 (the down projection's operand) instead of bf16: C = fp8 [M, N/2] (ldc in bytes),
+    // block scales to mxo_scales ([N/2 / 128][mxo_pad] words).  A wave's 32 output columns are exactly one block.
+    uint32_t* mxo_scales; int mxo_pad;
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
@@ -137,8 +140,13 @@ struct AttnArgs {
     // softmaxes to uniform over ALL Skv keys in the reference (the mask is finfo.min, not -inf): it gets vmean[n][hkv][:].
     const int* kv_len;      // device [N] or null
     const bf16_t* vmean;    // device [N][Hkv][128], required when kv_len is set
+    // MXFP8 output (the o_proj MX GEMM's operand, rows = n * Sq + s, Hq * 128 columns): out_q fp8 [N * Sq, Hq * 128], block scales
+    // [Hq][out_pad] words (a head's 128 columns = one K step, byte dt = columns 32 dt .. 32 dt + 31).  attn_gqa_kernel only
+    // (attention_mx_out_ok); `out` is not written then.
+    uint8_t* out_q; uint32_t* out_scales; int out_pad;
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
+bool attention_mx_out_ok(const AttnArgs& a);  // will launch_attention take the kernel that can write MXFP8?
 
 struct ModEntry {  // one modulated norm: g = w * (1 + sc1 + tproj[sc2_off..]), sft = sh1 + tproj[sh2_off..]
     const float *w, *sc1, *sh1;
@@ -146,6 +154,9 @@ struct ModEntry {  // one modulated norm: g = w * (1 + sc1 + tproj[sc2_off..]), 
 };
 int launch_rmsnorm_gs(const float* x, const float* g, const float* sft, bf16_t* y, int M, int D, float eps, long stride,
                       int rows_per_seq, hipStream_t s);
+// the same norm with an MXFP8 output (q fp8 [M, D] + block scales): bit-identical to launch_rmsnorm_gs -> launch_mx_quant
+int launch_rmsnorm_gs_mx(const float* x, const float* g, const float* sft, uint8_t* q, uint32_t* scales, int rows_pad, int M, int D,
+                         float eps, long stride, int rows_per_seq, hipStream_t s);
 int launch_mod_gs(const ModEntry* entries_dev, int n_entries, const float* tproj, long tp_stride, int rows, float* out, int D,
                   hipStream_t s);
 int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, float eps, const float* sc1,

@@ -88,6 +88,8 @@ struct ace355_dit {
     std::vector<void*> mx_allocs;      // weight copies
     uint8_t* xq = nullptr;             // activation operand of the current MX GEMM, fp8 [M, max(D, F)]
     uint32_t* xs = nullptr;            // its scales [max(D, F) / 128][xs_pad]
+    uint8_t* aq = nullptr;             // SwiGLU output as MXFP8 [M, F] (written by the gate|up GEMM's epilogue, read by the down GEMM)
+    uint32_t* as_ = nullptr;           // [F / 128][xs_pad]
     int xs_pad = 0;
     int mx_min_rows = 1536;            // below this many token rows the 192x256 tile does not fill the chip: bf16 kernels
 
@@ -215,10 +217,21 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
 
 // The same projection on the MXFP8 path: the bf16 activation operand is block-quantised (mx_quant_kernel) into the handle's scratch,
 // then the MX GEMM runs against the layer's fp8 weight copy with the bf16 kernel's epilogue.  Caller checked mx_usable().
+// A == nullptr: the producer already left the operand in the scratch as MXFP8 (launch_rmsnorm_gs_mx).
 int gemm_mx(ace355_dit* h, const bf16_t* A, int lda, const MxW& W, void* C, int ldc, int M, int N, int K, const GemmEpilogue& ep,
-            hipStream_t s) {
-    int rc = launch_mx_quant(A, lda, M, K, h->xq, h->xs, h->xs_pad, s);
-    if (rc) return rc;
+            hipStream_t s, const uint8_t* preq = nullptr, const uint32_t* pres = nullptr) {
+    if (A) {
+        int rc = launch_mx_quant(A, lda, M, K, h->xq, h->xs, h->xs_pad, s);
+        if (rc) return rc;
+    }
+    if (preq) {
+        EvScope ev(h, &h->gemm_ev, s);
+        if (h->profile) {
+            h->gemm_flops += 2.0 * M * N * K;
+            h->gemm_launches++;
+        }
+        return launch_gemm_mx(preq, pres, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, ep, s);
+    }
     EvScope ev(h, &h->gemm_ev, s);
     if (h->profile) {
         h->gemm_flops += 2.0 * M * N * K;
@@ -284,6 +297,9 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
         ALLOC(h->ws_allocs, h->xq, (size_t)M * KX + 256);
         ALLOC(h->ws_allocs, h->xs, (size_t)(KX / 128 + 1) * h->xs_pad);
         ACE_HIP(hipMemsetAsync(h->xs, 0, (size_t)(KX / 128 + 1) * h->xs_pad * sizeof(uint32_t), s));
+        ALLOC(h->ws_allocs, h->aq, (size_t)M * h->F + 256);
+        ALLOC(h->ws_allocs, h->as_, (size_t)(h->F / 128 + 1) * h->xs_pad);
+        ACE_HIP(hipMemsetAsync(h->as_, 0, (size_t)(h->F / 128 + 1) * h->xs_pad * sizeof(uint32_t), s));
     }
     h->ws_N = capN;
     h->ws_T = capT;
@@ -353,6 +369,11 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const LayerW& W = h->layers[li];
         const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
         // ---- self attention (base.py:499-511)
+        const bool mx_qkv = mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD) && D == 2048;
+        if (mx_qkv)  // the norm writes the MX GEMM's operand directly (fp8 + block scales): no bf16 xn round trip, no quantise pass
+            rc = launch_rmsnorm_gs_mx(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xq, h->xs, h->xs_pad,
+                                      M, D, eps, gs_stride, S, s);
+        else
         rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, M, D, eps,
                                gs_stride, S, s);
         if (rc) return rc;
@@ -360,11 +381,13 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};
         ep.hn_wq = W.qn_s, ep.hn_wk = W.kn_s, ep.hn_cos = h->rope_cos, ep.hn_sin = h->rope_sin;
         ep.hn_q_cols = QD, ep.hn_qk_cols = QD + KVD, ep.hn_eps = eps;
-        if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
+        if (mx_qkv) rc = gemm_mx(h, nullptr, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
+        else if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
         if (rc) return rc;
         rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
         if (rc) return rc;
+        bool ao_is_mx = false;
         {
             AttnArgs a{};
             a.q = h->qkv; a.q_seq_stride = (long)S * QKV; a.q_row_stride = QKV;
@@ -375,6 +398,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.N = N; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
             a.window = sliding ? h->cfg.sliding_window : -1;
             a.scale = scale;
+            if (mx_usable(h, W.mx_o, M, D, QD, 2) && attention_mx_out_ok(a)) {  // the o_proj MX GEMM's operand straight from the attention epilogue
+                a.out_q = h->xq; a.out_scales = h->xs; a.out_pad = h->xs_pad;
+                ao_is_mx = true;
+            }
             EvScope ev(h, &h->attn_ev, s);
             if (h->profile) {
                 double keys = (double)S;
@@ -389,7 +416,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             if (rc) return rc;
         }
         ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S, cconst ? cconst + (size_t)li * D : nullptr, Mc};
-        if (mx_usable(h, W.mx_o, M, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
+        if (ao_is_mx) rc = gemm_mx(h, nullptr, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
+        else if (mx_usable(h, W.mx_o, M, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
 
@@ -426,15 +454,25 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         }
 
         // ---- SwiGLU MLP (base.py:530-533)
+        const bool mx_gu = mx_usable(h, W.mx_gu, M, 2 * F, D, 3) && D == 2048;
+        if (mx_gu)
+            rc = launch_rmsnorm_gs_mx(h->h, h->gs + (size_t)(li * 2 + 1) * 2 * D, h->gs + (size_t)(li * 2 + 1) * 2 * D + D, h->xq, h->xs, h->xs_pad,
+                                      M, D, eps, gs_stride, S, s);
+        else
         rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 1) * 2 * D, h->gs + (size_t)(li * 2 + 1) * 2 * D + D, h->xn, M, D, eps,
                                gs_stride, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{3, nullptr, nullptr, nullptr, 0, 0};
-        if (mx_usable(h, W.mx_gu, M, 2 * F, D, 3)) rc = gemm_mx(h, h->xn, D, W.mx_gu, h->act, F, M, 2 * F, D, ep, s);
+        const bool mx_down = mx_usable(h, W.mx_down, M, D, F, 2);
+        const bool act_q = mx_gu && mx_down && F % 128 == 0;  // the SwiGLU epilogue writes the down projection's MXFP8 operand itself
+        if (act_q) { ep.mxo_scales = h->as_; ep.mxo_pad = h->xs_pad; }
+        if (mx_gu) rc = gemm_mx(h, nullptr, D, W.mx_gu, act_q ? (void*)h->aq : (void*)h->act, F, M, 2 * F, D, ep, s);
+        else if (mx_usable(h, W.mx_gu, M, 2 * F, D, 3)) rc = gemm_mx(h, h->xn, D, W.mx_gu, h->act, F, M, 2 * F, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, h->tproj + 5 * D, tstride, S};
-        if (mx_usable(h, W.mx_down, M, D, F, 2)) rc = gemm_mx(h, h->act, F, W.mx_down, h->h, D, M, D, F, ep, s);
+        if (act_q) rc = gemm_mx(h, nullptr, F, W.mx_down, h->h, D, M, D, F, ep, s, h->aq, h->as_);
+        else if (mx_down) rc = gemm_mx(h, h->act, F, W.mx_down, h->h, D, M, D, F, ep, s);
         else rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
         if (rc) return rc;
         if (h->tap_dst[li]) ACE_HIP(hipMemcpyAsync(h->tap_dst[li], h->h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -70,10 +70,24 @@ __global__ __launch_bounds__(256) void rmsnorm_mod_kernel(const float* __restric
 // sft = sh1 + sh2.  The five-vector form above reads 40 KB of (cached) vectors per 8 KB row and was bound by those loads
 // (19.4 us at M = 6000 against 14.1 us unmodulated); the DiT folds the vectors of all layers once per forward
 // (mod_gs_kernel) and streams x through this kernel: 8 consecutive columns per lane, one 16-byte store per 8 outputs.
-template <int NP, bool SHIFT>  // NP = D / 512 passes held in registers (0: generic two-pass); SHIFT: sft != nullptr
+// MXQ: the output leaves as OCP MXFP8 (the operand of an MX GEMM) instead of bf16: q fp8 e4m3 [M, D] at `y`, E8M0 block scales at
+// `mxs` ([D / 128][mx_pad] words, GemmEpilogue::mx_sa layout).  The value that is quantised is the BF16-ROUNDED norm output, so the
+// fused kernel is bit-identical to rmsnorm -> mx_quant_kernel.  A 32-column block = 4 neighbouring lanes of a pass, a scale word = 16.
+__device__ __forceinline__ int mx_block_exp(float amax) {
+    int sb = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+    return sb < 0 ? 0 : (sb > 254 ? 254 : sb);
+}
+__device__ __forceinline__ uint32_t mx_pack4(float a0, float a1, float a2, float a3, float inv) {
+    a0 = fminf(fmaxf(a0 * inv, -448.f), 448.f); a1 = fminf(fmaxf(a1 * inv, -448.f), 448.f);
+    a2 = fminf(fmaxf(a2 * inv, -448.f), 448.f); a3 = fminf(fmaxf(a3 * inv, -448.f), 448.f);
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+}
+template <int NP, bool SHIFT, bool MXQ = false>  // NP = D / 512 passes held in registers (0: generic two-pass); SHIFT: sft != nullptr
 __global__ __launch_bounds__(256) void rmsnorm_gs_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ sft, bf16_t* __restrict__ y, int M, int D,
-                                                         float eps, long stride, int rows_per_seq) {
+                                                         float eps, long stride, int rows_per_seq, uint32_t* __restrict__ mxs = nullptr,
+                                                         int mx_pad = 0) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -89,7 +103,25 @@ __global__ __launch_bounds__(256) void rmsnorm_gs_kernel(const float* __restrict
         if (SHIFT) {
             o[0] += sa[0], o[1] += sa[1], o[2] += sa[2], o[3] += sa[3], o[4] += sb[0], o[5] += sb[1], o[6] += sb[2], o[7] += sb[3];
         }
-        *reinterpret_cast<uint4*>(yr + c) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+        const uint4 pk = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+        if constexpr (!MXQ) {
+            *reinterpret_cast<uint4*>(yr + c) = pk;
+        } else {
+            const float v[8] = {bf_lo(pk.x), bf_hi(pk.x), bf_lo(pk.y), bf_hi(pk.y), bf_lo(pk.z), bf_hi(pk.z), bf_lo(pk.w), bf_hi(pk.w)};
+            float amax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+            amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+            const int sbe = mx_block_exp(amax);
+            const float inv = __uint_as_float((uint32_t)(254 - sbe) << 23);
+            uint8_t* qr = reinterpret_cast<uint8_t*>(y) + (long)row * D + c;
+            *reinterpret_cast<uint2*>(qr) = make_uint2(mx_pack4(v[0], v[1], v[2], v[3], inv), mx_pack4(v[4], v[5], v[6], v[7], inv));
+            uint32_t wv = (uint32_t)sbe << (8 * ((lane >> 2) & 3));  // lanes 4b..4b+3 = block b of the 16-lane (128-column) K step
+            wv |= __shfl_xor(wv, 4, 64);
+            wv |= __shfl_xor(wv, 8, 64);
+            if ((lane & 15) == 0) mxs[(long)(c >> 7) * mx_pad + row] = wv;
+        }
     };
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     if (NP > 0) {
@@ -693,6 +725,17 @@ int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, 
     if (D == 2048) hipLaunchKernelGGL(rmsnorm_mod_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     else if (D == 256) hipLaunchKernelGGL(rmsnorm_mod_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
     else hipLaunchKernelGGL(rmsnorm_mod_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, s, x, w, y, M, D, eps, sc1, sc2, sh1, sh2, stride, rps);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_rmsnorm_gs_mx(const float* x, const float* g, const float* sft, uint8_t* q, uint32_t* scales, int rows_pad, int M, int D,
+                         float eps, long stride, int rows_per_seq, hipStream_t s) {
+    ACE_CHECK(D == 2048 && stride % 4 == 0 && rows_pad >= M, "rmsnorm_gs_mx: D = 2048 only");
+    const int rps = rows_per_seq > 0 ? rows_per_seq : 1;
+    const dim3 grid((M + 3) / 4);
+    if (sft) hipLaunchKernelGGL((rmsnorm_gs_kernel<4, true, true>), grid, dim3(256), 0, s, x, g, sft, reinterpret_cast<bf16_t*>(q), M, D, eps, stride, rps, scales, rows_pad);
+    else hipLaunchKernelGGL((rmsnorm_gs_kernel<4, false, true>), grid, dim3(256), 0, s, x, g, sft, reinterpret_cast<bf16_t*>(q), M, D, eps, stride, rps, scales, rows_pad);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -189,6 +189,38 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     if (ROWS_FULL || m < M) *reinterpret_cast<u32x4e*>(out + (long)m * ldc) = v[u];
                 }
             }
+        } else if (MODE == 3 && ep.mxo_scales) {
+            // SwiGLU result straight to MXFP8: the 4 lanes of a staged row hold the wave's 32 output columns = one block
+            uint8_t* outq = reinterpret_cast<uint8_t*>(Cv) + (nw0 >> 1) + slot * 8;
+            const int kblk = (nw0 >> 1) >> 5;
+            uint8_t* scb = reinterpret_cast<uint8_t*>(ep.mxo_scales) + (long)(kblk >> 2) * ep.mxo_pad * 4 + (kblk & 3);
+#pragma unroll
+            for (int t = 0; t < NTI; ++t) {
+                const int row = t * RPI + rsub;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + stage_off<RB>(row, slot));
+                const int m = mw0 + row;
+                const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                int sbe = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 8;
+                sbe = sbe < 0 ? 0 : (sbe > 254 ? 254 : sbe);
+                const float inv = __uint_as_float((uint32_t)(254 - sbe) << 23);
+                uint32_t w[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float a0 = fminf(fmaxf(f[4 * e + 0] * inv, -448.f), 448.f), a1 = fminf(fmaxf(f[4 * e + 1] * inv, -448.f), 448.f);
+                    const float a2 = fminf(fmaxf(f[4 * e + 2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(f[4 * e + 3] * inv, -448.f), 448.f);
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+                    w[e] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+                }
+                if (ROWS_FULL || m < M) {
+                    *reinterpret_cast<uint2*>(outq + (long)m * ldc) = make_uint2(w[0], w[1]);
+                    if (slot == 0) scb[(long)m * 4] = (uint8_t)sbe;
+                }
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < NTI; ++t) {

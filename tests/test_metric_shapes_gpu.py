@@ -126,3 +126,50 @@ def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, fu
     assert r2 < 1.5e-2 and r16 < 1.5e-2 and r23 < 1.2e-2, (r2, r16, r23)  # measured 5.9e-3, 5.9e-3, 4.2e-3
     assert rx < 2e-3, rx  # measured 0.0: the same arithmetic per wave whatever the block / tile shape
     assert _rel(v16[2], v16[3]) > 0.3  # other seeds really are other songs
+
+
+def test_240s_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
+    """G14 / BASELINE configs[3] shape (240 s, T = 6000, S = 3000; each of the 8 GPUs runs 4 such songs x 60 steps): one CFG pair through
+    the native forward vs the imported reference."""
+    G = np.load(f"{golden_dir}/g14_240s_forward.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    assert abs(wsum - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    T = 6000
+    x1, ctx1 = _inputs(1, T, seed0=4000, ctx_seed=47)
+    assert _close(float(x1.double().abs().sum()), float(G["x_sum"])) and _close(float(ctx1.double().abs().sum()), float(G["ctx_sum"]))
+    dit.set_condition(0, enc[0])
+    dit.set_condition(1, null.reshape(1, -1), L=enc.shape[1])
+    t = float(G["t"])
+    v = dit.forward(torch.cat([x1, x1]), ctx1.expand(2, -1, -1).contiguous(), [t, t], [t, t], [0, 1])
+    r = _rel(v, torch.from_numpy(G["v"]))
+    print(f"240 s forward (N=2, T=6000): rel L2 vs reference fp32 = {r:.3e}")
+    assert torch.isfinite(v).all() and r < 1.5e-2, r
+
+
+@pytest.mark.parametrize("name,T,B,steps,precision", [
+    ("configs[3] per-GPU share: 240 s, batch 4", 6000, 4, 2, "bf16"),
+    ("configs[4] per-GPU shape: 600 s, fp8 MFMA", 15000, 2, 2, "mxfp8")])
+def test_long_config_sampler_properties(gpu_device, golden_dir, full_dit_seed4, name, T, B, steps, precision):
+    """The two 8-GPU configurations of BASELINE.json at their per-GPU shapes (the fp32 oracle would need minutes per step there):
+    size-independent properties of the sampler - finite, deterministic (same request twice is bit-identical), songs independent
+    (item 1 of the batch equals the same seed run alone up to fp32 summation order across tile shapes), seeds matter."""
+    from ace355.dit import generate_latents
+    dit, cfg, null, wsum = full_dit_seed4
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    _, ctx1 = _inputs(1, T, seed0=5000, ctx_seed=48)
+    kw = dict(infer_steps=steps, diffusion_guidance_sale=7.0)
+    seeds = [7000 + i for i in range(B)]
+    dit.set_precision(precision)
+    try:
+        a = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=seeds, **kw)["target_latents"]
+        b = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=seeds, **kw)["target_latents"]
+        solo = generate_latents(dit, null, enc, ctx1, seed=[seeds[1]], **kw)["target_latents"]
+    finally:
+        dit.set_precision("bf16")
+    assert torch.isfinite(a).all() and float(a.std()) > 0.1
+    assert torch.equal(a, b), "same request twice must be bit-identical"
+    r = _rel(a[1:2], solo)
+    print(f"{name} ({precision}): item 1 of {B} vs alone, rel L2 {r:.3e}")
+    assert r < (2e-2 if precision == "mxfp8" else 5e-3), r   # MXFP8: the quantiser sees the same rows either way; only tile order differs
+    assert _rel(a[0:1], a[1:2]) > 0.5

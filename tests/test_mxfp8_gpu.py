@@ -128,7 +128,21 @@ def test_mxfp8_forward_and_sampler_at_the_metric_shape(gpu_device, golden_dir, f
         rs = _rel(out.cpu(), torch.from_numpy(G12["out"]))
     finally:
         dit.set_precision("bf16")
-    print(f"MXFP8 DiT at the metric shape: forward rel L2 vs reference fp32 {r:.3e} (vs the bf16 path {rb:.3e}); 3-step CFG sampler {rs:.3e}")
+    # the same error in the waveform domain (north_star states the tolerance on the decoded waveform): the reference's latents and
+    # the MXFP8 latents through the same native Oobleck decoder (first 2 songs, 96 latent frames = 3.8 s)
+    import ace355
+    from ace355 import weightgen
+    from ace355.vae import NativeVae
+    vcfg = ace355.VaeConfig()
+    vae = NativeVae(vcfg, gpu_device)
+    vae.load_state_dict(weightgen.make_vae_weights(vcfg.weight_shapes(), seed=4, mode="init"))
+    zr = torch.from_numpy(G12["out"])[:2, :96].transpose(1, 2).contiguous()
+    zf = out.cpu()[:2, :96].transpose(1, 2).contiguous()
+    wr, wf = vae.decode(zr).cpu(), vae.decode(zf).cpu()
+    snr = float(10 * torch.log10(wr.pow(2).sum() / (wf - wr).pow(2).sum()))
+    print(f"MXFP8 DiT at the metric shape: forward rel L2 vs reference fp32 {r:.3e} (vs the bf16 path {rb:.3e}); 3-step CFG sampler {rs:.3e}; "
+          f"decoded waveform SNR vs the reference latents decoded the same way {snr:.1f} dB")
+    assert snr > 22.0, snr   # measured 25.9 dB
     assert torch.isfinite(v).all() and not torch.equal(v, v_bf16)   # the mode is really on
     assert r < 8e-2 and rs < 8e-2, (r, rs)
     assert _rel(dit.forward(*args).cpu(), v_bf16.cpu()) == 0.0     # and really off again

@@ -259,3 +259,30 @@ def test_g11_metric_shape_pair(golden_dir):
     stride = int(G11["tap_stride"])
     assert G11["tap_seqs"].tolist()[0] == 0 and G11["tap_seqs"].tolist()[2] == 8
     assert float((taps["l23.out"][:, ::stride] - T(G11["l23_out"])[[0, 2]]).abs().max()) < 1e-3
+
+
+def test_mx_block_quantiser_rules():
+    """oracle/mx.py (OCP MX v1.0 section 6.3 restated; parity unpinned against torchao, which is absent): the shared exponent is
+    floor(log2(amax)) - 8, elements saturate at +-448, an all-zero block gets the smallest scale, quantisation is idempotent."""
+    from oracle import mx as o_mx
+    x = torch.zeros(4, 64)
+    x[0, :32] = torch.linspace(-448.0, 448.0, 32)          # amax 448 = 1.75 * 2^8 -> X = 2^0
+    x[0, 32:] = torch.linspace(-1.0, 1.0, 32)              # amax 1 -> X = 2^-8
+    x[1, :32] = 500.0                                      # 500 = 1.95 * 2^8 -> X = 1, saturates to 448
+    x[2, 3] = 3.0e4                                        # one outlier owns the block: 3e4 = 1.83 * 2^14 -> X = 2^6
+    x[2, 4] = 1.0                                          # ... 1.0 = 2^-6 * 64 is still e4m3's smallest normal: survives
+    x[2, 5] = 0.05                                         # ... below half of the smallest subnormal (2^-9 * 64 / 2 = 0.0625): rounds to 0
+    q, sb = o_mx.mx_quantize(x)
+    assert sb[0].tolist() == [127, 119] and sb[1, 0] == 127 and sb[2, 0] == 133 and sb[3].tolist() == [0, 0]
+    d = o_mx.mx_dequantize(q, sb)
+    assert torch.equal(d[0, :32][[0, -1]], torch.tensor([-448.0, 448.0])) and float(d[1, :32].max()) == 448.0
+    assert float(d[2, 3]) == 28672.0 and float(d[2, 4]) == 1.0 and float(d[2, 5]) == 0.0   # 3e4 -> 448 * 64 (e4m3 step there is 32 * 64)
+    q2, sb2 = o_mx.mx_quantize(d)
+    assert torch.equal(q2.view(torch.uint8), q.view(torch.uint8)) and torch.equal(sb2[:3], sb[:3])
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(64, 256, generator=g)
+    qy, sy = o_mx.mx_quantize(y)
+    rel = float((o_mx.mx_dequantize(qy, sy) - y).norm() / y.norm())
+    assert 1.5e-2 < rel < 4e-2, rel                        # e4m3: 3 mantissa bits
+    w = o_mx.pack_scales(sy, 320)
+    assert w.shape == (2, 320) and int(w[1, 5]) == int(sy[5, 4]) | int(sy[5, 5]) << 8 | int(sy[5, 6]) << 16 | int(sy[5, 7]) << 24

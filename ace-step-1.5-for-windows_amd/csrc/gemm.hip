@@ -743,15 +743,18 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             for (int m = 0; m < NM; ++m) {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
                 acc[i][j] = mfma32(qw[h][j], qa[h][i], acc[i][j]);
-                if (m < AJ + WJ) {
-                    if (dma) {
-                        if (m < AJ) glds16_sv(a_voff[m], a_k2, sb + m * (NW * 1024));
-                        else glds16_sv(w_voff[m - AJ], w_k2, sb + A_BYTES + (m - AJ) * (NW * 1024));
+                constexpr int DP = (AJ + WJ + NM - 1) / NM < 1 ? 1 : (AJ + WJ + NM - 1) / NM;   // DMA pieces per MFMA slot (1 for every product tile)
+                constexpr int DSL = (AJ + WJ + DP - 1) / DP;                                      // MFMA slots that carry DMA
+                if (dma) {
+#pragma unroll
+                    for (int q = 0; q < DP; ++q) {
+                        const int pc = m * DP + q;
+                        if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
+                        else if (pc < AJ + WJ) glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
                     }
                 }
-                static_assert(AJ + WJ <= NM, "at most one DMA piece per MFMA slot");
                 if (more) {
-                    constexpr int F0 = (AJ + WJ < NM) ? (AJ + WJ) : 0;  // first MFMA slot that carries fragment reads
+                    constexpr int F0 = (DSL < NM) ? DSL : 0;  // first MFMA slot that carries fragment reads
                     constexpr int PER = (NF + (NM - F0) - 1) / (NM - F0);
 #pragma unroll
                     for (int q = 0; q < PER; ++q) {

@@ -7,6 +7,8 @@
 
 #include "../../include/ace355.h"
 #include "common.h"
+#include <dlfcn.h>
+#include <stdlib.h>
 
 namespace ace355 {
 
@@ -21,6 +23,29 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     (void)hipGetLastError();  // clear the sticky error so the next call starts clean
     return ACE355_ERR_HIP;
 }
+
+// roctx through dlopen: ACE355_ROCTX=1 switches the ranges on (common.h)
+namespace {
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char* e = getenv("ACE355_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        // rocprofv3 (rocprofiler-sdk) listens to its own roctx library; the older libroctx64 is the fallback for rocprof v1 / v2
+        void* lib = nullptr;
+        for (const char* name : {"librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { fprintf(stderr, "[ace355] ACE355_ROCTX=1 but no roctx library can be loaded: %s\n", dlerror()); return; }
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+RoctxApi& roctx_api() { static RoctxApi a; return a; }
+}  // namespace
+void roctx_push(const char* name) { if (roctx_api().push) roctx_api().push(name); }
+void roctx_pop() { if (roctx_api().pop) roctx_api().pop(); }
 
 namespace {
 // Temporaries of the unit hooks: freed (after the stream has drained) on every exit path, early error returns included.

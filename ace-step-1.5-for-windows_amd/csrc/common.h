@@ -26,6 +26,18 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 #define ACE_LAUNCH_CHECK() ACE_HIP(hipGetLastError())
 
+// ------------------------------------------------------------------ roctx ranges (the reference brackets its
+// phases with profiler ranges, acestep/profile_inference.py).  ACE355_ROCTX=1 loads librocprofiler-sdk-roctx.so (or libroctx64.so) at first use (dlopen: no link-time
+// dependency, nothing happens without the variable); rocprofv3 --marker-trace then shows sample / step / forward / layer / decode.
+void roctx_push(const char* name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char* name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 // ------------------------------------------------------------------ device types
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -365,7 +365,9 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     rc = gemm(h, h->xin, 2 * h->cfg.in_channels, h->w_in, 2 * h->cfg.in_channels, h->h, D, M, D, 2 * h->cfg.in_channels, ep, s);
     if (rc) return rc;
 
+    RoctxRange r_fwd("ace355.dit_forward");
     for (int li = 0; li < h->NL; ++li) {
+        RoctxRange r_layer("ace355.dit_layer");
         const LayerW& W = h->layers[li];
         const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
         // ---- self attention (base.py:499-511)
@@ -526,6 +528,7 @@ int run_sampler_steps(ace355_dit* h, const ace355_sample_params* p, int B, int T
             if (do_cfg) slots[B + b] = p->null_slot;
         }
         const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
+        RoctxRange r_step("ace355.sampler_step");
         rc = time_embed(h, &t_curr, &t_curr, 1, s);
         if (rc) return rc;
         rc = forward_core(h, N, T, slots, 1, s);
@@ -791,6 +794,7 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     const int copies = do_cfg ? 2 : 1, N = B * copies;
     ACE_CHECK(N <= ACE355_MAX_SEQS, "dit_sample: at most 64 sequences per call");
     hipStream_t s = (hipStream_t)stream;
+    RoctxRange r_sample("ace355.dit_sample");
     int rc = ensure_workspace(h, N, T, s);
     if (rc) return rc;
     const int Tpad = 2 * ((T + 1) / 2);

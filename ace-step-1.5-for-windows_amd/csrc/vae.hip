@@ -551,6 +551,7 @@ static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t
 }
 
 int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream) {
+    RoctxRange r_dec("ace355.vae_decode");
     ACE_CHECK(h && z_dev && wav_out_dev, "vae_decode: null argument");
     if (!h->finalized) { set_error("vae_decode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
     ACE_CHECK(B > 0 && T > 0, "vae_decode: empty problem");

@@ -108,6 +108,18 @@ int ace355_latent_check(const float* lat_dev, int64_t numel, int32_t* flags_host
 }
 
 // ------------------------------------------------------------------------------------------ unit hooks
+// The residual-GEMM hooks lend launch_gemm ordered split-K counters like the handles do, so the unit tests run the product's small-M path
+// (one array per process, allocated on first use: launches through the hooks are serial).
+static int hook_counters(GemmEpilogue& ep) {
+    static int* cnt = nullptr;
+    if (!cnt) {
+        ACE_HIP(hipMalloc((void**)&cnt, SK_MAX_TILES * sizeof(int)));
+        ACE_HIP(hipMemset(cnt, 0, SK_MAX_TILES * sizeof(int)));
+    }
+    ep.sk_cnt = cnt;
+    return 0;
+}
+
 int ace355_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int out_dtype, const float* bias, void* stream) {
     ACE_CHECK(A && W && C, "gemm_bf16: null pointer");
     GemmEpilogue ep{out_dtype == ACE355_DTYPE_F32 ? 1 : 0, bias, nullptr, nullptr, 0, 0};
@@ -120,6 +132,7 @@ int ace355_gemm_bf16_fused(const void* A, const void* W, void* out, int M, int N
     ACE_CHECK(mode == 0 || mode == 1, "gemm_bf16_fused: mode");
     if (mode == 0) {
         GemmEpilogue ep{2, nullptr, g1, g2, g2_stride, rows_per_seq};
+        if (int rc = hook_counters(ep)) return rc;
         return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, out, N, M, N, K, ep, (hipStream_t)stream);
     }
     GemmEpilogue ep{3, nullptr, nullptr, nullptr, 0, 0};
@@ -130,6 +143,7 @@ int ace355_gemm_bf16_residual(const void* A, const void* W, float* H, int M, int
                               int g2_stride, int rows_per_seq, const float* cvec, int cvec_row0, void* stream) {
     ACE_CHECK(A && W && H, "gemm_bf16_residual: null pointer");
     GemmEpilogue ep{2, nullptr, g1, g2, g2_stride, rows_per_seq, cvec, cvec_row0};
+    if (int rc = hook_counters(ep)) return rc;
     return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, H, N, M, N, K, ep, (hipStream_t)stream);
 }
 

@@ -107,7 +107,7 @@ struct GemmEpilogue {
     const float* cvec;  // mode 2: rows m >= cvec_row0 additionally get + cvec[n] (constant cross-attention term of broadcast slots)
     int cvec_row0;
     int clk_probe;  // set by launch_gemm (ACE355_GEMM_CLK diagnostic)
-    int ksplit;     // set by launch_gemm: > 1 = split-K (mode 2 only): blockIdx.y owns a K range and ADDS into H with fp32 atomics
+    int ksplit;     // set by launch_gemm: > 1 = split-K (mode 2 only): blockIdx.y owns a K range and adds its share into H (see sk_cnt)
     int wide_ok;  // set by launch_gemm: C / ldc / per-column vectors are 16-byte aligned, so the 16-byte staged epilogue may be used
     // mode 4 (self-attention QKV projection with PACK_ROWS_HEADPAIR q / k rows): columns [0, hn_q_cols) are q heads, up to
     // hn_qk_cols k heads, the rest v.  q / k leave the GEMM head-normed (weights hn_wq / hn_wk [128], eps hn_eps) and rotated
@@ -124,6 +124,21 @@ struct GemmEpilogue {
     // mode 3 only: the SwiGLU output leaves as MXFP8 (the down projection's operand) instead of bf16: C = fp8 [M, N/2] (ldc in bytes),
     // block scales to mxo_scales ([N/2 / 128][mxo_pad] words).  A wave's 32 output columns are exactly one block.
     uint32_t* mxo_scales; int mxo_pad;
+    // RMSNorm folded into the neighbouring GEMMs (dit.hip forward_core, sampler path; base.py:493-533).  rmsnorm(h) * g + shift feeds a
+    // projection W: (h * g) W^T * rstd_row + shift W^T.  Producer (mode 2, the GEMM that finishes h): besides H it writes
+    // xg[m][n] = bf16(h_new * g[n]) and adds each row's sum of h_new^2 into rowsq[m]; rows m < nf_split use the A set (g vector, rowsq
+    // array), the others the B set (the self-attention o_proj feeds the cross-attention norm on conditional rows and the MLP norm on the
+    // rows that skip cross-attention).  Consumer (modes 0 / 3 / 4): acc = acc * rsqrt(rowsq[m] * nc_inv_d + nc_eps) + nc_bias[n]
+    // (nc_bias = shift W^T, fp32 [N], NULL for an un-shifted norm) ahead of the mode's own epilogue.  Wide epilogue only (launch_gemm checks).
+    bf16_t* nf_xg; int nf_ldx; int nf_split;
+    const float* nf_gA; const float* nf_gB;
+    // split-K (mode 2) in part order instead of fp32 atomics: the caller lends a zeroed counter array (SK_MAX_TILES ints, one stream at a
+    // time); part y of a tile waits until parts 0 .. y-1 have added their share to H, then does the plain read-modify-write itself, so
+    // the sum has one order and the result is bit-reproducible.  sk_ord is set by launch_gemm.  NULL: the atomics path.
+    int* sk_cnt; int sk_ord;
+    unsigned long long* nf_sqA; unsigned long long* nf_sqB;   // 2^-24 fixed point: integer adds commute, so the sums (and with them
+    const unsigned long long* nc_rowsq; const float* nc_bias;  // every result) do not depend on the order the atomics arrive in
+    float nc_inv_d, nc_eps;
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
@@ -135,6 +150,8 @@ bool gemm_mx_supported(int M, int N, int K, int mode);
 // x bf16 [M, K] (row stride ld) -> q fp8 e4m3 [M, K] + scales uint32 [K / 128][rows_pad] (rows_pad >= M, multiple of 4)
 int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t* scales, int rows_pad, hipStream_t s);
 inline int mx_rows_pad(int rows) { return ((rows + 255) / 256) * 256 + 256; }
+
+constexpr int SK_MAX_TILES = 4096;
 
 struct AttnArgs {
     const bf16_t* q; long q_seq_stride; int q_row_stride;           // q[n][s][h*128 + d]
@@ -171,6 +188,8 @@ int launch_rmsnorm_gs_mx(const float* x, const float* g, const float* sft, uint8
                          float eps, long stride, int rows_per_seq, hipStream_t s);
 int launch_mod_gs(const ModEntry* entries_dev, int n_entries, const float* tproj, long tp_stride, int rows, float* out, int D,
                   hipStream_t s);
+// gs [rows][n_entries][2][D] (launch_mod_gs) -> the shift halves as bf16 rows, out [n_entries][rows][D]
+int launch_shift_rows(const float* gs, int n_entries, int rows, bf16_t* out, int D, hipStream_t s);
 int launch_rmsnorm_mod(const float* x, const float* w, bf16_t* y, int M, int D, float eps, const float* sc1,
                        const float* sc2, const float* sh1, const float* sh2, int stride, int rows_per_seq, hipStream_t s);
 int launch_headnorm_rope(bf16_t* x, int M, int ld, int col0, int heads, const float* w, float eps,

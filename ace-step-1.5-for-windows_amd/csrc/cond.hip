@@ -60,6 +60,7 @@ struct EncBase {
     long rowsrc_cap = 0;
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_S = 0;
+    int* sk_cnt = nullptr;   // ordered split-K turn counters (GemmEpilogue::sk_cnt), allocated with the rope tables
 };
 
 struct ace355_cond : EncBase {
@@ -153,6 +154,10 @@ int ensure_rope(EncBase* h, int S, hipStream_t s) {
     int rc = launch_rope_table(h->rope_cos, h->rope_sin, cap, h->theta, s);
     if (rc) return rc;
     h->rope_S = cap;
+    if (!h->sk_cnt) {
+        ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
+        ACE_HIP(hipMemsetAsync(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int), s));
+    }
     return 0;
 }
 
@@ -226,6 +231,7 @@ int encoder_layers(EncBase* h, const EncoderW& E, int N, int S, const int* kv_le
         rc = launch_attention(a, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};  // h += o_proj(attn)
+        ep.sk_cnt = h->sk_cnt;
         rc = launch_gemm(h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
         // SwiGLU MLP (base.py:430-433)
@@ -235,6 +241,7 @@ int encoder_layers(EncBase* h, const EncoderW& E, int N, int S, const int* kv_le
         rc = launch_gemm(h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};
+        ep.sk_cnt = h->sk_cnt;
         rc = launch_gemm(h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
         if (rc) return rc;
     }

@@ -93,6 +93,27 @@ struct ace355_dit {
     int xs_pad = 0;
     int mx_min_rows = 1536;            // below this many token rows the 192x256 tile does not fill the chip: bf16 kernels
 
+    // RMSNorm folded into the neighbouring GEMM epilogues (sampler path, big-M bf16 launches; GemmEpilogue::nf_* / nc_*): the residual
+    // GEMM that finishes h also writes bf16(h * g_next) and the rows' sums of squares, the consumer projection applies rstd and the
+    // shift's projection (shift W^T, precomputed for every step of the schedule at the start of the call) to its accumulators.
+    struct NormFold {
+        int enabled = 1;                 // ACE355_NORM_FOLD (default on)
+        bool on = false;                 // the current sampler call runs folded
+        int step = 0;                    // current step (row of the bias tables)
+        int rows = 0;                    // steps of the tables
+        int cap_rows = 0; long cap_M = 0;
+        std::vector<void*> allocs;
+        float *tfreq = nullptr, *ta1 = nullptr, *temb = nullptr, *tsilu = nullptr, *tproj = nullptr, *gs = nullptr;
+        bf16_t* shift = nullptr;         // [2 NL][rows][D]
+        float* bias_qkv = nullptr;       // [NL][rows][QKV]
+        float* bias_gu = nullptr;        // [NL][rows][2F]
+        unsigned long long* rowsq = nullptr;  // [NL][3][cap_M] (2^-24 fixed point): self-attention norm, cross-attention norm, MLP norm
+        std::vector<float> key;          // schedule the tables were built for ...
+        hipStream_t key_stream = nullptr; // ... and the stream that built them (another stream is not ordered behind it)
+    } nf;
+
+    int* sk_cnt = nullptr;   // ordered split-K turn counters lent to launch_gemm (GemmEpilogue::sk_cnt)
+
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> gemm_ev, attn_ev;
@@ -212,7 +233,9 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
         h->gemm_flops += 2.0 * M * N * K;
         h->gemm_launches++;
     }
-    return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, ep, s);
+    GemmEpilogue e2 = ep;
+    e2.sk_cnt = h->sk_cnt;
+    return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, e2, s);
 }
 
 // The same projection on the MXFP8 path: the bf16 activation operand is block-quantised (mx_quant_kernel) into the handle's scratch,
@@ -308,22 +331,102 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
 }
 
 // TimestepEmbedding x2 (base.py:1340-1344): temb[rows][D], tproj[rows][6D] for `rows` distinct (t, t - t_r) pairs.
-int time_embed(ace355_dit* h, const float* t, const float* tr, int rows, hipStream_t s) {
+int time_embed_into(ace355_dit* h, const float* t, const float* tr, int rows, float* tfreq, float* ta1, float* temb, float* tsilu,
+                    float* tproj, hipStream_t s) {
     TVals tv;
     const int D = h->D;
+    ACE_CHECK(rows <= 64, "time_embed: at most 64 rows per call");
     for (int e = 0; e < 2; ++e) {
         for (int i = 0; i < rows; ++i) tv.t[i] = e == 0 ? t[i] : (t[i] - tr[i]);
-        float* tf = h->tfreq + (size_t)e * rows * 256;
+        float* tf = tfreq + (size_t)e * rows * 256;
         int rc = launch_sinusoid(tv, rows, tf, s);
         if (rc) return rc;
         const TimeEmbedW& T = h->te[e];
-        rc = launch_small_linear_ex(tf, T.l1, T.b1, h->ta1, nullptr, rows, D, 256, /*silu_out*/ 1, 0, s);
+        rc = launch_small_linear_ex(tf, T.l1, T.b1, ta1, nullptr, rows, D, 256, /*silu_out*/ 1, 0, s);
         if (rc) return rc;
-        rc = launch_small_linear_ex(h->ta1, T.l2, T.b2, h->temb, h->tsilu, rows, D, D, 0, /*accumulate*/ e, s);
+        rc = launch_small_linear_ex(ta1, T.l2, T.b2, temb, tsilu, rows, D, D, 0, /*accumulate*/ e, s);
         if (rc) return rc;
-        rc = launch_small_linear_ex(h->tsilu, T.tp, T.bp, h->tproj, nullptr, rows, 6 * D, D, 0, e, s);
+        rc = launch_small_linear_ex(tsilu, T.tp, T.bp, tproj, nullptr, rows, 6 * D, D, 0, e, s);
         if (rc) return rc;
     }
+    return 0;
+}
+int time_embed(ace355_dit* h, const float* t, const float* tr, int rows, hipStream_t s) {
+    return time_embed_into(h, t, tr, rows, h->tfreq, h->ta1, h->temb, h->tsilu, h->tproj, s);
+}
+
+// Folded RMSNorm, per sampler call: decide whether this call runs folded and (re)build the per-step bias tables
+// bias[li][i][:] = shift_i W^T for the QKV and gate|up projections (one M = steps GEMM per layer and projection: one pass over those
+// weights per CALL; as per-step GEMVs it would be one pass per forward, which costs what the norm kernels cost).
+bool normfold_eligible(const ace355_dit* h, int steps, int M) {
+    const int D = h->D, F = h->F, QD = h->QD, QKV = h->QD + 2 * h->KVD;
+    const bool mx = h->precision == ACE355_PRECISION_MXFP8 && M >= h->mx_min_rows;
+    return h->nf.enabled && !mx && M >= 1536 && D % 256 == 0 && QKV % 256 == 0 && QD % 256 == 0 && (2 * F) % 256 == 0 && h->KVD % 128 == 0 &&
+           steps <= 1024;
+}
+// (allocation: outside any stream capture, next to ensure_workspace)
+int normfold_reserve(ace355_dit* h, int steps, int N, int T, hipStream_t s) {
+    auto& nf = h->nf;
+    const int S = (T + 1) / 2, M = N * S;
+    if (!normfold_eligible(h, steps, M) || (steps <= nf.cap_rows && M <= nf.cap_M)) return 0;
+    const int D = h->D, F = h->F, QKV = h->QD + 2 * h->KVD, NL = h->NL;
+    ACE_HIP(hipStreamSynchronize(s));
+    for (void* q : nf.allocs) hipFree(q);
+    nf.allocs.clear();
+    nf.key.clear();
+    const size_t R = std::max(steps, nf.cap_rows), MM = std::max<long>(M, nf.cap_M);
+    ALLOC(nf.allocs, nf.tfreq, 2 * R * 256);
+    ALLOC(nf.allocs, nf.ta1, R * D);
+    ALLOC(nf.allocs, nf.temb, R * D);
+    ALLOC(nf.allocs, nf.tsilu, R * D);
+    ALLOC(nf.allocs, nf.tproj, R * 6 * D);
+    ALLOC(nf.allocs, nf.gs, R * NL * 4 * D);
+    ALLOC(nf.allocs, nf.shift, (size_t)2 * NL * R * D);
+    ALLOC(nf.allocs, nf.bias_qkv, (size_t)NL * R * QKV);
+    ALLOC(nf.allocs, nf.bias_gu, (size_t)NL * R * 2 * F);
+    ALLOC(nf.allocs, nf.rowsq, (size_t)NL * 3 * MM);
+    nf.cap_rows = (int)R;
+    nf.cap_M = (long)MM;
+    h->ws_epoch++;   // a captured graph holds these addresses
+    return 0;
+}
+int normfold_prepare(ace355_dit* h, const ace355_sample_params* p, int N, int T, hipStream_t s) {
+    auto& nf = h->nf;
+    nf.on = false;
+    const int S = (T + 1) / 2, M = N * S, steps = p->num_steps;
+    const int D = h->D, F = h->F, QKV = h->QD + 2 * h->KVD, NL = h->NL;
+    if (!normfold_eligible(h, steps, M) || steps > nf.cap_rows || M > nf.cap_M) return 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (cap != hipStreamCaptureStatusNone) nf.key.clear();   // a captured call always carries its own table build
+    std::vector<float> key(p->t_sched_host, p->t_sched_host + steps);
+    if (key != nf.key || nf.rows != steps || nf.key_stream != s) {
+        int rc;
+        for (int r0 = 0; r0 < steps; r0 += 64) {   // TimestepEmbedding over the whole schedule, 64 rows per launch group
+            const int nr = std::min(64, steps - r0);
+            // (the two embeddings' sinusoid rows of a chunk sit side by side in tfreq: give every chunk its own 2 x 64 x 256 block)
+            rc = time_embed_into(h, p->t_sched_host + r0, p->t_sched_host + r0, nr, nf.tfreq + (size_t)2 * r0 * 256, nf.ta1 + (size_t)r0 * D,
+                                 nf.temb + (size_t)r0 * D, nf.tsilu + (size_t)r0 * D, nf.tproj + (size_t)r0 * 6 * D, s);
+            if (rc) return rc;
+        }
+        rc = launch_mod_gs(h->mod_tab, 2 * NL, nf.tproj, 6L * D, steps, nf.gs, D, s);
+        if (rc) return rc;
+        rc = launch_shift_rows(nf.gs, 2 * NL, steps, nf.shift, D, s);
+        if (rc) return rc;
+        for (int li = 0; li < NL; ++li) {
+            const LayerW& W = h->layers[li];
+            GemmEpilogue ep{1, nullptr, nullptr, nullptr, 0, 0};
+            rc = gemm(h, nf.shift + (size_t)(li * 2 + 0) * steps * D, D, W.wqkv, D, nf.bias_qkv + (size_t)li * steps * QKV, QKV, steps, QKV, D, ep, s);
+            if (rc) return rc;
+            rc = gemm(h, nf.shift + (size_t)(li * 2 + 1) * steps * D, D, W.wgu, D, nf.bias_gu + (size_t)li * steps * 2 * F, 2 * F, steps, 2 * F, D, ep, s);
+            if (rc) return rc;
+        }
+        nf.key = key;
+        nf.rows = steps;
+        nf.key_stream = s;
+    }
+    nf.on = true;
+    nf.step = 0;
     return 0;
 }
 
@@ -359,6 +462,12 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     rc = launch_mod_gs(h->mod_tab, 2 * h->NL, h->tproj, 6L * D, temb_rows, h->gs, D, s);
     if (rc) return rc;
     const long gs_stride = temb_rows == 1 ? 0 : (long)h->NL * 4 * D;
+    // folded RMSNorm (sampler path): row sums of squares of the 3 NL norm inputs accumulate during this forward
+    const bool fold = h->nf.on && temb_rows == 1 && M <= h->nf.cap_M;
+    const auto& nf = h->nf;
+    auto rowsq = [&](int li, int which) { return nf.rowsq + ((size_t)li * 3 + which) * nf.cap_M; };
+    if (fold) ACE_HIP(hipMemsetAsync(nf.rowsq, 0, (size_t)h->NL * 3 * nf.cap_M * sizeof(unsigned long long), s));
+    const float inv_d = 1.0f / (float)D;
 
     // patchify: Conv1d(192 -> D, k=2, s=2) == GEMM over [M, 384] (base.py:1358)
     ep = GemmEpilogue{1, h->b_in, nullptr, nullptr, 0, 0};
@@ -372,7 +481,9 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
         // ---- self attention (base.py:499-511)
         const bool mx_qkv = mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD) && D == 2048;
-        if (mx_qkv)  // the norm writes the MX GEMM's operand directly (fp8 + block scales): no bf16 xn round trip, no quantise pass
+        const bool fold_sa = fold && li > 0;   // layer 0's input comes from the patchify GEMM: its norm stays a kernel
+        if (fold_sa) rc = 0;                   // xn = bf16(h * g) and the row sums were written by the previous layer's down projection
+        else if (mx_qkv)  // the norm writes the MX GEMM's operand directly (fp8 + block scales): no bf16 xn round trip, no quantise pass
             rc = launch_rmsnorm_gs_mx(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xq, h->xs, h->xs_pad,
                                       M, D, eps, gs_stride, S, s);
         else
@@ -383,6 +494,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};
         ep.hn_wq = W.qn_s, ep.hn_wk = W.kn_s, ep.hn_cos = h->rope_cos, ep.hn_sin = h->rope_sin;
         ep.hn_q_cols = QD, ep.hn_qk_cols = QD + KVD, ep.hn_eps = eps;
+        if (fold_sa) {
+            ep.nc_rowsq = rowsq(li, 0); ep.nc_bias = nf.bias_qkv + ((size_t)li * nf.rows + nf.step) * QKV;
+            ep.nc_inv_d = inv_d; ep.nc_eps = eps;
+        }
         if (mx_qkv) rc = gemm_mx(h, nullptr, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
@@ -418,6 +533,12 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             if (rc) return rc;
         }
         ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S, cconst ? cconst + (size_t)li * D : nullptr, Mc};
+        const float* g_mlp = h->gs + (size_t)(li * 2 + 1) * 2 * D;
+        if (fold) {  // conditional rows go on to the cross-attention norm (plain weight), the others straight to the MLP norm
+            ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = Nc > 0 ? Mc : 0;
+            ep.nf_gA = W.n_ca; ep.nf_sqA = rowsq(li, 1);
+            ep.nf_gB = g_mlp; ep.nf_sqB = rowsq(li, 2);
+        }
         if (ao_is_mx) rc = gemm_mx(h, nullptr, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else if (mx_usable(h, W.mx_o, M, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
@@ -428,12 +549,14 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         static int mx_cross = -1;
         if (mx_cross < 0) { const char* e = getenv("ACE355_MX_CROSS"); mx_cross = e ? atoi(e) : 0; }
         const bool mx_qc = mx_cross && mx_usable(h, W.mx_qc, Mc, QD, D, 4, QD, QD) && D == 2048;
-        if (mx_qc) rc = launch_rmsnorm_gs_mx(h->h, W.n_ca, nullptr, h->xq, h->xs, h->xs_pad, Mc, D, eps, 0, S, s);  // (x rstd) w: rmsnorm_mod's product
+        if (fold) rc = 0;
+        else if (mx_qc) rc = launch_rmsnorm_gs_mx(h->h, W.n_ca, nullptr, h->xq, h->xs, h->xs_pad, Mc, D, eps, 0, S, s);  // (x rstd) w: rmsnorm_mod's product
         else rc = launch_rmsnorm_mod(h->h, W.n_ca, h->xn, Mc, D, eps, nullptr, nullptr, nullptr, nullptr, 0, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{4, nullptr, nullptr, nullptr, 0, S};  // q head-norm in the epilogue (no RoPE on the cross path)
         ep.hn_wq = ep.hn_wk = W.qn_c, ep.hn_cos = ep.hn_sin = nullptr;
         ep.hn_q_cols = ep.hn_qk_cols = QD, ep.hn_eps = eps;
+        if (fold) { ep.nc_rowsq = rowsq(li, 1); ep.nc_bias = nullptr; ep.nc_inv_d = inv_d; ep.nc_eps = eps; }
         if (mx_qc) rc = gemm_mx(h, nullptr, D, W.mx_qc, h->qkv, QD, Mc, QD, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wq_c, D, h->qkv, QD, Mc, QD, D, ep, s);
         if (rc) return rc;
@@ -461,6 +584,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             if (rc) return rc;
         }
         ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};
+        if (fold) {  // the conditional rows' MLP-norm operand
+            ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = Mc;
+            ep.nf_gA = ep.nf_gB = g_mlp; ep.nf_sqA = ep.nf_sqB = rowsq(li, 2);
+        }
         if (cao_is_mx) rc = gemm_mx(h, nullptr, QD, W.mx_oc, h->h, D, Mc, D, QD, ep, s);
         else if (mx_cross && mx_usable(h, W.mx_oc, Mc, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_oc, h->h, D, Mc, D, QD, ep, s);
         else rc = gemm(h, h->ao, QD, W.wo_c, QD, h->h, D, Mc, D, QD, ep, s);
@@ -469,7 +596,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
 
         // ---- SwiGLU MLP (base.py:530-533)
         const bool mx_gu = mx_usable(h, W.mx_gu, M, 2 * F, D, 3) && D == 2048;
-        if (mx_gu)
+        if (fold) rc = 0;
+        else if (mx_gu)
             rc = launch_rmsnorm_gs_mx(h->h, h->gs + (size_t)(li * 2 + 1) * 2 * D, h->gs + (size_t)(li * 2 + 1) * 2 * D + D, h->xq, h->xs, h->xs_pad,
                                       M, D, eps, gs_stride, S, s);
         else
@@ -480,11 +608,19 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const bool mx_down = mx_usable(h, W.mx_down, M, D, F, 2);
         const bool act_q = mx_gu && mx_down && F % 128 == 0;  // the SwiGLU epilogue writes the down projection's MXFP8 operand itself
         if (act_q) { ep.mxo_scales = h->as_; ep.mxo_pad = h->xs_pad; }
+        if (fold) {
+            ep.nc_rowsq = rowsq(li, 2); ep.nc_bias = nf.bias_gu + ((size_t)li * nf.rows + nf.step) * 2 * F;
+            ep.nc_inv_d = inv_d; ep.nc_eps = eps;
+        }
         if (mx_gu) rc = gemm_mx(h, nullptr, D, W.mx_gu, act_q ? (void*)h->aq : (void*)h->act, F, M, 2 * F, D, ep, s);
         else if (mx_usable(h, W.mx_gu, M, 2 * F, D, 3)) rc = gemm_mx(h, h->xn, D, W.mx_gu, h->act, F, M, 2 * F, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, h->tproj + 5 * D, tstride, S};
+        if (fold && li + 1 < h->NL) {  // the next layer's self-attention norm operand
+            ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = M;
+            ep.nf_gA = ep.nf_gB = h->gs + (size_t)((li + 1) * 2 + 0) * 2 * D; ep.nf_sqA = ep.nf_sqB = rowsq(li + 1, 0);
+        }
         if (act_q) rc = gemm_mx(h, nullptr, F, W.mx_down, h->h, D, M, D, F, ep, s, h->aq, h->as_);
         else if (mx_down) rc = gemm_mx(h, h->act, F, W.mx_down, h->h, D, M, D, F, ep, s);
         else rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
@@ -514,7 +650,10 @@ int run_sampler_steps(ace355_dit* h, const ace355_sample_params* p, int B, int T
     int cond = p->cond_slot;
     bool switched = false;
     int apg_calls = 0;
+    rc = normfold_prepare(h, p, N, T, s);
+    if (rc) return rc;
     for (int i = 0; i < p->num_steps; ++i) {
+        h->nf.step = i;
         if (i >= p->cover_switch_step && !switched) {  // base.py:1916-1927
             switched = true;
             ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
@@ -601,8 +740,11 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->norm_out, D);
     ALLOC(h->allocs, h->sst_out, 2 * D);
     ALLOC(h->allocs, h->flags_dev, 4);
+    ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
+    ACE_HIP(hipMemset(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int)));
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
+    if (const char* e = getenv("ACE355_NORM_FOLD")) h->nf.enabled = atoi(e);
     *out = h;
     return ACE355_OK;
 }
@@ -613,6 +755,7 @@ void ace355_dit_destroy(ace355_dit* h) {
     for (void* p : h->allocs) hipFree(p);
     for (void* p : h->ws_allocs) hipFree(p);
     for (void* p : h->mx_allocs) hipFree(p);
+    for (void* p : h->nf.allocs) hipFree(p);
     for (CondSlot& c : h->slots) {
         if (c.kv) hipFree(c.kv);
         if (c.vt) hipFree(c.vt);
@@ -778,6 +921,7 @@ int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, 
     if (rc) return rc;
     rc = time_embed(h, t_host, t_r_host, N, s);
     if (rc) return rc;
+    h->nf.on = false;   // the folded-norm bias tables exist per sampler schedule only
     rc = forward_core(h, N, T, slots_host, N, s);
     if (rc) return rc;
     return launch_copy_v(h->vpad, v_out_dev, N, T, Tpad, s);
@@ -796,6 +940,8 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     hipStream_t s = (hipStream_t)stream;
     RoctxRange r_sample("ace355.dit_sample");
     int rc = ensure_workspace(h, N, T, s);
+    if (rc) return rc;
+    rc = normfold_reserve(h, p->num_steps, N, T, s);
     if (rc) return rc;
     const int Tpad = 2 * ((T + 1) / 2);
     const size_t lat_bytes = (size_t)B * T * h->OUTC * sizeof(float);
@@ -914,6 +1060,13 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
     }
     h->precision = precision;
     h->ws_epoch++;  // a captured sampler graph holds the other precision's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_set_norm_fold(ace355_dit* h, int enable) {
+    ACE_CHECK(h, "set_norm_fold: null handle");
+    h->nf.enabled = enable != 0;
+    h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
     return ACE355_OK;
 }
 

@@ -177,6 +177,14 @@ __global__ void mod_gs_kernel(const ModEntry* __restrict__ entries, int n_entrie
     }
 }
 
+// Folded RMSNorm (dit.hip): the shift rows of every modulated norm as bf16 GEMM operands, out[e][row][D] <- gs[row][e][1][D]
+__global__ void shift_rows_kernel(const float* __restrict__ gs, int n_entries, int rows, bf16_t* __restrict__ out, int D) {
+    const int e = blockIdx.x, row = blockIdx.y;
+    const float* src = gs + ((long)row * n_entries + e) * 2 * D + D;
+    bf16_t* o = out + ((long)e * rows + row) * D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) o[c] = f2bf(src[c]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // In-place per-head RMSNorm(128) (+ RoPE, rotate-half form) on bf16 x[M, ld], heads at col0 + h*128.
 // 16 lanes per head: lane j holds d = 4j..4j+3 and 64+4j..64+4j+3 (the rotate_half partners).
@@ -755,6 +763,12 @@ int launch_rmsnorm_gs(const float* x, const float* g, const float* sft, bf16_t* 
 int launch_mod_gs(const ModEntry* entries_dev, int n_entries, const float* tproj, long tp_stride, int rows, float* out, int D,
                   hipStream_t s) {
     hipLaunchKernelGGL(mod_gs_kernel, dim3(n_entries, rows), dim3(256), 0, s, entries_dev, n_entries, tproj, tp_stride, out, D);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_shift_rows(const float* gs, int n_entries, int rows, bf16_t* out, int D, hipStream_t s) {
+    hipLaunchKernelGGL(shift_rows_kernel, dim3(n_entries, rows), dim3(256), 0, s, gs, n_entries, rows, out, D);
     ACE_LAUNCH_CHECK();
     return 0;
 }

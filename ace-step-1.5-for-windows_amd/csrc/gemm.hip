@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <type_traits>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace ace355 {
 
@@ -48,6 +49,11 @@ __device__ __forceinline__ int stage_off(int row, int slot) {
 }
 
 __device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// v + (v of the lane a DPP control selects): cross-lane adds on the VALU, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 
 template <int MODE, int MT, int NTW, bool ROWS_FULL>
 __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
@@ -55,6 +61,30 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                                                    int wave = 0) {
     const int frow = lane & 31, fhalf = lane >> 5;
     if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
+        if (ep.nc_rowsq) {
+            // folded RMSNorm, consumer side: the A operand was h * g (bf16); the row's rstd and the shift's projection complete
+            // rmsnorm(h) * g + shift on the fp32 accumulators.  lane = row (frow), register r = column 8 (r >> 2) + 4 fhalf + (r & 3).
+            float rs_in[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int m = mw0 + i * 32 + frow;
+                rs_in[i] = rsqrtf((float)(long long)ep.nc_rowsq[ROWS_FULL ? m : min(m, M - 1)] * (1.f / 16777216.f) * ep.nc_inv_d + ep.nc_eps);
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (ep.nc_bias) b = ldf4(ep.nc_bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        acc[i][j][4 * g + 0] = acc[i][j][4 * g + 0] * rs_in[i] + b.x;
+                        acc[i][j][4 * g + 1] = acc[i][j][4 * g + 1] * rs_in[i] + b.y;
+                        acc[i][j][4 * g + 2] = acc[i][j][4 * g + 2] * rs_in[i] + b.z;
+                        acc[i][j][4 * g + 3] = acc[i][j][4 * g + 3] * rs_in[i] + b.w;
+                    }
+                }
+        }
         // mode 4, q / k tiles (workgroup-uniform): per-row sum of squares over the head's 128 columns = this wave's 64 (two
         // half-rows in lanes l and l^32) + the neighbouring wave's 64, swapped through `xw`; then w * (v * rstd) and the
         // rotation of the adjacent (d, d+64) pairs, all on the fp32 accumulators (one bf16 rounding instead of two)
@@ -234,6 +264,9 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         constexpr int NT = MT * 4;  // 8-row groups per 32-column half
         const int rsub = lane >> 3, slot = lane & 7;
         const int rps = ep.rows_per_seq;
+        float nf_rs[NT];  // folded RMSNorm, producer side (mode 2): this lane group's row sums of h_new^2 over the wave's columns
+#pragma unroll
+        for (int t = 0; t < NT; ++t) nf_rs[t] = 0.f;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
 #pragma unroll
@@ -265,14 +298,14 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 // them: one memory round trip per half instead of three (each gate sum used to wait for its own loads
                 // before the H loads were even issued)
                 float4 hv[NT];
-                if (ep.ksplit <= 1) {
+                if (ep.ksplit <= 1 || ep.sk_ord) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int m = mw0 + t * 8 + rsub;
                         hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
                     }
                 }
-                if (ep.cvec) cv = ldf4(ep.cvec + n);
+                if (ep.cvec && (ep.ksplit <= 1 || blockIdx.y == 0)) cv = ldf4(ep.cvec + n);  // (the first K part adds the constant term)
                 if (ep.g1) {
                     g1 = ldf4(ep.g1 + n);
                     const int seqA = mw0 / rps, last = (M - 1) / rps;
@@ -282,7 +315,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     gA = {g1.x + a2.x, g1.y + a2.y, g1.z + a2.z, g1.w + a2.w};
                     gB = {g1.x + b2.x, g1.y + b2.y, g1.z + b2.z, g1.w + b2.w};
                 }
-                if (ep.ksplit > 1) {
+                if (ep.ksplit > 1 && !ep.sk_ord) {
                     // (Requesting the old H values of both column halves before the barrier / staging - one memory round
                     //  trip instead of two - was tried for the read-modify-write variant below: neutral at M = 6000, and the
                     //  larger live range slowed THIS path by 25-50 %; reverted.)
@@ -317,6 +350,24 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 // The per-row gate lookup of short sequences is a separate loop: as a branch inside the store loop its (skipped)
                 // load still left an `s_waitcnt vmcnt(0)` at the join, and vmcnt counts stores too - every 16-byte store of the
                 // residual update waited for the previous one's acknowledgement (25-28 k cycles per tile).
+                float4 ngA = {0.f, 0.f, 0.f, 0.f}, ngB = ngA;
+                if (ep.nf_xg) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
+                // the next norm's operand leaves with the row: xg = bf16(h_new * g) (8 lanes x 8 bytes = a 64-byte half line per row),
+                // the sum of h_new^2 over these 32 columns = the 8 lanes of the row adds up in nf_rs.  (Keeping the packed values until
+                // both column halves are done and writing whole 128-byte rows through the staging image costs 48 registers: the 192x256
+                // kernel then spills; the stores themselves measured 2.3 us per launch as they are.)
+                auto nf_emit = [&](int t, int m, const float4& o) {
+                    const float4 gq = (m < ep.nf_split) ? ngA : ngB;
+                    uint2 pk;
+                    pk.x = pack_bf2(o.x * gq.x, o.y * gq.y);
+                    pk.y = pack_bf2(o.z * gq.z, o.w * gq.w);
+                    if (ROWS_FULL || m < M) *reinterpret_cast<uint2*>(ep.nf_xg + (long)m * ep.nf_ldx + n) = pk;
+                    float sq = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+                    sq = dpp_add<0xB1>(sq);    // quad_perm [1,0,3,2]
+                    sq = dpp_add<0x4E>(sq);    // quad_perm [2,3,0,1]
+                    sq = dpp_add<0x141>(sq);   // row_half_mirror: the other quad of the 8 lanes
+                    nf_rs[t] += sq;
+                };
                 if (!ep.g1 || two_gate) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -327,6 +378,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                         if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
+                        if (ep.nf_xg) nf_emit(t, m, o);
                     }
                 } else {  // short sequences (tiny configs): a wave's rows touch more than two sequences
 #pragma unroll
@@ -339,6 +391,19 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                         if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
+                        if (ep.nf_xg) nf_emit(t, m, o);
+                    }
+                }
+            }
+        }
+        if constexpr (MODE == 2) {
+            if (ep.nf_xg) {
+                if (slot == 0) {  // one lane per row adds the wave's partial row sums (the wave's NTW * 32 of the N columns)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int m = mw0 + t * 8 + rsub;
+                        if (ROWS_FULL || m < M)
+                            atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, (unsigned long long)(long long)(nf_rs[t] * 16777216.f));
                     }
                 }
             }
@@ -375,7 +440,7 @@ __device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], voi
                     if (ep.g1) gate = ep.g1[n] + ep.g2[(long)(m / ep.rows_per_seq) * ep.g2_stride + n];
                     float add = gate * v;
                     if (ep.cvec && m >= ep.cvec_row0 && (ep.ksplit <= 1 || blockIdx.y == 0)) add += ep.cvec[n];
-                    if (ep.ksplit > 1) unsafeAtomicAdd(reinterpret_cast<float*>(Cv) + (long)m * ldc + n, add);
+                    if (ep.ksplit > 1 && !ep.sk_ord) unsafeAtomicAdd(reinterpret_cast<float*>(Cv) + (long)m * ldc + n, add);
                     else reinterpret_cast<float*>(Cv)[(long)m * ldc + n] += add;
                 }
             }
@@ -854,7 +919,26 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         }
         unsigned long long e0 = 0;
         if (probe) e0 = clock64();
+        if constexpr (MODE == 2 && !PERS && !FP8) {
+            if (ep.sk_ord) {
+                // ordered split-K: wait until the parts before this one have added their share of this tile to H.  A part's
+                // workgroups are dispatched after every workgroup of the parts before it (blockIdx.y is the slow grid index), so
+                // whoever is waited for is already running.  The counter lives in L2 like the fp32 atomics it replaces.
+                if (tid == 0) {
+                    const int tile = tm * tiles_n + tn;
+                    while (atomicAdd(ep.sk_cnt + tile, 0) != (int)blockIdx.y) __builtin_amdgcn_s_sleep(8);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
         gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+        if constexpr (MODE == 2 && !PERS && !FP8) {
+            if (ep.sk_ord) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's H rows are in L2
+                __syncthreads();
+                if (tid == 0) atomicExch(ep.sk_cnt + tm * tiles_n + tn, (int)blockIdx.y + 1 == ep.ksplit ? 0 : (int)blockIdx.y + 1);
+            }
+        }
         if (probe) {
             g_clk_probe[3] = clock64() - e0;            // epilogue until the last store is ISSUED
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -940,7 +1024,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
             if (mid_ns == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
             else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
         }
-    } else if (big && pers && region > 32) {
+    } else if (big && pers && region > 32 && (MODE != 2 || pers >= 2)) {
         const dim3 pgrid(8 * 32);
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
@@ -994,10 +1078,12 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     const int tiles_m = (M + bm - 1) / bm;
     const int nwg = tiles_m * tiles_n;
     // Small-M residual GEMMs (batch-1 requests: M = 750 rows -> 96 workgroups, each alone with a 32-96 step K loop) are
-    // latency bound: split K over blockIdx.y and let every part add gate * partial into H with fp32 atomics.  Only mode 2
-    // (its epilogue is an accumulation already); results then depend on the atomic arrival order in the last bits, so the
-    // split is limited to launches that fill less than a quarter of the chip's workgroup slots (ACE355_GEMM_KSPLIT=1 disables).
+    // latency bound: split K over blockIdx.y and let every part add gate * partial into H.  Only mode 2 (its epilogue is an
+    // accumulation already).  With turn counters from the caller (ep.sk_cnt) the parts add in part order with plain read-modify-writes
+    // - bit-reproducible, and two serialised 4 us updates cost less than 16 k fp32 atomics per part (12 us); without counters the
+    // parts use fp32 atomics and the last bits depend on the arrival order.  ACE355_GEMM_KSPLIT=1 disables the split.
     ep.ksplit = 1;
+    ep.sk_ord = 0;
     if (variant != 1 && ep.mode == 2 && big == 0) {
         static int ks_env = -1;
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
@@ -1006,8 +1092,22 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         if (nwg < 128) {  // stay at one workgroup per CU: that regime gets the deep (3-4 stage) pipeline, measured best together
             while (ks < 8 && nwg * ks * 2 <= 256 && nk / (ks * 2) >= 4) ks *= 2;
         }
+        static int ord_env = -1;
+        if (ord_env < 0) ord_env = env_int("ACE355_GEMM_SKORD", 1);  // 0: fp32 atomics in arrival order (A/B)
+        const bool ord = ord_env && ep.sk_cnt && nwg <= SK_MAX_TILES;
+        if (ord && ks > 2) ks = 2;   // the parts' read-modify-writes of a tile run one after the other: measured best at two parts
         if (ks_env >= 1) ks = ks_env;
+        ks = std::min(ks, nk);
+        while (ks > 1 && (ks - 1) * ((nk + ks - 1) / ks) >= nk) --ks;   // every part owns at least one K step (an ordered part must arrive)
         ep.ksplit = ks;
+        ep.sk_ord = (ord && ks > 1) ? 1 : 0;
+    }
+    if (ep.nf_xg || ep.nc_rowsq) {  // folded RMSNorm (dit.hip): lives in the wide epilogue only, whole tiles, no split-K
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        ACE_CHECK(variant != 1 && ep.wide_ok && N % bn == 0 && ep.ksplit == 1, "gemm: the folded-norm epilogue needs whole, 16-byte aligned tiles");
+        ACE_CHECK(!ep.nf_xg || (ep.mode == 2 && ep.nf_gA && ep.nf_gB && ep.nf_sqA && ep.nf_sqB && ep.nf_ldx % 8 == 0 && al16(ep.nf_xg) &&
+                                al16(ep.nf_gA) && al16(ep.nf_gB)), "gemm: folded-norm producer arguments");
+        ACE_CHECK(!ep.nc_rowsq || ((ep.mode == 0 || ep.mode == 3 || ep.mode == 4) && al16(ep.nc_bias)), "gemm: folded-norm consumer arguments");
     }
     switch (ep.mode) {
         case 0: launch_mode<0>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
@@ -1099,6 +1199,7 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
     ACE_CHECK(al16(Aq) && al16(Wq) && al16(sa) && al16(sw), "gemm_mx: operands must be 16-byte aligned");
     ep.clk_probe = 0;
     ep.ksplit = 1;
+    ep.sk_ord = 0;
     ep.mx_sa = sa; ep.mx_sw = sw; ep.mx_sa_ld = sa_ld; ep.mx_sw_ld = sw_ld;
     if (ep.mode == 4)
         ACE_CHECK(ep.hn_wq && ep.hn_wk && (!ep.hn_cos == !ep.hn_sin) && ep.rows_per_seq > 0 && ep.hn_q_cols % 256 == 0 && ep.hn_qk_cols % 256 == 0 &&

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ace355_dit_set_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ace355_dit_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
+    "ace355_dit_set_norm_fold": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ace355_dit_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),

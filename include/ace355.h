@@ -144,6 +144,13 @@ int ace355_dit_set_precision(ace355_dit* h, int precision);
 int ace355_dit_set_graph(ace355_dit* h, int enable);
 int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
 
+/* RMSNorm folding (on by default; ACE355_NORM_FOLD=0 in the environment or enable = 0 here turns it off): in ace355_dit_sample calls
+ * whose launches take the big GEMM tiles (>= 1536 token rows, bf16 precision) the three RMSNorms of a decoder layer (base.py:493-533)
+ * are not kernels of their own: the residual GEMM that finishes hidden_states also writes bf16(h * g) and the rows' sums of squares,
+ * the consuming projection applies rsqrt(mean(h^2) + eps) and the modulation shift's projection (shift W^T, precomputed per step of
+ * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently. */
+int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
+
 /* Test / debug hook: after decoder layer `layer` (0-based) of every following forward, copy the fp32 residual stream
  * hidden_states [N*S, hidden] (the layer's output, base.py:539) to dst_dev; dst_dev NULL clears the tap.  Lets the parity
  * tests compare the per-layer activations the golden fixtures hold, not only the final velocity. */

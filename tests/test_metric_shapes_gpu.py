@@ -89,6 +89,31 @@ def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_d
     assert r < 1e-2 and max(per) < 1.2e-2, (r, per)  # measured 4.0e-3 / 4.0e-3
 
 
+def test_metric_batch_sampler_norm_fold_on_off(gpu_device, golden_dir, full_dit_seed4):
+    """The folded RMSNorm path (default in big-M sampler calls: GemmEpilogue nf_* / nc_*, include/ace355.h ace355_dit_set_norm_fold)
+    against the same call with the norms as kernels of their own, and both against the reference golden G12."""
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g12_metric_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    _, ctx1 = _inputs(B, T)
+    ref = torch.from_numpy(G["out"])
+    outs = {}
+    try:
+        for fold in (True, False):
+            dit.set_norm_fold(fold)
+            outs[fold] = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G["seeds"].tolist(),
+                                          infer_steps=int(G["steps"]), diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
+    finally:
+        dit.set_norm_fold(True)
+    r_on, r_off, r_ab = _rel(outs[True], ref), _rel(outs[False], ref), _rel(outs[True], outs[False])
+    print(f"norm fold: on vs reference {r_on:.3e}, off vs reference {r_off:.3e}, on vs off {r_ab:.3e}")
+    assert torch.isfinite(outs[True]).all()
+    assert r_on < 1e-2 and r_off < 1e-2 and r_ab < 6e-3, (r_on, r_off, r_ab)
+    assert not torch.equal(outs[True], outs[False])  # the two paths really are different launch sequences
+
+
 def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, full_dit_seed4):
     """G13 / BASELINE configs[2] (120 s, T = 3000, S = 1500): a CFG pair vs the reference (attn3_kernel<4>: 32 (seq, head) pairs do
     not fill the chip with 256-row blocks), then the same pair inside a batch of N = 16, where launch_attention switches to

@@ -8,7 +8,7 @@ agg = collections.OrderedDict()
 for r in csv.DictReader(open(f)):
     if pat not in r["Kernel_Name"]:
         continue
-    name = r["Kernel_Name"].split("(")[0].replace("void ace355::(anonymous namespace)::", "").replace("ace355::(anonymous namespace)::", "")
+    name = r["Kernel_Name"].replace("void ace355::(anonymous namespace)::", "").replace("ace355::(anonymous namespace)::", "").replace("void ace355::", "").split("(")[0]
     key = (name, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"], r["Workgroup_Size_X"])
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = agg.setdefault(key, [0, 0.0])

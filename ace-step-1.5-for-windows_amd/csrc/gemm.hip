@@ -55,13 +55,13 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int MODE, int MT, int NTW, bool ROWS_FULL>
+template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
 __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
                                                    int wave = 0) {
     const int frow = lane & 31, fhalf = lane >> 5;
     if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
-        if (ep.nc_rowsq) {
+        if (FOLD && ep.nc_rowsq) {
             // folded RMSNorm, consumer side: the A operand was h * g (bf16); the row's rstd and the shift's projection complete
             // rmsnorm(h) * g + shift on the fp32 accumulators.  lane = row (frow), register r = column 8 (r >> 2) + 4 fhalf + (r & 3).
             float rs_in[MT];
@@ -351,7 +351,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 // load still left an `s_waitcnt vmcnt(0)` at the join, and vmcnt counts stores too - every 16-byte store of the
                 // residual update waited for the previous one's acknowledgement (25-28 k cycles per tile).
                 float4 ngA = {0.f, 0.f, 0.f, 0.f}, ngB = ngA;
-                if (ep.nf_xg) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
+                if (FOLD && ep.nf_xg) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
                 // the next norm's operand leaves with the row: xg = bf16(h_new * g) (8 lanes x 8 bytes = a 64-byte half line per row),
                 // the sum of h_new^2 over these 32 columns = the 8 lanes of the row adds up in nf_rs.  (Keeping the packed values until
                 // both column halves are done and writing whole 128-byte rows through the staging image costs 48 registers: the 192x256
@@ -378,7 +378,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                         if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
-                        if (ep.nf_xg) nf_emit(t, m, o);
+                        if (FOLD && ep.nf_xg) nf_emit(t, m, o);
                     }
                 } else {  // short sequences (tiny configs): a wave's rows touch more than two sequences
 #pragma unroll
@@ -391,12 +391,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                         if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
-                        if (ep.nf_xg) nf_emit(t, m, o);
+                        if (FOLD && ep.nf_xg) nf_emit(t, m, o);
                     }
                 }
             }
         }
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 && FOLD) {
             if (ep.nf_xg) {
                 if (slot == 0) {  // one lane per row adds the wave's partial row sums (the wave's NTW * 32 of the N columns)
 #pragma unroll
@@ -448,7 +448,7 @@ __device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], voi
 }
 
 // smem: the workgroup's LDS (dead after the K loop; every wave stages MT*32 rows x 128 B in its own slice of it).
-template <int MODE, int MT, int NTW = 2>
+template <int MODE, int MT, int NTW = 2, bool FOLD = true>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem, void* __restrict__ Cv, int ldc, int M, int N,
                                               const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int wave, int lane,
                                               int bm = MT * 64, int bn = 128) {
@@ -458,8 +458,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem
         __builtin_amdgcn_s_barrier();  // every wave is done reading operand fragments: the stages may be overwritten
         char* stg = smem + wave * (MT * 32 * 128);
         float* xw = reinterpret_cast<float*>(smem + (bn / (NTW * 32)) * (bm / (MT * 32)) * (MT * 32 * 128));  // behind the last staging slice
-        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
-        else gemm_epilogue_wide<MODE, MT, NTW, false>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
+        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
     } else {
         gemm_epilogue_scalar<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
     }
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 asm volatile("" ::: "memory");
             }
         }
-        gemm_epilogue<MODE, MT, NTW>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+        gemm_epilogue<MODE, MT, NTW, !FP8>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's H rows are in L2
@@ -1197,6 +1197,7 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
     ep.wide_ok = al16(C) && (ldc % per16) == 0 && al16(ep.bias) && al16(ep.g1) && al16(ep.g2) && al16(ep.cvec) && (ep.g2_stride % 4) == 0;
     ACE_CHECK(ep.wide_ok, "gemm_mx: output / vectors must be 16-byte aligned");
     ACE_CHECK(al16(Aq) && al16(Wq) && al16(sa) && al16(sw), "gemm_mx: operands must be 16-byte aligned");
+    ACE_CHECK(!ep.nf_xg && !ep.nc_rowsq, "gemm_mx: the folded-norm epilogue exists in the bf16 kernels only");
     ep.clk_probe = 0;
     ep.ksplit = 1;
     ep.sk_ord = 0;

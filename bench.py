@@ -445,6 +445,21 @@ def main():
             vae.set_profile(False)
             result["roofline"]["vae_conv_tflops"] = vp["conv_flops"] / (vp["conv_ms"] * 1e-3) / 1e12 if vp["conv_ms"] > 0 else 0.0
             result["roofline"]["vae_conv_ms_per_pass"] = vp["conv_ms"]
+        if not args.fp8 and hasattr(dit, "set_norm_fold"):
+            # The GEMM launches of the default path also do the RMSNorm work of 71 of the 72 norms per forward (folded into their
+            # epilogues); the same launches without that work, for comparison with earlier rounds' fractions:
+            dit.set_norm_fold(False)
+            dit.set_profile(True)
+            one_pass(collective=False)
+            torch.cuda.synchronize()
+            q = dit.get_profile()
+            dit.set_profile(False)
+            dit.set_norm_fold(True)
+            q_tf = q["gemm_flops"] / (q["gemm_ms"] * 1e-3) / 1e12 if q["gemm_ms"] > 0 else 0.0
+            result["roofline"]["norm_fold"] = {
+                "default": "on: the residual GEMMs also write bf16(h*g) + row sums, the QKV / cross-q / gate|up GEMMs apply rstd + shift W^T; "
+                           "the standalone rmsnorm kernels (13.0 + 13.0 + 7.3 us per layer) are gone from the pass",
+                "gemm_ms_per_pass_norms_as_kernels": q["gemm_ms"], "achieved_norms_as_kernels": q_tf, "frac_norms_as_kernels": q_tf / peak}
         tr = result["roofline"]["traffic"]
         # HBM-side GB/s of the dominant kernel = PMC bytes per launch (committed profile of this command) / live launch time
         result["roofline"]["hbm_gbps"] = (tr / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9) if tr else None

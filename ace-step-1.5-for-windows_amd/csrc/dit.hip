@@ -832,6 +832,7 @@ int ace355_dit_finalize(ace355_dit* h) {
         if (!h->mod_tab) ALLOC(h->allocs, h->mod_tab, tab.size());
         ACE_HIP(hipMemcpy(h->mod_tab, tab.data(), tab.size() * sizeof(ModEntry), hipMemcpyHostToDevice));
     }
+    h->nf.key.clear();   // folded-norm bias tables are projections of the (possibly new) weights
     h->finalized = true;
     return ACE355_OK;
 }

@@ -31,6 +31,9 @@ def _close(a, b):
     return abs(a - b) <= 1e-9 * abs(b)
 
 
+GATE_G15 = 1e-2  # measured 3.47e-3 (folded and unfolded alike)
+
+
 def test_metric_shape_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
     """G11: AceStepDiTModel.forward (base.py:1303-1507) at N = 16 (8 conditional + 8 null_condition_emb.expand_as, :1905-1911),
     T = 750, L = 769: velocity of all 16 sequences + residual-stream taps after layers 0 and 23."""
@@ -112,6 +115,33 @@ def test_metric_batch_sampler_norm_fold_on_off(gpu_device, golden_dir, full_dit_
     assert torch.isfinite(outs[True]).all()
     assert r_on < 1e-2 and r_off < 1e-2 and r_ab < 6e-3, (r_on, r_off, r_ab)
     assert not torch.equal(outs[True], outs[False])  # the two paths really are different launch sequences
+
+
+def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
+    """G15: the reference's generate_audio over the WHOLE 27-step schedule at full size (B = 3 x 30 s, CFG 7 + APG: N = 6 sequences,
+    2250 token rows = big GEMM tiles + folded RMSNorm in the native sampler) against one ace355_dit_sample call, folded and unfolded."""
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g15_full_schedule_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    assert abs(wsum - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 3, 750
+    _, ctx1 = _inputs(B, T)
+    assert _close(float(ctx1.double().abs().sum()), float(G["ctx_sum"]))
+    ref = torch.from_numpy(G["out"])
+    res = {}
+    try:
+        for fold in (True, False):
+            dit.set_norm_fold(fold)
+            out = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G["seeds"].tolist(),
+                                   infer_steps=int(G["steps"]), diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
+            res[fold] = (_rel(out, ref), max(_rel(out[i], ref[i]) for i in range(B)))
+            assert torch.isfinite(out).all()
+    finally:
+        dit.set_norm_fold(True)
+    print(f"full-schedule sampler (B=3, 27 steps, CFG 7 + APG) vs reference fp32: folded {res[True][0]:.3e} (per item max {res[True][1]:.3e}), "
+          f"norms as kernels {res[False][0]:.3e} (per item max {res[False][1]:.3e})")
+    assert res[True][0] < GATE_G15 and res[False][0] < GATE_G15, res
 
 
 def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, full_dit_seed4):

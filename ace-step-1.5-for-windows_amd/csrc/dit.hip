@@ -98,6 +98,8 @@ struct ace355_dit {
     // shift's projection (shift W^T, precomputed for every step of the schedule at the start of the call) to its accumulators.
     struct NormFold {
         int enabled = 1;                 // ACE355_NORM_FOLD (default on)
+        int min_rows = 1536;             // ACE355_NORM_FOLD_MIN_ROWS: token rows below which the norms stay kernels (measured: at
+                                         // M = 750 folding costs 1.2 %: 5 us norm launches are cheaper than the producers' extra work)
         bool on = false;                 // the current sampler call runs folded
         int step = 0;                    // current step (row of the bias tables)
         int rows = 0;                    // steps of the tables
@@ -361,7 +363,7 @@ int time_embed(ace355_dit* h, const float* t, const float* tr, int rows, hipStre
 bool normfold_eligible(const ace355_dit* h, int steps, int M) {
     const int D = h->D, F = h->F, QD = h->QD, QKV = h->QD + 2 * h->KVD;
     const bool mx = h->precision == ACE355_PRECISION_MXFP8 && M >= h->mx_min_rows;
-    return h->nf.enabled && !mx && M >= 1536 && D % 256 == 0 && QKV % 256 == 0 && QD % 256 == 0 && (2 * F) % 256 == 0 && h->KVD % 128 == 0 &&
+    return h->nf.enabled && gemm_fold_supported() && !mx && M >= (h->nf.enabled >= 2 ? 64 : h->nf.min_rows) && D % 256 == 0 && QKV % 256 == 0 && QD % 256 == 0 && (2 * F) % 256 == 0 && h->KVD % 128 == 0 &&
            steps <= 1024;
 }
 // (allocation: outside any stream capture, next to ensure_workspace)
@@ -745,6 +747,7 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
     if (const char* e = getenv("ACE355_NORM_FOLD")) h->nf.enabled = atoi(e);
+    if (const char* e = getenv("ACE355_NORM_FOLD_MIN_ROWS")) h->nf.min_rows = atoi(e);
     *out = h;
     return ACE355_OK;
 }
@@ -1066,7 +1069,7 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
 
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable) {
     ACE_CHECK(h, "set_norm_fold: null handle");
-    h->nf.enabled = enable != 0;
+    h->nf.enabled = enable;   // 0 off, 1 default (big-M calls), 2 every call the kernels support (tests)
     h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
     return ACE355_OK;
 }

@@ -264,7 +264,9 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         constexpr int NT = MT * 4;  // 8-row groups per 32-column half
         const int rsub = lane >> 3, slot = lane & 7;
         const int rps = ep.rows_per_seq;
-        float nf_rs[NT];  // folded RMSNorm, producer side (mode 2): this lane group's row sums of h_new^2 over the wave's columns
+        // folded RMSNorm, producer side (mode 2).  Under an ordered split-K only the last part sees the finished h.
+        const bool nf_on = FOLD && MODE == 2 && ep.nf_xg && (ep.ksplit <= 1 || (int)blockIdx.y == ep.ksplit - 1);
+        float nf_rs[NT];  // this lane group's row sums of h_new^2 over the wave's columns
 #pragma unroll
         for (int t = 0; t < NT; ++t) nf_rs[t] = 0.f;
 #pragma unroll
@@ -351,7 +353,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 // load still left an `s_waitcnt vmcnt(0)` at the join, and vmcnt counts stores too - every 16-byte store of the
                 // residual update waited for the previous one's acknowledgement (25-28 k cycles per tile).
                 float4 ngA = {0.f, 0.f, 0.f, 0.f}, ngB = ngA;
-                if (FOLD && ep.nf_xg) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
+                if (nf_on) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
                 // the next norm's operand leaves with the row: xg = bf16(h_new * g) (8 lanes x 8 bytes = a 64-byte half line per row),
                 // the sum of h_new^2 over these 32 columns = the 8 lanes of the row adds up in nf_rs.  (Keeping the packed values until
                 // both column halves are done and writing whole 128-byte rows through the staging image costs 48 registers: the 192x256
@@ -378,7 +380,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                         if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
-                        if (FOLD && ep.nf_xg) nf_emit(t, m, o);
+                        if (nf_on) nf_emit(t, m, o);
                     }
                 } else {  // short sequences (tiny configs): a wave's rows touch more than two sequences
 #pragma unroll
@@ -391,13 +393,13 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
                         if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
-                        if (FOLD && ep.nf_xg) nf_emit(t, m, o);
+                        if (nf_on) nf_emit(t, m, o);
                     }
                 }
             }
         }
         if constexpr (MODE == 2 && FOLD) {
-            if (ep.nf_xg) {
+            if (nf_on) {
                 if (slot == 0) {  // one lane per row adds the wave's partial row sums (the wave's NTW * 32 of the N columns)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -966,6 +968,7 @@ static int gemm_variant() {
     }
     return v;
 }
+bool gemm_fold_supported() { return gemm_variant() != 1; }
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -1104,7 +1107,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     }
     if (ep.nf_xg || ep.nc_rowsq) {  // folded RMSNorm (dit.hip): lives in the wide epilogue only, whole tiles, no split-K
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        ACE_CHECK(variant != 1 && ep.wide_ok && N % bn == 0 && ep.ksplit == 1, "gemm: the folded-norm epilogue needs whole, 16-byte aligned tiles");
+        ACE_CHECK(variant != 1 && ep.wide_ok && N % bn == 0 && (ep.ksplit == 1 || ep.sk_ord), "gemm: the folded-norm epilogue needs whole, 16-byte aligned tiles");
         ACE_CHECK(!ep.nf_xg || (ep.mode == 2 && ep.nf_gA && ep.nf_gB && ep.nf_sqA && ep.nf_sqB && ep.nf_ldx % 8 == 0 && al16(ep.nf_xg) &&
                                 al16(ep.nf_gA) && al16(ep.nf_gB)), "gemm: folded-norm producer arguments");
         ACE_CHECK(!ep.nc_rowsq || ((ep.mode == 0 || ep.mode == 3 || ep.mode == 4) && al16(ep.nc_bias)), "gemm: folded-norm consumer arguments");

@@ -182,9 +182,10 @@ class NativeDit:
         with torch.cuda.device(self.device):
             native.check(self._lib.ace355_dit_set_precision(self._h, code), "dit_set_precision")
 
-    def set_norm_fold(self, enable: bool) -> None:
-        """RMSNorms folded into the neighbouring GEMM epilogues in big-M sampler calls (default on; include/ace355.h)."""
-        native.check(self._lib.ace355_dit_set_norm_fold(self._h, 1 if enable else 0), "dit_set_norm_fold")
+    def set_norm_fold(self, enable) -> None:
+        """RMSNorms folded into the neighbouring GEMM epilogues in big-M sampler calls (default on; include/ace355.h).
+        False / 0: off; True / 1: default (calls with >= 1536 token rows); 2: every call the kernels support."""
+        native.check(self._lib.ace355_dit_set_norm_fold(self._h, int(enable)), "dit_set_norm_fold")
 
     # ------------------------------------------------------------------ hipGraph replay of the sampler loop
     def set_graph(self, enable: bool) -> None:

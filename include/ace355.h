@@ -148,7 +148,8 @@ int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
  * whose launches take the big GEMM tiles (>= 1536 token rows, bf16 precision) the three RMSNorms of a decoder layer (base.py:493-533)
  * are not kernels of their own: the residual GEMM that finishes hidden_states also writes bf16(h * g) and the rows' sums of squares,
  * the consuming projection applies rsqrt(mean(h^2) + eps) and the modulation shift's projection (shift W^T, precomputed per step of
- * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently. */
+ * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently.
+ * enable: 0 off, 1 default (calls with >= 1536 token rows: below that the norm launches are cheaper), 2 every call (tests). */
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 
 /* Test / debug hook: after decoder layer `layer` (0-based) of every following forward, copy the fp32 residual stream

@@ -96,6 +96,32 @@ def test_tiny_sampler_vs_reference_golden(gpu_device, golden_dir, name):
     assert r < 5e-3, r
 
 
+def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
+    """The folded-RMSNorm path on the small-M launches (set_norm_fold(2): 4-wave tiles, ordered split-K where only the last K part emits
+    the next norm's operand) against the reference's 27-step golden and against the default path of the same call."""
+    from ace355 import weightgen
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
+    name = "cfg7_shift1"
+    cfg, w, dit = _make(TINY, int(G["seed"]), gpu_device)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=int(G["seed"]))
+    enc = torch.from_numpy(G[f"{name}_enc"])
+    ctx = torch.from_numpy(G[f"{name}_ctx"])
+    B = ctx.shape[0]
+    lo, hi = G[f"{name}_interval"].tolist()
+    kw = dict(seed=G[f"{name}_seeds"].tolist(), infer_steps=int(G[f"{name}_steps"]), diffusion_guidance_sale=float(G[f"{name}_guidance"]),
+              cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=G[f"{name}_timesteps"].tolist() or None)
+    ref = torch.from_numpy(G[f"{name}_out"])
+    plain = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+    dit.set_norm_fold(2)
+    folded = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+    again = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+    r_f, r_p, r_x = _rel(folded, ref), _rel(plain, ref), _rel(folded, plain)
+    print(f"tiny sampler, norm fold forced: folded vs reference {r_f:.3e}, default vs reference {r_p:.3e}, folded vs default {r_x:.3e}")
+    assert r_f < 5e-3 and r_p < 5e-3, (r_f, r_p)
+    assert torch.equal(folded, again) and not torch.equal(folded, plain)
+
+
 def test_tiny_sampler_cover_switch(gpu_device, golden_dir):
     from ace355 import weightgen
     from ace355.dit import generate_latents

@@ -115,6 +115,7 @@ static int hook_counters(GemmEpilogue& ep) {
     if (!cnt) {
         ACE_HIP(hipMalloc((void**)&cnt, SK_MAX_TILES * sizeof(int)));
         ACE_HIP(hipMemset(cnt, 0, SK_MAX_TILES * sizeof(int)));
+        if (int rc = gemm_verify_splitk_placement()) return rc;
     }
     ep.sk_cnt = cnt;
     return 0;

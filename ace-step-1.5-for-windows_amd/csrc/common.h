@@ -147,6 +147,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
 int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8_t* Wq, const uint32_t* sw, int sw_ld, void* C, int ldc,
                    int M, int N, int K, const GemmEpilogue& ep, hipStream_t s);
 bool gemm_mx_supported(int M, int N, int K, int mode);
+int gemm_verify_splitk_placement();   // one-time XCD placement check behind the small-M split-K (gemm.hip); handle constructors call it
 bool gemm_fold_supported();   // the folded-RMSNorm epilogue hooks exist in the kernels launch_gemm will use (not the v1 bring-up kernel)
 // x bf16 [M, K] (row stride ld) -> q fp8 e4m3 [M, K] + scales uint32 [K / 128][rows_pad] (rows_pad >= M, multiple of 4)
 int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t* scales, int rows_pad, hipStream_t s);

@@ -157,6 +157,7 @@ int ensure_rope(EncBase* h, int S, hipStream_t s) {
     if (!h->sk_cnt) {
         ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
         ACE_HIP(hipMemsetAsync(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int), s));
+        if (int prc = gemm_verify_splitk_placement()) return prc;
     }
     return 0;
 }

@@ -744,6 +744,7 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->flags_dev, 4);
     ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
     ACE_HIP(hipMemset(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int)));
+    if (int prc = gemm_verify_splitk_placement()) return prc;
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
     if (const char* e = getenv("ACE355_NORM_FOLD")) h->nf.enabled = atoi(e);

@@ -957,7 +957,34 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 }
 
 
+// Split-K placement probe: every workgroup of a (16, 2) grid reports the XCD it runs on (HW_REG_XCC_ID, bits 3:0).
+__global__ void xcd_probe_kernel(int* out) {
+    if (threadIdx.x == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
+}
+
 }  // namespace
+
+// The split-K parts of a tile (same blockIdx.x, consecutive blockIdx.y) exchange their share of H through L2, which is private to an
+// XCD: that is only right while both parts run on the same XCD.  The dispatcher places workgroup b on XCD b % 8 and the grids here
+// have gridDim.x % 8 == 0, but HIP promises no placement - so it is CHECKED once per process on the device in use (a (16, 2) probe grid:
+// same XCD for both blockIdx.y of every blockIdx.x, and XCD == blockIdx.x % 8).  Not verified (not run, or the check failed): launch_gemm
+// does not split K at all.  Called from the handle constructors (never under stream capture).
+static int g_splitk_ok = -1;  // -1 unknown, 0 refused, 1 verified
+int gemm_verify_splitk_placement() {
+    if (g_splitk_ok >= 0) return 0;
+    int* d = nullptr;
+    int h[32];
+    ACE_HIP(hipMalloc((void**)&d, sizeof(h)));
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(16, 2), dim3(64), 0, nullptr, d);
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) return hip_fail(e, "split-K placement probe", __FILE__, __LINE__);
+    bool ok = true;
+    for (int x = 0; x < 16; ++x) ok = ok && h[x] == h[16 + x] && h[x] == (h[0] + x) % 8;
+    g_splitk_ok = ok ? 1 : 0;
+    if (!ok) fprintf(stderr, "[ace355] workgroup -> XCD placement is not blockIdx %% 8 on this device: split-K launches disabled\n");
+    return 0;
+}
 
 static int gemm_variant() {
     static int v = -1;
@@ -1087,7 +1114,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     // parts use fp32 atomics and the last bits depend on the arrival order.  ACE355_GEMM_KSPLIT=1 disables the split.
     ep.ksplit = 1;
     ep.sk_ord = 0;
-    if (variant != 1 && ep.mode == 2 && big == 0) {
+    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1) {
         static int ks_env = -1;
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
         const int nk = K / BK;

@@ -22,6 +22,7 @@ struct MxW {  // MXFP8 copy of one packed projection (ace355_dit_set_precision):
     uint8_t* q = nullptr;
     uint32_t* sc = nullptr;
     int pad = 0;
+    int bit = 0;   // which projection (ACE355_MX_MASK: 1 qkv, 2 o_proj, 4 gate|up, 8 down, 16 cross q, 32 cross o)
 };
 struct LayerW {
     bf16_t *wqkv, *wo, *wq_c, *wkv_c, *wo_c, *wgu, *wdown;
@@ -265,7 +266,9 @@ int gemm_mx(ace355_dit* h, const bf16_t* A, int lda, const MxW& W, void* C, int 
     return launch_gemm_mx(h->xq, h->xs, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, ep, s);
 }
 bool mx_usable(const ace355_dit* h, const MxW& W, int M, int N, int K, int mode, int q_cols = 0, int qk_cols = 0) {
-    return h->precision == ACE355_PRECISION_MXFP8 && W.q && M >= h->mx_min_rows && gemm_mx_supported(M, N, K, mode) &&
+    static int mask = -1;  // ACE355_MX_MASK: subset of the projections that run in MXFP8 (error / time trade-offs)
+    if (mask < 0) { const char* e = getenv("ACE355_MX_MASK"); mask = e ? atoi(e) : 63; }
+    return h->precision == ACE355_PRECISION_MXFP8 && W.q && (mask & W.bit) && M >= h->mx_min_rows && gemm_mx_supported(M, N, K, mode) &&
            (mode != 4 || (q_cols % 256 == 0 && qk_cols % 256 == 0));
 }
 
@@ -1053,6 +1056,7 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
             return launch_mx_quant(w, K, N, K, out->q, out->sc, out->pad, nullptr);
         };
         for (LayerW& L : h->layers) {
+            L.mx_qkv.bit = 1; L.mx_o.bit = 2; L.mx_gu.bit = 4; L.mx_down.bit = 8; L.mx_qc.bit = 16; L.mx_oc.bit = 32;
             int rc = make(L.wqkv, h->QD + 2 * h->KVD, h->D, &L.mx_qkv);
             if (!rc) rc = make(L.wo, h->D, h->QD, &L.mx_o);
             if (!rc) rc = make(L.wgu, 2 * h->F, h->D, &L.mx_gu);

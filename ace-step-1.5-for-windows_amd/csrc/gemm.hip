@@ -928,7 +928,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 // whoever is waited for is already running.  The counter lives in L2 like the fp32 atomics it replaces.
                 if (tid == 0) {
                     const int tile = tm * tiles_n + tn;
-                    while (atomicAdd(ep.sk_cnt + tile, 0) != (int)blockIdx.y) __builtin_amdgcn_s_sleep(8);
+                    // (bounded: a counter left behind by a faulted launch must not hang the device; ~1 s, then the update goes ahead)
+                    for (int spins = 0; atomicAdd(ep.sk_cnt + tile, 0) != (int)blockIdx.y && spins < (1 << 20); ++spins) __builtin_amdgcn_s_sleep(8);
                 }
                 asm volatile("" ::: "memory");
             }

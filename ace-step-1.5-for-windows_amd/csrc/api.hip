@@ -277,6 +277,10 @@ static int attention_hook(const void* q, const void* k, const void* v, void* out
         a.out = (bf16_t*)out; a.o_seq_stride = (long)Sq * Hq * 128; a.o_row_stride = Hq * 128;
         a.N = N; a.Sq = Sq; a.Skv = Skv; a.Hq = Hq; a.Hkv = Hkv; a.window = window; a.scale = scale;
         a.kv_len = kvl; a.vmean = vmean;
+        // the hook lends the split-KV scratch the DiT handle lends (small problems then take the product's split path)
+        const long part_floats = 16L << 20;
+        ACE_HIP(hipMalloc(&t.p[3], (size_t)part_floats * sizeof(float)));
+        a.part = (float*)t.p[3]; a.part_floats = part_floats;
         rc = launch_attention(a, s);
     }
     hipError_t e = hipStreamSynchronize(s);

@@ -11,6 +11,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 
 namespace ace355 {
 
@@ -49,7 +50,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
     const unsigned long long t_entry = clock64();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+    const int ksp = a.kv_split > 1 ? a.kv_split : 1;
+    // (integer division runs on the VALU: readfirstlane tells hipcc the quotient is wave-uniform, the DMA helpers need SGPR operands)
+    const int qb = __builtin_amdgcn_readfirstlane((int)blockIdx.x / ksp), sp = (int)blockIdx.x - qb * ksp, h = blockIdx.y, n = blockIdx.z;
     const int hkv = h / (a.Hq / a.Hkv);
     const int q0 = qb * QB;
     const int lq = lane & 31, half = lane >> 5;
@@ -64,6 +67,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
     if (a.window >= 0) {
         kt_lo = max(0, q0 - a.window) / KB;
         kt_hi = min(kt_hi, (min(skv - 1, q0 + QB - 1 + a.window)) / KB + 1);
+    }
+    if (ksp > 1) {  // split-KV: this workgroup's share of the key tiles (possibly empty: it then leaves a neutral partial)
+        const int chunk = __builtin_amdgcn_readfirstlane((max(kt_hi - kt_lo, 0) + ksp - 1) / ksp);
+        kt_lo = kt_lo + sp * chunk;
+        kt_hi = min(kt_hi, kt_lo + chunk);
     }
     const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
     const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
@@ -268,6 +276,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
     }
     // O[q][d] = O^T[d][q] / l; register r of o[dt] is d = dt*32 + 16*(r>>3) + 8*half + (r&7)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (ksp > 1) {
+        // split-KV partial: row record = [128 x O (relative to m_run) | m_run | l | 2 pad] floats (16-byte aligned rows); attn_merge_kernel finishes the softmax
+        if (qrow < a.Sq) {
+            float* pr = a.part + ((((long)sp * a.N + n) * a.Hq + h) * a.Sq + qrow) * 132;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float* d8 = pr + dt * 32 + 16 * g + 8 * half;
+                    *reinterpret_cast<float4*>(d8 + 0) = make_float4(o[dt][8 * g + 0], o[dt][8 * g + 1], o[dt][8 * g + 2], o[dt][8 * g + 3]);
+                    *reinterpret_cast<float4*>(d8 + 4) = make_float4(o[dt][8 * g + 4], o[dt][8 * g + 5], o[dt][8 * g + 6], o[dt][8 * g + 7]);
+                }
+            if (half == 0) *reinterpret_cast<float2*>(pr + 128) = make_float2(m_run, l_tot);
+        }
+        return;
+    }
     const float inv = 1.f / l_tot;
     if (qrow < a.Sq && l_tot == 0.f) {
         // no valid key at all (only possible with kv_len): the reference's finfo.min mask makes this row uniform over ALL keys
@@ -290,6 +314,36 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(AttnArgs a, float sca
             }
     }
     if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_attn_probe[5] = clock64() - t_entry; }
+}
+
+// Split-KV merge: out[n][row][h*128 + d] = sum_s 2^(m_s - M) O_s[d] / sum_s 2^(m_s - M) l_s, M = max_s m_s (m in log2 units, as the
+// kernels keep it).  32 lanes per row (4 d each), parts summed in part order.
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part, int nsplit, int N, int Hq, int Sq, bf16_t* __restrict__ out,
+                                                         long o_seq_stride, int o_row_stride) {
+    const long unit = (long)blockIdx.x * 8 + (threadIdx.x >> 5);   // (n, h, row)
+    const int c = threadIdx.x & 31;
+    if (unit >= (long)N * Hq * Sq) return;
+    const int row = (int)(unit % Sq);
+    const int h = (int)((unit / Sq) % Hq);
+    const int n = (int)(unit / ((long)Sq * Hq));
+    const long stride = (long)N * Hq * Sq * 132;
+    const float* pr = part + unit * 132;
+    float M = -INFINITY;
+    for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, pr[s2 * stride + 128]);
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int s2 = 0; s2 < nsplit; ++s2) {
+        const float m = pr[s2 * stride + 128];
+        const float w = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - M);
+        const float4 v = *reinterpret_cast<const float4*>(pr + s2 * stride + 4 * c);
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        l += w * pr[s2 * stride + 129];
+    }
+    const float inv = 1.f / l;
+    uint2 pk;
+    pk.x = pack_bf2(acc.x * inv, acc.y * inv);
+    pk.y = pack_bf2(acc.z * inv, acc.w * inv);
+    *reinterpret_cast<uint2*>(out + (long)n * o_seq_stride + (long)row * o_row_stride + h * 128 + 4 * c) = pk;
 }
 
 // ------------------------------------------------------------------------------------------------ GQA-shared kernel
@@ -709,12 +763,39 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     int nw = (a.Sq >= 1024 && heads * ((a.Sq + 255) / 256) >= 512) ? 8 : 4;
     if (nw_env == 4 || nw_env == 8) nw = nw_env;
     const int qbk = nw * 32;
-    dim3 grid((a.Sq + qbk - 1) / qbk, a.Hq, a.N);
+    const int nqb = (a.Sq + qbk - 1) / qbk;
     AttnArgs ap = a;
     ap.clk_probe = clk;
+    // split-KV: few workgroups, each with a long serial walk over the key tiles (batch-1 requests) -> up to 8 workgroups per
+    // (q-block, head, sequence), at least two tiles each, about one workgroup per CU in total; needs the caller's scratch and no
+    // key-padding mask (the all-masked-row rule of the encoders lives in the one-pass epilogue)
+    ap.kv_split = 1;
+    {
+        static int split_env = -1;
+        if (split_env < 0) { const char* e = getenv("ACE355_ATTN_KVSPLIT"); split_env = e ? atoi(e) : 0; }  // 0 heuristic, 1 off, n forced
+        const long wgs = (long)nqb * heads;
+        int tiles = (a.Skv + KB - 1) / KB;
+        if (a.window >= 0) tiles = std::min(tiles, (qbk + 2 * a.window + KB - 1) / KB + 1);
+        int sp = 1;
+        // (measured at batch 1, S = 375: the 13-tile cross-attention walk 22.2 -> 13.9 + 5.2 us in 4 parts; the 6-tile self-attention
+        //  14.1 -> 12.9 + 5.1 us in 2 parts, a loss: the fp32 partials and the merge launch cost ~8 us, so only long walks split)
+        if (nw == 4 && a.part && !a.kv_len && !a.out_q && wgs < 128 && tiles >= 8) {
+            while (sp < 8 && wgs * sp * 2 <= 256 && tiles / (sp * 2) >= 2) sp *= 2;
+            if (split_env >= 1) sp = split_env;
+            if ((long)sp * a.N * a.Hq * a.Sq * 132 > a.part_floats) sp = 1;
+        }
+        ap.kv_split = sp;
+    }
+    dim3 grid(nqb * ap.kv_split, a.Hq, a.N);
     if (nw == 8) hipLaunchKernelGGL(attn3_kernel<8>, grid, dim3(512), 0, s, ap, scale_log2, thr);
     else hipLaunchKernelGGL(attn3_kernel<4>, grid, dim3(256), 0, s, ap, scale_log2, thr);
     ACE_LAUNCH_CHECK();
+    if (ap.kv_split > 1) {
+        const long units = (long)a.N * a.Hq * a.Sq;
+        hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, s, a.part, ap.kv_split, a.N, a.Hq, a.Sq, a.out,
+                           a.o_seq_stride, a.o_row_stride);
+        ACE_LAUNCH_CHECK();
+    }
     if (clk) {
         unsigned long long hh[8] = {0};
         ACE_HIP(hipStreamSynchronize(s));

@@ -175,6 +175,11 @@ struct AttnArgs {
     // [Hq][out_pad] words (a head's 128 columns = one K step, byte dt = columns 32 dt .. 32 dt + 31).  attn_gqa_kernel only
     // (attention_mx_out_ok); `out` is not written then.
     uint8_t* out_q; uint32_t* out_scales; int out_pad;
+    // split-KV for problems with too few workgroups to fill the chip (batch-1 requests: 48-96 workgroups walking 6-13 key tiles one
+    // after the other): the caller lends a scratch (part, part_floats); launch_attention then lets `kv_split` workgroups share the key
+    // tiles of one (q-block, head, sequence), each leaving un-normalised O (fp32), its running max and its row sum, and a second small
+    // kernel merges them (same result as one pass up to fp32 rounding; order fixed, so bit-reproducible).  kv_split is set by launch_attention.
+    float* part; long part_floats; int kv_split;
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 bool attention_mx_out_ok(const AttnArgs& a);  // will launch_attention take the kernel that can write MXFP8?

@@ -116,6 +116,8 @@ struct ace355_dit {
     } nf;
 
     int* sk_cnt = nullptr;   // ordered split-K turn counters lent to launch_gemm (GemmEpilogue::sk_cnt)
+    float* attn_part = nullptr;   // split-KV scratch lent to launch_attention (AttnArgs::part): small problems only
+    long attn_part_floats = 0;
 
     // profiling
     bool profile = false;
@@ -520,6 +522,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.N = N; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
             a.window = sliding ? h->cfg.sliding_window : -1;
             a.scale = scale;
+            a.part = h->attn_part; a.part_floats = h->attn_part_floats;
             if (mx_usable(h, W.mx_o, M, D, QD, 2) && attention_mx_out_ok(a)) {  // the o_proj MX GEMM's operand straight from the attention epilogue
                 a.out_q = h->xq; a.out_scales = h->xs; a.out_pad = h->xs_pad;
                 ao_is_mx = true;
@@ -579,6 +582,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.vt_head_stride = 128L * Lpad; a.vt_ld = Lpad;
             a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
             a.N = Nc; a.Sq = S; a.Skv = L; a.Hq = h->HQ; a.Hkv = h->KVH; a.window = -1; a.scale = scale;
+            a.part = h->attn_part; a.part_floats = h->attn_part_floats;
             if (mx_cross && mx_usable(h, W.mx_oc, Mc, D, QD, 2) && attention_mx_out_ok(a)) {
                 a.out_q = h->xq; a.out_scales = h->xs; a.out_pad = h->xs_pad;
                 cao_is_mx = true;
@@ -746,6 +750,8 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->sst_out, 2 * D);
     ALLOC(h->allocs, h->flags_dev, 4);
     ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
+    h->attn_part_floats = 16L << 20;   // 64 MB: 8 parts of a 2 x 16 x 375-row problem (12.7 M floats); larger problems do not split
+    ALLOC(h->allocs, h->attn_part, (size_t)h->attn_part_floats);
     ACE_HIP(hipMemset(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int)));
     if (int prc = gemm_verify_splitk_placement()) return prc;
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;

@@ -215,7 +215,11 @@ def test_headnorm_rope(lib, gpu_device, N, S, heads, rope):
     (16, 375, 375, 16, 8, -1), (16, 375, 375, 16, 8, 128), (8, 375, 769, 16, 8, -1), (16, 375, 769, 16, 8, -1),
     (12, 375, 375, 16, 8, 128),   # NWH = 4 (8 waves, 128-row blocks)
     # other group sizes stay on attn3_kernel: <8> (256-query blocks; Sq >= 1024 and heads x ceil(Sq / 256) >= 512) and <4>
-    (6, 1500, 1500, 16, 16, -1), (6, 1500, 1500, 16, 16, 128), (4, 375, 375, 8, 8, 128)])
+    (6, 1500, 1500, 16, 16, -1), (6, 1500, 1500, 16, 16, 128), (4, 375, 375, 8, 8, 128),
+    # batch-1 requests: few workgroups with long key walks (>= 8 tiles) take the split-KV path of attn3_kernel<4> + attn_merge_kernel
+    # ((2, 375, 769) above: 2 parts): the cross-attention of one conditional sequence (48 workgroups x 13 tiles -> 4 parts),
+    # configs[0]'s shapes (Sq = 125: 16 workgroups -> 4 parts; banded self-attention, not split), a ragged split (9 tiles in 4 parts)
+    (1, 375, 769, 16, 8, -1), (1, 125, 769, 16, 8, -1), (2, 125, 125, 16, 8, 16), (1, 200, 550, 4, 2, -1)])
 def test_attention(lib, gpu_device, N, Sq, Skv, Hq, Hkv, window):
     from oracle import dit as o_dit
     g = torch.Generator().manual_seed(Sq + Skv + Hq)

@@ -1,5 +1,6 @@
+"""fp32-store GEMM timing + check at the metric M (used for the four-wave tile experiment of DESIGN.md section 10; that kernel variant is not in the tree)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ace355
 from ace355 import native
 lib = native.lib(); dev = torch.device("cuda:0"); P = native.ptr

@@ -378,10 +378,11 @@ int normfold_reserve(ace355_dit* h, int steps, int N, int T, hipStream_t s) {
     if (!normfold_eligible(h, steps, M) || (steps <= nf.cap_rows && M <= nf.cap_M)) return 0;
     const int D = h->D, F = h->F, QKV = h->QD + 2 * h->KVD, NL = h->NL;
     ACE_HIP(hipStreamSynchronize(s));
+    const size_t R = std::max(steps, nf.cap_rows), MM = std::max<long>(M, nf.cap_M);
     for (void* q : nf.allocs) hipFree(q);
     nf.allocs.clear();
     nf.key.clear();
-    const size_t R = std::max(steps, nf.cap_rows), MM = std::max<long>(M, nf.cap_M);
+    nf.cap_rows = 0; nf.cap_M = 0;   // (an allocation failure below must not leave capacities that point at freed buffers)
     ALLOC(nf.allocs, nf.tfreq, 2 * R * 256);
     ALLOC(nf.allocs, nf.ta1, R * D);
     ALLOC(nf.allocs, nf.temb, R * D);
@@ -472,8 +473,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     // folded RMSNorm (sampler path): row sums of squares of the 3 NL norm inputs accumulate during this forward
     const bool fold = h->nf.on && temb_rows == 1 && M <= h->nf.cap_M;
     const auto& nf = h->nf;
-    auto rowsq = [&](int li, int which) { return nf.rowsq + ((size_t)li * 3 + which) * nf.cap_M; };
-    if (fold) ACE_HIP(hipMemsetAsync(nf.rowsq, 0, (size_t)h->NL * 3 * nf.cap_M * sizeof(unsigned long long), s));
+    auto rowsq = [&](int li, int which) { return nf.rowsq + ((size_t)li * 3 + which) * M; };   // (M <= cap_M: this forward's rows)
+    if (fold) ACE_HIP(hipMemsetAsync(nf.rowsq, 0, (size_t)h->NL * 3 * M * sizeof(unsigned long long), s));
     const float inv_d = 1.0f / (float)D;
 
     // patchify: Conv1d(192 -> D, k=2, s=2) == GEMM over [M, 384] (base.py:1358)

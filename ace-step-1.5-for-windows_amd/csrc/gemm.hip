@@ -405,7 +405,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     for (int t = 0; t < NT; ++t) {
                         const int m = mw0 + t * 8 + rsub;
                         if (ROWS_FULL || m < M)
-                            atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, (unsigned long long)(long long)(nf_rs[t] * 16777216.f));
+                            atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, (unsigned long long)(long long)fminf(nf_rs[t] * 16777216.f, 1.4e17f));  // (2^-24 units; capped at 2^57: 64 partials cannot wrap)
                     }
                 }
             }

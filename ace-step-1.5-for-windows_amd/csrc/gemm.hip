@@ -1229,7 +1229,11 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
     ACE_CHECK(ep.wide_ok, "gemm_mx: output / vectors must be 16-byte aligned");
     ACE_CHECK(al16(Aq) && al16(Wq) && al16(sa) && al16(sw), "gemm_mx: operands must be 16-byte aligned");
     ACE_CHECK(!ep.nf_xg && !ep.nc_rowsq, "gemm_mx: the folded-norm epilogue exists in the bf16 kernels only");
-    ep.clk_probe = 0;
+    {
+        static int clk = -1;
+        if (clk < 0) clk = env_int("ACE355_GEMM_CLK", 0);
+        ep.clk_probe = clk;
+    }
     ep.ksplit = 1;
     ep.sk_ord = 0;
     ep.mx_sa = sa; ep.mx_sw = sw; ep.mx_sa_ld = sa_ld; ep.mx_sw_ld = sw_ld;
@@ -1249,6 +1253,15 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
         default: launch_mx_mode<4>(s, A, Kh, W, Kh, C, ldc, M, N, Kh, ep, tiles_n, nwg); break;
     }
     ACE_LAUNCH_CHECK();
+    if (ep.clk_probe) {
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        ACE_HIP(hipStreamSynchronize(s));
+        ACE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), sizeof(h)));
+        if (h[1]) fprintf(stderr, "[ace355 gemm-mx clk] M=%d N=%d K=%d mode=%d: %.3f GHz shader clock, %.0f cycles / K-step of 128 (%.3f us); prologue %.0f, "
+                          "epilogue issue %.0f / acked %.0f cycles (last tile of workgroup 0)\n", M, N, K, ep.mode,
+                          (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2],
+                          (double)h[5], (double)h[3], (double)h[4]);
+    }
     return 0;
 }
 

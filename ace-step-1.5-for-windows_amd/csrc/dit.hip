@@ -466,9 +466,6 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     const int Nc = N - n_sc, Mc = Nc * S;
     const float* cconst = n_sc ? h->slots[slots[N - 1]].cross_const : nullptr;
 
-    // fold w * (1 + scale) and shift of the 2 * NL modulated norms for this forward's timestep rows (one launch)
-    rc = launch_mod_gs(h->mod_tab, 2 * h->NL, h->tproj, 6L * D, temb_rows, h->gs, D, s);
-    if (rc) return rc;
     const long gs_stride = temb_rows == 1 ? 0 : (long)h->NL * 4 * D;
     // folded RMSNorm (sampler path): row sums of squares of the 3 NL norm inputs accumulate during this forward
     const bool fold = h->nf.on && temb_rows == 1 && M <= h->nf.cap_M;
@@ -476,6 +473,16 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     auto rowsq = [&](int li, int which) { return nf.rowsq + ((size_t)li * 3 + which) * M; };   // (M <= cap_M: this forward's rows)
     if (fold) ACE_HIP(hipMemsetAsync(nf.rowsq, 0, (size_t)h->NL * 3 * M * sizeof(unsigned long long), s));
     const float inv_d = 1.0f / (float)D;
+    // (a folded call computed the TimestepEmbedding and the folded norm vectors of EVERY step when it built its bias tables: this step's
+    //  rows are used in place, and the sampler skips the per-step time_embed / mod_gs launches)
+    const float* tproj_p = fold ? nf.tproj + (size_t)nf.step * 6 * D : h->tproj;
+    const float* temb_p = fold ? nf.temb + (size_t)nf.step * D : h->temb;
+    const float* gs_p = fold ? nf.gs + (size_t)nf.step * h->NL * 4 * D : h->gs;
+    if (!fold) {
+        // fold w * (1 + scale) and shift of the 2 * NL modulated norms for this forward's timestep rows (one launch)
+        rc = launch_mod_gs(h->mod_tab, 2 * h->NL, h->tproj, 6L * D, temb_rows, h->gs, D, s);
+        if (rc) return rc;
+    }
 
     // patchify: Conv1d(192 -> D, k=2, s=2) == GEMM over [M, 384] (base.py:1358)
     ep = GemmEpilogue{1, h->b_in, nullptr, nullptr, 0, 0};
@@ -492,10 +499,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const bool fold_sa = fold && li > 0;   // layer 0's input comes from the patchify GEMM: its norm stays a kernel
         if (fold_sa) rc = 0;                   // xn = bf16(h * g) and the row sums were written by the previous layer's down projection
         else if (mx_qkv)  // the norm writes the MX GEMM's operand directly (fp8 + block scales): no bf16 xn round trip, no quantise pass
-            rc = launch_rmsnorm_gs_mx(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xq, h->xs, h->xs_pad,
+            rc = launch_rmsnorm_gs_mx(h->h, gs_p + (size_t)(li * 2 + 0) * 2 * D, gs_p + (size_t)(li * 2 + 0) * 2 * D + D, h->xq, h->xs, h->xs_pad,
                                       M, D, eps, gs_stride, S, s);
         else
-        rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 0) * 2 * D, h->gs + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, M, D, eps,
+        rc = launch_rmsnorm_gs(h->h, gs_p + (size_t)(li * 2 + 0) * 2 * D, gs_p + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, M, D, eps,
                                gs_stride, S, s);
         if (rc) return rc;
         // QKV projection with q / k head-norm + RoPE in its epilogue (mode 4; launch_gemm falls back to two kernels)
@@ -541,8 +548,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             rc = launch_attention(a, s);
             if (rc) return rc;
         }
-        ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, h->tproj + 2 * D, tstride, S, cconst ? cconst + (size_t)li * D : nullptr, Mc};
-        const float* g_mlp = h->gs + (size_t)(li * 2 + 1) * 2 * D;
+        ep = GemmEpilogue{2, nullptr, W.sst + 2 * D, tproj_p + 2 * D, tstride, S, cconst ? cconst + (size_t)li * D : nullptr, Mc};
+        const float* g_mlp = gs_p + (size_t)(li * 2 + 1) * 2 * D;
         if (fold) {  // conditional rows go on to the cross-attention norm (plain weight), the others straight to the MLP norm
             ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = Nc > 0 ? Mc : 0;
             ep.nf_gA = W.n_ca; ep.nf_sqA = rowsq(li, 1);
@@ -608,10 +615,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const bool mx_gu = mx_usable(h, W.mx_gu, M, 2 * F, D, 3) && D == 2048;
         if (fold) rc = 0;
         else if (mx_gu)
-            rc = launch_rmsnorm_gs_mx(h->h, h->gs + (size_t)(li * 2 + 1) * 2 * D, h->gs + (size_t)(li * 2 + 1) * 2 * D + D, h->xq, h->xs, h->xs_pad,
+            rc = launch_rmsnorm_gs_mx(h->h, gs_p + (size_t)(li * 2 + 1) * 2 * D, gs_p + (size_t)(li * 2 + 1) * 2 * D + D, h->xq, h->xs, h->xs_pad,
                                       M, D, eps, gs_stride, S, s);
         else
-        rc = launch_rmsnorm_gs(h->h, h->gs + (size_t)(li * 2 + 1) * 2 * D, h->gs + (size_t)(li * 2 + 1) * 2 * D + D, h->xn, M, D, eps,
+        rc = launch_rmsnorm_gs(h->h, gs_p + (size_t)(li * 2 + 1) * 2 * D, gs_p + (size_t)(li * 2 + 1) * 2 * D + D, h->xn, M, D, eps,
                                gs_stride, S, s);
         if (rc) return rc;
         ep = GemmEpilogue{3, nullptr, nullptr, nullptr, 0, 0};
@@ -626,10 +633,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         else if (mx_usable(h, W.mx_gu, M, 2 * F, D, 3)) rc = gemm_mx(h, h->xn, D, W.mx_gu, h->act, F, M, 2 * F, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
         if (rc) return rc;
-        ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, h->tproj + 5 * D, tstride, S};
+        ep = GemmEpilogue{2, nullptr, W.sst + 5 * D, tproj_p + 5 * D, tstride, S};
         if (fold && li + 1 < h->NL) {  // the next layer's self-attention norm operand
             ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = M;
-            ep.nf_gA = ep.nf_gB = h->gs + (size_t)((li + 1) * 2 + 0) * 2 * D; ep.nf_sqA = ep.nf_sqB = rowsq(li + 1, 0);
+            ep.nf_gA = ep.nf_gB = gs_p + (size_t)((li + 1) * 2 + 0) * 2 * D; ep.nf_sqA = ep.nf_sqB = rowsq(li + 1, 0);
         }
         if (act_q) rc = gemm_mx(h, nullptr, F, W.mx_down, h->h, D, M, D, F, ep, s, h->aq, h->as_);
         else if (mx_down) rc = gemm_mx(h, h->act, F, W.mx_down, h->h, D, M, D, F, ep, s);
@@ -639,7 +646,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     }
 
     // output norm + modulation with temb (base.py:1491-1496): shift = sst[0] + temb, scale = sst[1] + temb
-    rc = launch_rmsnorm_mod(h->h, h->norm_out, h->xn, M, D, eps, h->sst_out + D, h->temb, h->sst_out, h->temb,
+    rc = launch_rmsnorm_mod(h->h, h->norm_out, h->xn, M, D, eps, h->sst_out + D, temb_p, h->sst_out, temb_p,
                             temb_rows == 1 ? 0 : D, S, s);
     if (rc) return rc;
     // proj_out: ConvTranspose1d(D -> 64, k=2, s=2) == GEMM to [M, 128] == [N, 2S, 64] (base.py:1498)
@@ -678,8 +685,10 @@ int run_sampler_steps(ace355_dit* h, const ace355_sample_params* p, int B, int T
         }
         const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
         RoctxRange r_step("ace355.sampler_step");
-        rc = time_embed(h, &t_curr, &t_curr, 1, s);
-        if (rc) return rc;
+        if (!h->nf.on) {   // (a folded call already holds the embeddings of the whole schedule: forward_core reads row i)
+            rc = time_embed(h, &t_curr, &t_curr, 1, s);
+            if (rc) return rc;
+        }
         rc = forward_core(h, N, T, slots, 1, s);
         if (rc) return rc;
         const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;

@@ -102,6 +102,8 @@ struct ace355_dit {
         int min_rows = 1536;             // ACE355_NORM_FOLD_MIN_ROWS: token rows below which the norms stay kernels (measured: at
                                          // M = 750 folding costs 1.2 %: 5 us norm launches are cheaper than the producers' extra work)
         bool on = false;                 // the current sampler call runs folded
+        bool emb_on = false;             // the current sampler call reads its per-step timestep embeddings / norm vectors from the tables
+        bool bias_ok = false;            // bias tables match `key`
         int step = 0;                    // current step (row of the bias tables)
         int rows = 0;                    // steps of the tables
         int cap_rows = 0; long cap_M = 0;
@@ -375,7 +377,7 @@ bool normfold_eligible(const ace355_dit* h, int steps, int M) {
 int normfold_reserve(ace355_dit* h, int steps, int N, int T, hipStream_t s) {
     auto& nf = h->nf;
     const int S = (T + 1) / 2, M = N * S;
-    if (!normfold_eligible(h, steps, M) || (steps <= nf.cap_rows && M <= nf.cap_M)) return 0;
+    if (steps > 1024 || (steps <= nf.cap_rows && M <= nf.cap_M)) return 0;   // (every sampler call uses the embedding tables; the fold its bias tables)
     const int D = h->D, F = h->F, QKV = h->QD + 2 * h->KVD, NL = h->NL;
     ACE_HIP(hipStreamSynchronize(s));
     const size_t R = std::max(steps, nf.cap_rows), MM = std::max<long>(M, nf.cap_M);
@@ -401,24 +403,38 @@ int normfold_reserve(ace355_dit* h, int steps, int N, int T, hipStream_t s) {
 int normfold_prepare(ace355_dit* h, const ace355_sample_params* p, int N, int T, hipStream_t s) {
     auto& nf = h->nf;
     nf.on = false;
+    nf.emb_on = false;
     const int S = (T + 1) / 2, M = N * S, steps = p->num_steps;
     const int D = h->D, F = h->F, QKV = h->QD + 2 * h->KVD, NL = h->NL;
-    if (!normfold_eligible(h, steps, M) || steps > nf.cap_rows || M > nf.cap_M) return 0;
+    if (steps > nf.cap_rows || M > nf.cap_M) return 0;
+    static int tab_env = -1;   // ACE355_SCHED_TABLES=0: per-step time_embed / mod_gs launches as in round 1 (A/B; also switches the fold off)
+    if (tab_env < 0) { const char* e = getenv("ACE355_SCHED_TABLES"); tab_env = e ? atoi(e) : 1; }
+    if (!tab_env) return 0;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     if (cap != hipStreamCaptureStatusNone) nf.key.clear();   // a captured call always carries its own table build
     std::vector<float> key(p->t_sched_host, p->t_sched_host + steps);
+    int rc;
     if (key != nf.key || nf.rows != steps || nf.key_stream != s) {
-        int rc;
-        for (int r0 = 0; r0 < steps; r0 += 64) {   // TimestepEmbedding over the whole schedule, 64 rows per launch group
+        // TimestepEmbedding x2 and the folded norm vectors of the WHOLE schedule (64 rows per launch group): the per-step launches
+        // of the loop (8 small linears + mod_gs) become reads of row i
+        for (int r0 = 0; r0 < steps; r0 += 64) {
             const int nr = std::min(64, steps - r0);
-            // (the two embeddings' sinusoid rows of a chunk sit side by side in tfreq: give every chunk its own 2 x 64 x 256 block)
+            // (the two embeddings' sinusoid rows of a chunk sit side by side in tfreq: every chunk gets its own 2 x 64 x 256 block)
             rc = time_embed_into(h, p->t_sched_host + r0, p->t_sched_host + r0, nr, nf.tfreq + (size_t)2 * r0 * 256, nf.ta1 + (size_t)r0 * D,
                                  nf.temb + (size_t)r0 * D, nf.tsilu + (size_t)r0 * D, nf.tproj + (size_t)r0 * 6 * D, s);
             if (rc) return rc;
         }
         rc = launch_mod_gs(h->mod_tab, 2 * NL, nf.tproj, 6L * D, steps, nf.gs, D, s);
         if (rc) return rc;
+        nf.key = key;
+        nf.rows = steps;
+        nf.key_stream = s;
+        nf.bias_ok = false;
+    }
+    nf.emb_on = true;
+    if (!normfold_eligible(h, steps, M)) return 0;
+    if (!nf.bias_ok) {
         rc = launch_shift_rows(nf.gs, 2 * NL, steps, nf.shift, D, s);
         if (rc) return rc;
         for (int li = 0; li < NL; ++li) {
@@ -429,9 +445,7 @@ int normfold_prepare(ace355_dit* h, const ace355_sample_params* p, int N, int T,
             rc = gemm(h, nf.shift + (size_t)(li * 2 + 1) * steps * D, D, W.wgu, D, nf.bias_gu + (size_t)li * steps * 2 * F, 2 * F, steps, 2 * F, D, ep, s);
             if (rc) return rc;
         }
-        nf.key = key;
-        nf.rows = steps;
-        nf.key_stream = s;
+        nf.bias_ok = true;
     }
     nf.on = true;
     nf.step = 0;
@@ -473,12 +487,13 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     auto rowsq = [&](int li, int which) { return nf.rowsq + ((size_t)li * 3 + which) * M; };   // (M <= cap_M: this forward's rows)
     if (fold) ACE_HIP(hipMemsetAsync(nf.rowsq, 0, (size_t)h->NL * 3 * M * sizeof(unsigned long long), s));
     const float inv_d = 1.0f / (float)D;
-    // (a folded call computed the TimestepEmbedding and the folded norm vectors of EVERY step when it built its bias tables: this step's
-    //  rows are used in place, and the sampler skips the per-step time_embed / mod_gs launches)
-    const float* tproj_p = fold ? nf.tproj + (size_t)nf.step * 6 * D : h->tproj;
-    const float* temb_p = fold ? nf.temb + (size_t)nf.step * D : h->temb;
-    const float* gs_p = fold ? nf.gs + (size_t)nf.step * h->NL * 4 * D : h->gs;
-    if (!fold) {
+    // (a sampler call computed the TimestepEmbedding and the folded norm vectors of EVERY step up front: this step's rows are used in
+    //  place, and the loop has no per-step time_embed / mod_gs launches)
+    const bool emb = nf.emb_on && temb_rows == 1;
+    const float* tproj_p = emb ? nf.tproj + (size_t)nf.step * 6 * D : h->tproj;
+    const float* temb_p = emb ? nf.temb + (size_t)nf.step * D : h->temb;
+    const float* gs_p = emb ? nf.gs + (size_t)nf.step * h->NL * 4 * D : h->gs;
+    if (!emb) {
         // fold w * (1 + scale) and shift of the 2 * NL modulated norms for this forward's timestep rows (one launch)
         rc = launch_mod_gs(h->mod_tab, 2 * h->NL, h->tproj, 6L * D, temb_rows, h->gs, D, s);
         if (rc) return rc;
@@ -685,7 +700,7 @@ int run_sampler_steps(ace355_dit* h, const ace355_sample_params* p, int B, int T
         }
         const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
         RoctxRange r_step("ace355.sampler_step");
-        if (!h->nf.on) {   // (a folded call already holds the embeddings of the whole schedule: forward_core reads row i)
+        if (!h->nf.emb_on) {   // (normfold_prepare already computed the embeddings of the whole schedule: forward_core reads row i)
             rc = time_embed(h, &t_curr, &t_curr, 1, s);
             if (rc) return rc;
         }
@@ -855,7 +870,7 @@ int ace355_dit_finalize(ace355_dit* h) {
         if (!h->mod_tab) ALLOC(h->allocs, h->mod_tab, tab.size());
         ACE_HIP(hipMemcpy(h->mod_tab, tab.data(), tab.size() * sizeof(ModEntry), hipMemcpyHostToDevice));
     }
-    h->nf.key.clear();   // folded-norm bias tables are projections of the (possibly new) weights
+    h->nf.key.clear();   // embedding / bias tables are functions of the (possibly new) weights
     h->finalized = true;
     return ACE355_OK;
 }
@@ -946,6 +961,7 @@ int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, 
     rc = time_embed(h, t_host, t_r_host, N, s);
     if (rc) return rc;
     h->nf.on = false;   // the folded-norm bias tables exist per sampler schedule only
+    h->nf.emb_on = false;
     rc = forward_core(h, N, T, slots_host, N, s);
     if (rc) return rc;
     return launch_copy_v(h->vpad, v_out_dev, N, T, Tpad, s);

@@ -34,8 +34,8 @@ PEAK_MXFP8_TFLOPS = 5000.0  # dense MX-scaled fp8 MFMA (same guide; measured cei
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=30.0, help="seconds of audio per song")
     ap.add_argument("--infer-steps", type=int, default=27)
     ap.add_argument("--batch", type=int, default=8, help="songs per rank per step")

@@ -474,6 +474,25 @@ def main():
         result["achieved_tflops_executed"] = executed / 1e12 / (elapsed / args.steps)
         result["null_branch_shortcut_tflop_saved"] = (alg - executed) / 1e12
 
+    if rank == 0 and not args.no_roofline:
+        # board state while the DiT part of one more pass is in flight (rocm-smi, best effort): the same binary measures 493-549 ms per pass
+        # across the boxes of the pool, and sclk / package power under load say which kind of box a line came from
+        try:
+            import re
+            import subprocess
+            dit.set_condition(SLOT_COND, enc)
+            dit.set_condition(SLOT_NULL, null.reshape(1, -1), L=L)
+            _ = dit.sample(noise, ctx_shared[None].expand(B, -1, -1).contiguous(), ts, guidance_scale=args.guidance)   # queued, not awaited
+            out_smi = subprocess.run(["rocm-smi", "-d", str(device.index or 0), "--showclocks", "--showpower"], capture_output=True, text=True,
+                                     timeout=20).stdout
+            torch.cuda.synchronize()
+            sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out_smi)
+            pw = re.search(r"Power \(W\): ([0-9.]+)", out_smi)
+            result["gpu_state_under_load"] = {"sclk_mhz": int(sclk.group(1)) if sclk else None, "package_power_w": float(pw.group(1)) if pw else None,
+                                              "source": "rocm-smi during one extra untimed DiT pass"}
+        except Exception as e:  # no rocm-smi, no permission, ...: the line is complete without it
+            result["gpu_state_under_load"] = {"error": str(e)[:120]}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(args, dcfg, vcfg, sd, vsd, enc.cpu(), null.cpu(), ctx_shared.cpu()[None], T, L)
 

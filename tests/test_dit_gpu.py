@@ -340,6 +340,43 @@ def test_turbo_sampler_vs_reference_golden(gpu_device, golden_dir, name):
     assert r < (4e-3 if name.startswith("sde") else 2.5e-3), r  # measured 0.8e-3 (ode), 1.5e-3 (sde)
 
 
+def test_schedule_tables_equal_per_step_embeddings(gpu_device, golden_dir, tmp_path):
+    """A sampler call evaluates both TimestepEmbeddings and the folded norm vectors for its whole schedule up front (rows = steps) and
+    the loop reads row i; ACE355_SCHED_TABLES=0 keeps the per-step launches of round 1.  Same kernels, same per-row arithmetic: the two
+    must agree bit for bit (one fresh process per setting: the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import ace355\n"
+        "from ace355 import weightgen\n"
+        "from ace355.dit import NativeDit, generate_latents\n"
+        "G = np.load(%r)\n"
+        "kw = dict(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1)\n"
+        "cfg = ace355.DitConfig(**kw)\n"
+        "dit = NativeDit(cfg, torch.device('cuda:0'))\n"
+        "dit.load_state_dict(weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=int(G['seed']), mode='test'))\n"
+        "null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=int(G['seed']))\n"
+        "n = 'cfg7_shift1'\n"
+        "enc, ctx = torch.from_numpy(G[n + '_enc']), torch.from_numpy(G[n + '_ctx'])\n"
+        "lo, hi = G[n + '_interval'].tolist()\n"
+        "o = generate_latents(dit, null, enc.expand(ctx.shape[0], -1, -1), ctx, seed=G[n + '_seeds'].tolist(), infer_steps=int(G[n + '_steps']),\n"
+        "                     diffusion_guidance_sale=float(G[n + '_guidance']), cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[n + '_shift']))\n"
+        "np.save(sys.argv[1], o['target_latents'].float().cpu().numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f"{golden_dir}/g3_tiny_sampler.npz")
+    outs = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"lat{flag}.npy")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ACE355_SCHED_TABLES=flag), timeout=600)
+        outs[flag] = torch.from_numpy(np.load(out))
+    ref = torch.from_numpy(np.load(f"{golden_dir}/g3_tiny_sampler.npz")["cfg7_shift1_out"])
+    print(f"schedule tables on / off vs reference: {_rel(outs['1'], ref):.3e} / {_rel(outs['0'], ref):.3e}; on vs off max abs {float((outs['1'] - outs['0']).abs().max()):.1e}")
+    assert torch.equal(outs["1"], outs["0"])
+    assert _rel(outs["1"], ref) < 5e-3
+
+
 def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_path):
     """The QKV / cross-q GEMMs norm and rotate q, k in their epilogue (gemm.hip mode 4); tile shapes without that form, the v1
     kernel and ACE355_GEMM_HEADEPI=0 take GEMM + headnorm_rope_kernel(paired) instead.  Both must read the head-pair packing

@@ -64,30 +64,27 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                                                    int wave = 0) {
     const int frow = lane & 31, fhalf = lane >> 5;
     if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
+        // Folded RMSNorm, consumer side: the A operand was h * g (bf16); the row's rstd and the shift's projection complete
+        // rmsnorm(h) * g + shift on the fp32 accumulators: t = acc * rs_in[row] + nc_bias[col], applied WHERE a value is consumed (the
+        // head-norm's sum of squares, the pack loop).  lane = row (frow), register r = column 8 (r >> 2) + 4 fhalf + (r & 3).  The
+        // arithmetic is unconditional (rstd 1, bias 0 with the hooks off: x * 1 + 0 is x) and the accumulators are never written: an
+        // in-place update made hipcc move all 96 of them to VGPRs and spill (persistent QKV kernel: 192 B of scratch, epilogue 9.5 k ->
+        // 32 k cycles per tile, +19 us per launch even with the hooks OFF).
+        float rs_in[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rs_in[i] = 1.f;
         if (FOLD && ep.nc_rowsq) {
-            // folded RMSNorm, consumer side: the A operand was h * g (bf16); the row's rstd and the shift's projection complete
-            // rmsnorm(h) * g + shift on the fp32 accumulators.  lane = row (frow), register r = column 8 (r >> 2) + 4 fhalf + (r & 3).
-            float rs_in[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int m = mw0 + i * 32 + frow;
                 rs_in[i] = rsqrtf((float)(long long)ep.nc_rowsq[ROWS_FULL ? m : min(m, M - 1)] * (1.f / 16777216.f) * ep.nc_inv_d + ep.nc_eps);
             }
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 b = {0.f, 0.f, 0.f, 0.f};
-                    if (ep.nc_bias) b = ldf4(ep.nc_bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        acc[i][j][4 * g + 0] = acc[i][j][4 * g + 0] * rs_in[i] + b.x;
-                        acc[i][j][4 * g + 1] = acc[i][j][4 * g + 1] * rs_in[i] + b.y;
-                        acc[i][j][4 * g + 2] = acc[i][j][4 * g + 2] * rs_in[i] + b.z;
-                        acc[i][j][4 * g + 3] = acc[i][j][4 * g + 3] * rs_in[i] + b.w;
-                    }
-                }
         }
+        auto fold_bias = [&](int j, int g) -> float4 {   // nc_bias of this lane's 4 columns of group (j, g); zeros with the hooks off
+            float4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (FOLD && ep.nc_bias) bq = ldf4(ep.nc_bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+            return bq;
+        };
         // mode 4, q / k tiles (workgroup-uniform): per-row sum of squares over the head's 128 columns = this wave's 64 (two
         // half-rows in lanes l and l^32) + the neighbouring wave's 64, swapped through `xw`; then w * (v * rstd) and the
         // rotation of the adjacent (d, d+64) pairs, all on the fp32 accumulators (one bf16 rounding instead of two)
@@ -100,13 +97,22 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 hw = (nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk;
                 float ss[MT];
 #pragma unroll
+                for (int i = 0; i < MT; ++i) ss[i] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bq = fold_bias(j, g);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i) {
+                            const float t0 = __builtin_fmaf(acc[i][j][4 * g + 0], rs_in[i], bq.x), t1 = __builtin_fmaf(acc[i][j][4 * g + 1], rs_in[i], bq.y);
+                            const float t2 = __builtin_fmaf(acc[i][j][4 * g + 2], rs_in[i], bq.z), t3 = __builtin_fmaf(acc[i][j][4 * g + 3], rs_in[i], bq.w);
+                            ss[i] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+                        }
+                    }
+#pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) a += acc[i][j][r] * acc[i][j][r];
-                    ss[i] = a + __shfl_xor(a, 32, 64);
+                    ss[i] += __shfl_xor(ss[i], 32, 64);
                     if (lane < 32) xw[wave * (MT * 32) + i * 32 + frow] = ss[i];
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -157,25 +163,27 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         constexpr int RB = NJ * 64;                 // staged row bytes
         constexpr int J1 = NTW - 1;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const float4 bq = fold_bias(j, g);
+                float4 bu = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE == 3) bu = fold_bias(J1, g);
+                float4 bb = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (MODE != 4 && MODE != 3) {  // (the head epilogue takes no bias: launch_gemm checks)
+                    if (ep.bias) bb = ldf4(ep.bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+                }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int i = 0; i < MT; ++i) {
                     float v0, v1, v2, v3;
                     if constexpr (MODE == 3) {  // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up
-                        v0 = silu_f(acc[i][0][4 * g + 0]) * acc[i][J1][4 * g + 0];
-                        v1 = silu_f(acc[i][0][4 * g + 1]) * acc[i][J1][4 * g + 1];
-                        v2 = silu_f(acc[i][0][4 * g + 2]) * acc[i][J1][4 * g + 2];
-                        v3 = silu_f(acc[i][0][4 * g + 3]) * acc[i][J1][4 * g + 3];
+                        v0 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 0], rs_in[i], bq.x)) * __builtin_fmaf(acc[i][J1][4 * g + 0], rs_in[i], bu.x);
+                        v1 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 1], rs_in[i], bq.y)) * __builtin_fmaf(acc[i][J1][4 * g + 1], rs_in[i], bu.y);
+                        v2 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 2], rs_in[i], bq.z)) * __builtin_fmaf(acc[i][J1][4 * g + 2], rs_in[i], bu.z);
+                        v3 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 3], rs_in[i], bq.w)) * __builtin_fmaf(acc[i][J1][4 * g + 3], rs_in[i], bu.w);
                     } else {
-                        v0 = acc[i][j][4 * g + 0]; v1 = acc[i][j][4 * g + 1]; v2 = acc[i][j][4 * g + 2]; v3 = acc[i][j][4 * g + 3];
-                        if constexpr (MODE != 4) {  // (the head epilogue takes no bias: launch_gemm checks)
-                            if (ep.bias) {
-                                const float4 b = ldf4(ep.bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
-                                v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
-                            }
-                        }
+                        v0 = __builtin_fmaf(acc[i][j][4 * g + 0], rs_in[i], bq.x) + bb.x; v1 = __builtin_fmaf(acc[i][j][4 * g + 1], rs_in[i], bq.y) + bb.y;
+                        v2 = __builtin_fmaf(acc[i][j][4 * g + 2], rs_in[i], bq.z) + bb.z; v3 = __builtin_fmaf(acc[i][j][4 * g + 3], rs_in[i], bq.w) + bb.w;
                         if constexpr (MODE == 4) {
                             if (hn) {
                                 const int q8 = j * 4 + g;  // head-norm here (per-column weights broadcast over the rows) ...
@@ -189,7 +197,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     pk.y = pack_bf2(v2, v3);
                     *reinterpret_cast<uint2*>(stg + stage_off<RB>(i * 32 + frow, j * 4 + g) + 8 * fhalf) = pk;
                 }
-        }
+            }
         constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per staged row, rows per store instruction
         const int rsub = lane / LPR, slot = lane % LPR;
         bf16_t* out = reinterpret_cast<bf16_t*>(Cv) + (MODE == 3 ? (nw0 >> 1) : nw0) + slot * 8;

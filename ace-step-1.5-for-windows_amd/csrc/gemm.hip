@@ -61,7 +61,7 @@ __device__ __forceinline__ float dpp_add(float v) {
 template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
 __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
-                                                   int wave = 0) {
+                                                   int wave = 0, int wnw = 1) {
     const int frow = lane & 31, fhalf = lane >> 5;
     if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
         // Folded RMSNorm, consumer side: the A operand was h * g (bf16); the row's rstd and the shift's projection complete
@@ -410,13 +410,24 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
             }
         }
         if constexpr (MODE == 2 && FOLD) {
-            if (nf_on) {
-                if (slot == 0) {  // one lane per row adds the wave's partial row sums (the wave's NTW * 32 of the N columns)
+            if (nf_on) {   // (workgroup-uniform)
+                // the N-waves of a workgroup hold partial sums of the SAME rows: they meet in LDS (xw, behind the staging slices) and one
+                // wave per row block issues the atomics - a quarter of them (8 / 16 per row instead of 32 / 64)
+                if (slot == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) xw[wave * (MT * 32) + t * 8 + rsub] = nf_rs[t];
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_s_barrier();
+                const int wn = wave % wnw;
+                if (wn == 0 && slot == 0) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
+                        float tot = 0.f;
+                        for (int k = 0; k < wnw; ++k) tot += xw[(wave + k) * (MT * 32) + t * 8 + rsub];   // (fixed order)
                         const int m = mw0 + t * 8 + rsub;
                         if (ROWS_FULL || m < M)
-                            atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, (unsigned long long)(long long)fminf(nf_rs[t] * 16777216.f, 1.4e17f));  // (2^-24 units; capped at 2^57: 64 partials cannot wrap)
+                            atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, (unsigned long long)(long long)fminf(tot * 16777216.f, 1.4e17f));  // (2^-24 units; capped at 2^57: the partials of a row cannot wrap)
                     }
                 }
             }
@@ -471,8 +482,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem
         __builtin_amdgcn_s_barrier();  // every wave is done reading operand fragments: the stages may be overwritten
         char* stg = smem + wave * (MT * 32 * 128);
         float* xw = reinterpret_cast<float*>(smem + (bn / (NTW * 32)) * (bm / (MT * 32)) * (MT * 32 * 128));  // behind the last staging slice
-        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
-        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave);
+        const int wnw = bn / (NTW * 32);
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
+        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
     } else {
         gemm_epilogue_scalar<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
     }

@@ -325,56 +325,170 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         return outputs
 
     # ------------------------------------------------------------------ generate_music
-    def generate_music(self, encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor, seed=None,
+    def generate_music(self, encoder_hidden_states: Optional[torch.Tensor], context_latents: Optional[torch.Tensor], seed=None,
                        inference_steps: int = 27, guidance_scale: float = 7.0, shift: float = 1.0, infer_method: str = "ode",
                        timesteps=None, use_tiled_decode: bool = True, latent_shift: float = 0.0, latent_rescale: float = 1.0,
                        cfg_interval_start: float = 0.0, cfg_interval_end: float = 1.0, use_adg: bool = False,
-                       progress=None, **service_kwargs) -> Dict[str, Any]:
+                       progress=None, data_parallel: bool = False, **service_kwargs) -> Dict[str, Any]:
         """Counterpart of ``AceStepHandler.generate_music`` (handler/generate_music.py:22-190) from prepared conditions.
-        Never raises: every exception becomes the reference's error payload."""
+        Never raises: every exception becomes the reference's error payload.
+
+        ``data_parallel=True`` inside an initialised ``torch.distributed`` group (one process per GPU, every rank holding an
+        initialised handler): rank 0 passes the request of G songs (one seed per song), the other ranks pass ``None`` tensors;
+        the request is broadcast once, each rank generates its contiguous slice (``ace355.dist.run_request``: 8/4/2/1 songs
+        per rank for a batch of 8 on 1/2/4/8 GPUs) and rank 0 returns the payload with all G songs in order (the other ranks
+        return theirs).  The per-call cap of 8 (handler/service_generate_request.py:12) then holds per rank."""
+        if data_parallel:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                return self._generate_music_data_parallel(
+                    encoder_hidden_states, context_latents, seed, progress,
+                    dict(inference_steps=inference_steps, guidance_scale=guidance_scale, shift=shift, cfg_interval_start=cfg_interval_start,
+                         cfg_interval_end=cfg_interval_end, use_adg=float(bool(use_adg)), infer_method_sde=float(infer_method == "sde")),
+                    dict(timesteps=timesteps, use_tiled_decode=use_tiled_decode, latent_shift=latent_shift, latent_rescale=latent_rescale,
+                         **service_kwargs))
         try:
-            if progress:
-                progress(0.52, desc="Generating music...")
-            outputs = self.service_generate(encoder_hidden_states, context_latents, seed=seed, infer_steps=inference_steps,
-                                            guidance_scale=guidance_scale, shift=shift, infer_method=infer_method,
-                                            timesteps=timesteps, cfg_interval_start=cfg_interval_start,
-                                            cfg_interval_end=cfg_interval_end, use_adg=use_adg, **service_kwargs)
-            pred_latents, time_costs = self._prepare_decode_state(outputs, latent_shift, latent_rescale)
-            if progress:
-                progress(0.8, desc="Decoding audio...")
-            t0 = time.time()
-            with torch.inference_mode():
-                pred_latents_cpu = pred_latents.detach().cpu()
-                z = pred_latents.transpose(1, 2).contiguous()  # handler/generate_music_decode.py:123
-                pred_wavs = self.tiled_decode(z) if use_tiled_decode else self._native_vae_decode(z)
-                if pred_wavs.dtype != torch.float32:
-                    pred_wavs = pred_wavs.float()
-                if pred_wavs.is_cuda:
-                    from .vae import peak_normalize
-                    pred_wavs = peak_normalize(pred_wavs.contiguous())
-                else:
-                    peak = pred_wavs.abs().amax(dim=[1, 2], keepdim=True)
-                    if torch.any(peak > 1.0):
-                        pred_wavs = pred_wavs / peak.clamp(min=1.0)
-                if pred_wavs.is_cuda:
-                    torch.cuda.synchronize(pred_wavs.device)
-            time_costs["vae_decode_time_cost"] = time.time() - t0
-            time_costs["total_time_cost"] = time_costs["total_time_cost"] + time_costs["vae_decode_time_cost"]
-            time_costs["offload_time_cost"] = self.current_offload_cost
-            B = pred_wavs.shape[0]
-            audios = [{"tensor": pred_wavs[i].cpu(), "sample_rate": self.sample_rate} for i in range(B)]
-            seed_value = seed[0] if isinstance(seed, (list, tuple)) and seed else seed
-            extra = {"pred_latents": pred_latents_cpu, "target_latents": None,
-                     "src_latents": outputs["src_latents"].detach().cpu(), "chunk_masks": None, "latent_masks": None, "spans": [],
-                     "time_costs": time_costs, "seed_value": seed_value,
-                     "encoder_hidden_states": outputs["encoder_hidden_states"].detach().cpu(), "encoder_attention_mask": None,
-                     "context_latents": outputs["context_latents"].detach().cpu(), "lyric_token_idss": None}
-            return {"audios": audios, "status_message": "Generation completed successfully!", "extra_outputs": extra,
-                    "success": True, "error": None}
+            payload, _ = self._generate_music_local(encoder_hidden_states, context_latents, seed, inference_steps, guidance_scale, shift,
+                                                    infer_method, timesteps, use_tiled_decode, latent_shift, latent_rescale,
+                                                    cfg_interval_start, cfg_interval_end, use_adg, progress, service_kwargs)
+            return payload
         except Exception as exc:  # handler/generate_music.py:181-190
-            logger.exception("[generate_music] Generation failed")
-            return {"audios": [], "status_message": f"Error: {exc!s}\n{traceback.format_exc()}", "extra_outputs": {},
-                    "success": False, "error": f"{exc!s}"}
+            return self._error_payload(exc)
+
+    @staticmethod
+    def _error_payload(exc) -> Dict[str, Any]:
+        logger.exception("[generate_music] Generation failed")
+        return {"audios": [], "status_message": f"Error: {exc!s}\n{traceback.format_exc()}", "extra_outputs": {},
+                "success": False, "error": f"{exc!s}"}
+
+    def _generate_music_local(self, encoder_hidden_states, context_latents, seed, inference_steps, guidance_scale, shift, infer_method,
+                              timesteps, use_tiled_decode, latent_shift, latent_rescale, cfg_interval_start, cfg_interval_end, use_adg,
+                              progress, service_kwargs):
+        """The single-GPU body: service_generate -> _prepare_decode_state -> tiled_decode -> peak normalise -> payload.
+        Returns (payload, waveforms on the device [B, 2, samples]); raises on failure."""
+        if progress:
+            progress(0.52, desc="Generating music...")
+        outputs = self.service_generate(encoder_hidden_states, context_latents, seed=seed, infer_steps=inference_steps,
+                                        guidance_scale=guidance_scale, shift=shift, infer_method=infer_method,
+                                        timesteps=timesteps, cfg_interval_start=cfg_interval_start,
+                                        cfg_interval_end=cfg_interval_end, use_adg=use_adg, **service_kwargs)
+        pred_latents, time_costs = self._prepare_decode_state(outputs, latent_shift, latent_rescale)
+        if progress:
+            progress(0.8, desc="Decoding audio...")
+        t0 = time.time()
+        with torch.inference_mode():
+            pred_latents_cpu = pred_latents.detach().cpu()
+            z = pred_latents.transpose(1, 2).contiguous()  # handler/generate_music_decode.py:123
+            pred_wavs = self.tiled_decode(z) if use_tiled_decode else self._native_vae_decode(z)
+            if pred_wavs.dtype != torch.float32:
+                pred_wavs = pred_wavs.float()
+            if pred_wavs.is_cuda:
+                from .vae import peak_normalize
+                pred_wavs = peak_normalize(pred_wavs.contiguous())
+            else:
+                peak = pred_wavs.abs().amax(dim=[1, 2], keepdim=True)
+                if torch.any(peak > 1.0):
+                    pred_wavs = pred_wavs / peak.clamp(min=1.0)
+            if pred_wavs.is_cuda:
+                torch.cuda.synchronize(pred_wavs.device)
+        time_costs["vae_decode_time_cost"] = time.time() - t0
+        time_costs["total_time_cost"] = time_costs["total_time_cost"] + time_costs["vae_decode_time_cost"]
+        time_costs["offload_time_cost"] = self.current_offload_cost
+        B = pred_wavs.shape[0]
+        audios = [{"tensor": pred_wavs[i].cpu(), "sample_rate": self.sample_rate} for i in range(B)]
+        seed_value = seed[0] if isinstance(seed, (list, tuple)) and seed else seed
+        extra = {"pred_latents": pred_latents_cpu, "target_latents": None,
+                 "src_latents": outputs["src_latents"].detach().cpu(), "chunk_masks": None, "latent_masks": None, "spans": [],
+                 "time_costs": time_costs, "seed_value": seed_value,
+                 "encoder_hidden_states": outputs["encoder_hidden_states"].detach().cpu(), "encoder_attention_mask": None,
+                 "context_latents": outputs["context_latents"].detach().cpu(), "lyric_token_idss": None}
+        return ({"audios": audios, "status_message": "Generation completed successfully!", "extra_outputs": extra,
+                 "success": True, "error": None}, pred_wavs)
+
+    def _generate_music_data_parallel(self, encoder_hidden_states, context_latents, seed, progress, knobs, local_kwargs) -> Dict[str, Any]:
+        """One request over every rank of the process group (``ace355.dist.run_request``).  A failure on ANY rank becomes the error
+        payload on EVERY rank: the ranks agree on success (one MAX all-reduce) before the gather, so nobody waits in a
+        collective the failed rank never joins."""
+        import torch.distributed as dist
+        from . import dist as a_dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        err: Optional[BaseException] = None
+        request = None
+        state: Dict[str, Any] = {}
+        try:
+            if rank == 0:
+                if encoder_hidden_states is None or context_latents is None:
+                    raise ValueError("data_parallel: rank 0 must pass the request tensors")
+                G = max(encoder_hidden_states.shape[0], context_latents.shape[0])
+                if not isinstance(seed, (list, tuple)) or len(seed) != G or any(s is None or int(s) < 0 for s in seed):
+                    raise ValueError("data_parallel: one explicit seed per song is required (per-item generators make a song "
+                                     "independent of the rank it runs on; a scalar seed couples the batch, base.py:1733-1770)")
+                if G > MAX_BATCH_SIZE * world:
+                    raise ValueError(f"batch size {G} exceeds the per-call cap of {MAX_BATCH_SIZE} on {world} ranks")
+                request = a_dist.pack_request(encoder_hidden_states, context_latents, [int(s) for s in seed], None, **knobs)
+        except Exception as exc:
+            err = exc
+        # (rank 0 could not even build the request: the others learn it from an empty one)
+        if rank == 0 and request is None:
+            request = {"enc_rows": torch.zeros(0, 1, 1), "enc_index": torch.zeros(0, dtype=torch.int32), "ctx": torch.zeros(1, 1, 2),
+                       "seeds": torch.zeros(0, dtype=torch.int64), "knobs": torch.zeros(len(a_dist.KNOBS), dtype=torch.float64)}
+
+        def execute(local):
+            k = local["knobs"]
+            payload, wavs = self._generate_music_local(
+                local["encoder_hidden_states"], local["context_latents"], local["seeds"], int(k["inference_steps"]), k["guidance_scale"],
+                k["shift"], "sde" if k["infer_method_sde"] else "ode", local_kwargs.get("timesteps"), local_kwargs.get("use_tiled_decode", True),
+                local_kwargs.get("latent_shift", 0.0), local_kwargs.get("latent_rescale", 1.0), k["cfg_interval_start"], k["cfg_interval_end"],
+                bool(k["use_adg"]), progress if rank == 0 else None,
+                {kk: v for kk, v in local_kwargs.items() if kk not in ("timesteps", "use_tiled_decode", "latent_shift", "latent_rescale")})
+            state["payload"] = payload
+            return wavs
+
+        res = None
+        try:
+            res = a_dist.run_request(request, lambda local: self._dp_guard(execute, local, state), src=0, device=torch.device(self.device), gather=False)
+        except Exception as exc:
+            err = err or exc
+        if err is None and "error" in state:
+            err = state["error"]
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=torch.device(self.device))
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            return self._error_payload(err if err is not None else RuntimeError("generation failed on another rank"))
+        wavs = res["local"]
+        if wavs is None:   # this rank owns no song
+            wavs = torch.empty(0, 2, 0, device=torch.device(self.device))
+        # song-major gather to rank 0 (samples per song are equal: one request, one duration)
+        n = torch.tensor([wavs.shape[0], wavs.shape[-1]], dtype=torch.int64, device=wavs.device)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        payload = state.get("payload") or {"audios": [], "status_message": "Generation completed successfully!", "extra_outputs": {},
+                                           "success": True, "error": None}
+        if rank != 0:
+            if wavs.numel():
+                dist.send(wavs.contiguous(), dst=0)
+            payload["extra_outputs"]["song_range"] = res["range"]
+            return payload
+        audios = list(payload["audios"])
+        for r in range(1, world):
+            b, smp = int(sizes[r][0]), int(sizes[r][1])
+            if b * smp == 0:
+                continue
+            buf = torch.empty(b, wavs.shape[1], smp, dtype=wavs.dtype, device=wavs.device)
+            dist.recv(buf, src=r)
+            audios += [{"tensor": buf[i].cpu(), "sample_rate": self.sample_rate} for i in range(b)]
+        payload["audios"] = audios
+        payload["extra_outputs"]["song_range"] = res["range"]
+        payload["extra_outputs"]["data_parallel"] = {"world": world, "global_batch": res["global_batch"]}
+        return payload
+
+    @staticmethod
+    def _dp_guard(execute, local, state):
+        try:
+            return execute(local)
+        except Exception as exc:  # reported through the all-reduce of the caller, not raised past the collectives
+            state["error"] = exc
+            return None
 
     def _prepare_decode_state(self, outputs: Dict[str, Any], latent_shift: float, latent_rescale: float):
         """handler/generate_music_decode.py:16-96: NaN/Inf and all-zero guards, latent * rescale + shift."""

@@ -132,10 +132,17 @@ struct GemmEpilogue {
     // (nc_bias = shift W^T, fp32 [N], NULL for an un-shifted norm) ahead of the mode's own epilogue.  Wide epilogue only (launch_gemm checks).
     bf16_t* nf_xg; int nf_ldx; int nf_split;
     const float* nf_gA; const float* nf_gB;
-    // split-K (mode 2) in part order instead of fp32 atomics: the caller lends a zeroed counter array (SK_MAX_TILES ints, one stream at a
+    // split-K (mode 2) in part order instead of fp32 atomics: the caller lends a zeroed counter array (SK_CNT_INTS ints, one stream at a
     // time); part y of a tile waits until parts 0 .. y-1 have added their share to H, then does the plain read-modify-write itself, so
     // the sum has one order and the result is bit-reproducible.  sk_ord is set by launch_gemm.  NULL: the atomics path.
     int* sk_cnt; int sk_ord;
+    // slab split-K (every mode, small-M launches; round 3): the K range is cut into `kparts` parts over blockIdx.y; parts 0 .. kparts-2
+    // park their raw fp32 accumulators in `sk_slab` (per-lane layout, 16-byte coalesced; the parts of a tile run on one XCD, so the slab
+    // lives in that XCD's L2) and bump the tile's counter in sk_cnt; the LAST part (dispatched last, so everybody it waits for is resident)
+    // adds them to its own accumulators in part order - one summation order, bit-reproducible - and runs the normal epilogue ONCE
+    // (ksplit stays 1: no atomics, no serialised read-modify-writes of H).  kparts / sk_slab are set by launch_gemm; the caller lends
+    // sk_slab_cap floats.
+    float* sk_slab; long sk_slab_cap; int kparts;
     unsigned long long* nf_sqA; unsigned long long* nf_sqB;   // 2^-24 fixed point: integer adds commute, so the sums (and with them
     const unsigned long long* nc_rowsq; const float* nc_bias;  // every result) do not depend on the order the atomics arrive in
     float nc_inv_d, nc_eps;
@@ -154,6 +161,12 @@ int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t
 inline int mx_rows_pad(int rows) { return ((rows + 255) / 256) * 256 + 256; }
 
 constexpr int SK_MAX_TILES = 4096;
+constexpr long SK_SLAB_FLOATS = 8L << 20;   // slab a handle lends for the slab split-K: 32 MB = 341 parked 192x128 accumulator tiles
+constexpr int SK_CNT_INTS = SK_MAX_TILES + 8;   // size of a turn-counter array: the tiles' counters + [SK_MAX_TILES] = missed-turn count
+// A part that waited ~1 s for its turn (a counter left behind by a faulted launch, or a placement the one-time probe did not see)
+// goes ahead so the device cannot hang, but counts the event in sk_cnt[SK_MAX_TILES]: gemm_splitk_poll reads it (stream sync), and on a
+// non-zero count re-zeroes the counters and reports an error - the residual stream of that call is not trustworthy.
+int gemm_splitk_poll(int* sk_cnt, hipStream_t s);
 
 struct AttnArgs {
     const bf16_t* q; long q_seq_stride; int q_row_stride;           // q[n][s][h*128 + d]
@@ -264,6 +277,9 @@ struct ConvArgs {
     long y_shift; long y_valid;                                  // flat index valid iff 0 <= flat < y_valid (transposed conv crop)
     int out_mode;                                                // 0: bf16 NLC flat; 1: f32 NCL [b][n][m] (n < n_real)
     int n_real;
+    // out_mode 1, windowed (chunked decode): rows m in [ncl_m_lo, ncl_m_hi) land at y[b][n][ncl_off + m - ncl_m_lo] with row pitch
+    // ncl_ld; ncl_ld == 0: the whole tensor (pitch M, every row)
+    long ncl_ld; long ncl_off; int ncl_m_lo; int ncl_m_hi;
     int wide_ok;                                                 // set by launch_conv: y / res / strides allow the 16-byte staged epilogue
     int clk_probe;                                               // ACE355_CONV_CLK=1: one workgroup records its shader-clock phases
     // fused residual unit (Cin = N = 128, plain conv): y = res + bias2 + w2 . snake2(conv(x) + bias), w2 [N][1][N]: the k = 1

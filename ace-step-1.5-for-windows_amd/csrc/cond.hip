@@ -155,8 +155,8 @@ int ensure_rope(EncBase* h, int S, hipStream_t s) {
     if (rc) return rc;
     h->rope_S = cap;
     if (!h->sk_cnt) {
-        ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
-        ACE_HIP(hipMemsetAsync(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int), s));
+        ALLOC(h->allocs, h->sk_cnt, SK_CNT_INTS);
+        ACE_HIP(hipMemsetAsync(h->sk_cnt, 0, SK_CNT_INTS * sizeof(int), s));
         if (int prc = gemm_verify_splitk_placement()) return prc;
     }
     return 0;

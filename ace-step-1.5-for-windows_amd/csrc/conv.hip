@@ -361,7 +361,11 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     if (a.res) v += bf2f(a.res[(long)b * a.res_batch_stride + flat]);
                     reinterpret_cast<bf16_t*>(a.y)[(long)b * a.y_batch_stride + flat] = f2bf(v);
                 } else {  // f32 NCL [b][n][m]
-                    if (n < a.n_real) reinterpret_cast<float*>(a.y)[(long)b * a.y_batch_stride + (long)n * a.M + m] = v;
+                    if (n < a.n_real) {
+                        if (a.ncl_ld == 0) reinterpret_cast<float*>(a.y)[(long)b * a.y_batch_stride + (long)n * a.M + m] = v;
+                        else if (m >= a.ncl_m_lo && m < a.ncl_m_hi)
+                            reinterpret_cast<float*>(a.y)[(long)b * a.y_batch_stride + (long)n * a.ncl_ld + a.ncl_off + (m - a.ncl_m_lo)] = v;
+                    }
                 }
             }
     }

@@ -84,6 +84,8 @@ struct ace355_dit {
     hipEvent_t graph_in = nullptr, graph_out = nullptr;  // cannot be captured): ordered against the caller's by two events
     long ws_epoch = 0, cond_epoch = 0;   // bumped when workspace / condition-slot memory moves or changes shape
     long graph_replays = 0, graph_captures = 0;
+    float *g_ctx_nc = nullptr, *g_sde = nullptr;   // graph mode: handle-owned copies of ctx_non_cover / sde_noise (caller tensors are
+    size_t g_ctx_nc_n = 0, g_sde_n = 0;            // re-allocated per call: their addresses must not be part of the graph)
     // MXFP8 mode (BASELINE configs[4] "fp8 MFMA"): the four big projections of every layer run on v_mfma_scale_f32_32x32x64_f8f6f4
     int precision = 0;                 // ACE355_PRECISION_*
     std::vector<void*> mx_allocs;      // weight copies
@@ -117,7 +119,8 @@ struct ace355_dit {
         hipStream_t key_stream = nullptr; // ... and the stream that built them (another stream is not ordered behind it)
     } nf;
 
-    int* sk_cnt = nullptr;   // ordered split-K turn counters lent to launch_gemm (GemmEpilogue::sk_cnt)
+    int* sk_cnt = nullptr;   // split-K counters lent to launch_gemm (GemmEpilogue::sk_cnt)
+    float* sk_slab = nullptr;   // slab split-K scratch lent to launch_gemm (GemmEpilogue::sk_slab, SK_SLAB_FLOATS)
     float* attn_part = nullptr;   // split-KV scratch lent to launch_attention (AttnArgs::part): small problems only
     long attn_part_floats = 0;
 
@@ -242,6 +245,7 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
     }
     GemmEpilogue e2 = ep;
     e2.sk_cnt = h->sk_cnt;
+    e2.sk_slab = h->sk_slab; e2.sk_slab_cap = SK_SLAB_FLOATS;
     return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, e2, s);
 }
 
@@ -774,10 +778,11 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->norm_out, D);
     ALLOC(h->allocs, h->sst_out, 2 * D);
     ALLOC(h->allocs, h->flags_dev, 4);
-    ALLOC(h->allocs, h->sk_cnt, SK_MAX_TILES);
+    ALLOC(h->allocs, h->sk_cnt, SK_CNT_INTS);
+    ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
     h->attn_part_floats = 16L << 20;   // 64 MB: 8 parts of a 2 x 16 x 375-row problem (12.7 M floats); larger problems do not split
     ALLOC(h->allocs, h->attn_part, (size_t)h->attn_part_floats);
-    ACE_HIP(hipMemset(h->sk_cnt, 0, SK_MAX_TILES * sizeof(int)));
+    ACE_HIP(hipMemset(h->sk_cnt, 0, SK_CNT_INTS * sizeof(int)));
     if (int prc = gemm_verify_splitk_placement()) return prc;
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
@@ -799,6 +804,8 @@ void ace355_dit_destroy(ace355_dit* h) {
         if (c.vt) hipFree(c.vt);
         if (c.cross_const) hipFree(c.cross_const);
     }
+    if (h->g_ctx_nc) hipFree(h->g_ctx_nc);
+    if (h->g_sde) hipFree(h->g_sde);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph_stream) hipStreamDestroy(h->graph_stream);
     if (h->graph_in) hipEventDestroy(h->graph_in);
@@ -1005,15 +1012,34 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     // captured once, replayed for every later call with the same key (the latent / context inputs were copied into the
     // handle's own buffers above, the result is copied out below, so caller pointers are not part of the graph)
     bool done = false;
+    ace355_sample_params pg = *p;   // graph mode: the loop reads handle-owned copies of the caller's optional tensors
     if (h->graph_mode && !per_step_ms_host && !h->profile) {
         bool taps = false;
         for (int l = 0; l < h->NL; ++l) taps = taps || h->tap_dst[l] != nullptr;
         if (!taps) {
+            auto own = [&](const float* src, size_t n, float** dst, size_t* cap) -> int {
+                if (!src) return 0;
+                if (n > *cap) {
+                    ACE_HIP(hipStreamSynchronize(s));
+                    if (*dst) hipFree(*dst);
+                    *dst = nullptr; *cap = 0;
+                    ACE_HIP(hipMalloc((void**)dst, n * sizeof(float) + 256));
+                    *cap = n;
+                    h->ws_epoch++;
+                }
+                ACE_HIP(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+                return 0;
+            };
+            if ((rc = own(p->ctx_non_cover_dev, (size_t)B * T * 2 * h->OUTC, &h->g_ctx_nc, &h->g_ctx_nc_n))) return rc;
+            if ((rc = own(p->sde_noise_dev, (size_t)p->num_steps * B * T * h->OUTC, &h->g_sde, &h->g_sde_n))) return rc;
+            if (p->ctx_non_cover_dev) pg.ctx_non_cover_dev = h->g_ctx_nc;
+            if (p->sde_noise_dev) pg.sde_noise_dev = h->g_sde;
+            p = &pg;
             std::string key((const char*)p->t_sched_host, (size_t)(p->num_steps + 1) * sizeof(float));
             auto add = [&](const void* q, size_t n) { key.append((const char*)q, n); };
             const long scal[] = {B, T, p->num_steps, p->infer_method, p->use_adg, p->cond_slot, p->null_slot, p->cover_switch_step,
                                  p->non_cover_slot, p->sde_next_from_sched, h->ws_epoch, h->cond_epoch,
-                                 (long)(uintptr_t)p->ctx_non_cover_dev, (long)(uintptr_t)p->sde_noise_dev};
+                                 p->ctx_non_cover_dev ? 1L : 0L, p->sde_noise_dev ? 1L : 0L};
             add(scal, sizeof(scal));
             const float fl[] = {p->guidance_scale, p->cfg_interval_start, p->cfg_interval_end};
             add(fl, sizeof(fl));
@@ -1101,6 +1127,28 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
     }
     h->precision = precision;
     h->ws_epoch++;  // a captured sampler graph holds the other precision's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_poll_errors(ace355_dit* h, void* stream) {
+    ACE_CHECK(h, "poll_errors: null handle");
+    return gemm_splitk_poll(h->sk_cnt, (hipStream_t)stream);
+}
+
+int ace355_dit_trim_slots(ace355_dit* h, int first_unused) {
+    ACE_CHECK(h && first_unused >= 0 && first_unused <= ACE355_MAX_SLOTS, "trim_slots: slot out of range");
+    bool any = false;
+    for (int i = first_unused; i < ACE355_MAX_SLOTS; ++i) any = any || h->slots[i].kv || h->slots[i].vt || h->slots[i].cross_const;
+    if (!any) return ACE355_OK;
+    ACE_HIP(hipDeviceSynchronize());   // queued forwards may still read them
+    for (int i = first_unused; i < ACE355_MAX_SLOTS; ++i) {
+        CondSlot& c = h->slots[i];
+        if (c.kv) hipFree(c.kv);
+        if (c.vt) hipFree(c.vt);
+        if (c.cross_const) hipFree(c.cross_const);
+        c = CondSlot{};
+    }
+    h->cond_epoch++;
     return ACE355_OK;
 }
 

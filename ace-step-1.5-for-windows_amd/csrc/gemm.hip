@@ -708,11 +708,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // split-K (ep.ksplit > 1, mode 2): blockIdx.y owns K steps [kt0, kt0 + nk)
+    // split-K (ep.kparts > 1): blockIdx.y owns K steps [kt0, kt0 + nk)
     const int nk_all = K / BK;
-    const int kchunk = (nk_all + ep.ksplit - 1) / ep.ksplit;
-    const int kt0 = (ep.ksplit > 1) ? (int)blockIdx.y * kchunk : 0;
-    const int nk = (ep.ksplit > 1) ? min(kchunk, nk_all - kt0) : nk_all;
+    const int kchunk = (nk_all + ep.kparts - 1) / ep.kparts;
+    const int kt0 = (ep.kparts > 1) ? (int)blockIdx.y * kchunk : 0;
+    const int nk = (ep.kparts > 1) ? min(kchunk, nk_all - kt0) : nk_all;
     if (nk <= 0) return;
     const bf16_t* A = A0 + kt0 * BK;
     const bf16_t* W = W0 + kt0 * BK;
@@ -944,6 +944,52 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         }
         unsigned long long e0 = 0;
         if (probe) e0 = clock64();
+        if constexpr (!PERS && !FP8) {
+            if (ep.sk_slab) {   // slab split-K (workgroup-uniform): see GemmEpilogue::sk_slab
+                constexpr int NTH = NW * 64, VEC = MT * NTW * 4;   // float4 vectors per lane
+                const int tile = tm * tiles_n + tn;
+                const int nparts = ep.kparts - 1;
+                if ((int)blockIdx.y < nparts) {
+                    float4* dst = reinterpret_cast<float4*>(ep.sk_slab) + ((long)tile * nparts + blockIdx.y) * (VEC * NTH) + tid;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float4 v;
+                                v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
+                                dst[((i * NTW + j) * 4 + q) * NTH] = v;
+                            }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's accumulators are in L2
+                    __syncthreads();
+                    if (tid == 0) atomicAdd(ep.sk_cnt + tile, 1);
+                    return;
+                }
+                if (tid == 0) {
+                    int spins = 0;
+                    for (; atomicAdd(ep.sk_cnt + tile, 0) != nparts && spins < (1 << 20); ++spins) __builtin_amdgcn_s_sleep(2);
+                    if (spins >= (1 << 20)) atomicAdd(ep.sk_cnt + SK_MAX_TILES, 1);   // counted: gemm_splitk_poll turns it into an error
+                }
+                __syncthreads();
+                const float4* src = reinterpret_cast<const float4*>(ep.sk_slab) + (long)tile * nparts * (VEC * NTH) + tid;
+                for (int pp = 0; pp < nparts; ++pp) {   // part order: one summation order whatever the arrival order
+                    float4 v[VEC];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v[e] = src[((long)pp * VEC + e) * NTH];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 w = v[(i * NTW + j) * 4 + q];
+                                acc[i][j][4 * q + 0] += w.x; acc[i][j][4 * q + 1] += w.y; acc[i][j][4 * q + 2] += w.z; acc[i][j][4 * q + 3] += w.w;
+                            }
+                }
+                if (tid == 0) atomicExch(ep.sk_cnt + tile, 0);   // (only this workgroup looks at the counter from here on)
+            }
+        }
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 // ordered split-K: wait until the parts before this one have added their share of this tile to H.  A part's
@@ -951,8 +997,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 // whoever is waited for is already running.  The counter lives in L2 like the fp32 atomics it replaces.
                 if (tid == 0) {
                     const int tile = tm * tiles_n + tn;
-                    // (bounded: a counter left behind by a faulted launch must not hang the device; ~1 s, then the update goes ahead)
-                    for (int spins = 0; atomicAdd(ep.sk_cnt + tile, 0) != (int)blockIdx.y && spins < (1 << 20); ++spins) __builtin_amdgcn_s_sleep(8);
+                    // (bounded: a counter left behind by a faulted launch must not hang the device; after ~1 s the update goes ahead and the
+                    //  missed turn is COUNTED: the host turns it into an error and re-zeroes the counters, gemm_splitk_poll)
+                    int spins = 0;
+                    for (; atomicAdd(ep.sk_cnt + tile, 0) != (int)blockIdx.y && spins < (1 << 20); ++spins) __builtin_amdgcn_s_sleep(8);
+                    if (spins >= (1 << 20)) atomicAdd(ep.sk_cnt + SK_MAX_TILES, 1);
                 }
                 asm volatile("" ::: "memory");
             }
@@ -1010,6 +1059,20 @@ int gemm_verify_splitk_placement() {
     return 0;
 }
 
+int gemm_splitk_poll(int* sk_cnt, hipStream_t s) {
+    if (!sk_cnt) return 0;
+    int missed = 0;
+    ACE_HIP(hipMemcpyAsync(&missed, sk_cnt + SK_MAX_TILES, sizeof(int), hipMemcpyDeviceToHost, s));
+    ACE_HIP(hipStreamSynchronize(s));
+    if (missed) {
+        ACE_HIP(hipMemsetAsync(sk_cnt, 0, SK_CNT_INTS * sizeof(int), s));
+        set_error("gemm: " + std::to_string(missed) + " ordered split-K turn(s) timed out; the result of this call is invalid (counters reset; "
+                  "ACE355_GEMM_SKORD=0 selects the atomic path)");
+        return 2;
+    }
+    return 0;
+}
+
 static int gemm_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1056,9 +1119,9 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     }
     const int xcd_n = 8 / xcd_m;
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
-    const dim3 grid(8 * region, ep.ksplit > 1 ? ep.ksplit : 1);
+    const dim3 grid(8 * region, ep.kparts > 1 ? ep.kparts : 1);
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
-    const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.ksplit > 1 ? ep.ksplit : 1) <= 256;
+    const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= 256;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
         if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
@@ -1127,6 +1190,37 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         if (bigenv == 2 || (bigenv == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
         else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 && t192 <= 320))) { mt = 3; bn = 128; big = 2; }
     }
+    // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every
+    // workgroup alone on its CU with a long serial K loop.  Slab split-K: the 8-wave 192x128 tile (two waves per SIMD: ~87 % MFMA issue
+    // against 68 % for a lone 4-wave workgroup), K cut into as many parts as it takes to put ~one workgroup on every CU; parts exchange
+    // raw accumulators through the XCD's L2 and the last one runs the epilogue (GemmEpilogue::sk_slab).  Every mode but SwiGLU (whose
+    // epilogue pairs two column tiles per wave: NTW = 2).
+    ep.kparts = 1;
+    float* slab = ep.sk_slab;
+    ep.sk_slab = nullptr;
+    if (variant != 1 && big == 0 && slab && ep.sk_cnt && g_splitk_ok == 1 && ep.mode != 3 && ep.wide_ok && N % 128 == 0) {
+        static int slab_env = -1, slab_ks = 0, slab_mink = 4, slab_maxwg = 256;
+        if (slab_env < 0) {
+            slab_env = env_int("ACE355_GEMM_SLAB", 1);          // 0: round-2 small-M paths (A/B)
+            slab_ks = env_int("ACE355_GEMM_SLAB_KS", 0);        // force the part count
+            slab_mink = env_int("ACE355_GEMM_SLAB_MINK", 4);    // fewest K steps a part may own
+            slab_maxwg = env_int("ACE355_GEMM_SLAB_MAXWG", 256);
+        }
+        const long t2 = (long)((M + 191) / 192) * (N / 128);
+        const int nkk = K / BK;
+        int ks = 1;
+        while (ks < 16 && t2 * (ks * 2) <= slab_maxwg && nkk / (ks * 2) >= slab_mink) ks *= 2;
+        if (slab_ks >= 1) ks = std::min(slab_ks, nkk);
+        while (ks > 1 && (ks - 1) * ((nkk + ks - 1) / ks) >= nkk) --ks;   // every part owns at least one K step
+        const bool fits = t2 <= SK_MAX_TILES && t2 * (ks - 1) * (192L * 128) <= ep.sk_slab_cap;
+        static const int mid3 = env_int("ACE355_GEMM_MIDNS", 3) == 3;
+        const bool head_ok = ep.mode != 4 || (ep.hn_q_cols % 128 == 0 && ep.hn_qk_cols % 128 == 0 && mid3);
+        if (slab_env && ks > 1 && fits && head_ok) {
+            mt = 3; bn = 128; big = 2;
+            ep.kparts = ks;
+            ep.sk_slab = slab;
+        }
+    }
     const int tiles_n = (N + bn - 1) / bn;
     const int bm = mt * 64;
     const int tiles_m = (M + bm - 1) / bm;
@@ -1138,7 +1232,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     // parts use fp32 atomics and the last bits depend on the arrival order.  ACE355_GEMM_KSPLIT=1 disables the split.
     ep.ksplit = 1;
     ep.sk_ord = 0;
-    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1) {
+    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && !ep.sk_slab) {
         static int ks_env = -1;
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
         const int nk = K / BK;
@@ -1154,6 +1248,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         ks = std::min(ks, nk);
         while (ks > 1 && (ks - 1) * ((nk + ks - 1) / ks) >= nk) --ks;   // every part owns at least one K step (an ordered part must arrive)
         ep.ksplit = ks;
+        ep.kparts = ks;
         ep.sk_ord = (ord && ks > 1) ? 1 : 0;
     }
     if (ep.nf_xg || ep.nc_rowsq) {  // folded RMSNorm (dit.hip): lives in the wide epilogue only, whole tiles, no split-K
@@ -1258,6 +1353,8 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
         ep.clk_probe = clk;
     }
     ep.ksplit = 1;
+    ep.kparts = 1;
+    ep.sk_slab = nullptr;
     ep.sk_ord = 0;
     ep.mx_sa = sa; ep.mx_sw = sw; ep.mx_sa_ld = sa_ld; ep.mx_sw_ld = sw_ld;
     if (ep.mode == 4)

@@ -185,6 +185,11 @@ struct ace355_vae {
     // activations
     bf16_t* buf[3] = {nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
+    // decode memory policy (ace355_vae_set_decode_budget): bytes the three ping-pong buffers may take before the decode is split
+    // into windows (fewer items first, then overlap-discard windows in time)
+    size_t decode_budget = (size_t)96 << 30;
+    int decode_overlap = 0;          // latent frames of halo per window side; 0: max(16, receptive field + 2)
+    int last_plan[3] = {0, 0, 0};    // (items per window, core frames, overlap) of the last decode
     bf16_t* zin = nullptr;
     size_t zin_elems = 0;
     float* scratch = nullptr;
@@ -391,6 +396,7 @@ int ace355_vae_create(const ace355_vae_config* cfg, ace355_vae** out) {
         ACE_CHECK(cfg->upsampling_ratios[i] >= 1 && cfg->channel_multiples[i] >= 1, "vae_create: ratios/multiples");
         h->hop *= cfg->upsampling_ratios[i];
     }
+    if (const char* e = getenv("ACE355_VAE_BUDGET_MB")) { const long mb = atol(e); if (mb > 0) h->decode_budget = (size_t)mb << 20; }
     *out = h;
     return ACE355_OK;
 }
@@ -550,52 +556,48 @@ static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t
     return run_conv(h, a, s);
 }
 
-int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream) {
-    RoctxRange r_dec("ace355.vae_decode");
-    ACE_CHECK(h && z_dev && wav_out_dev, "vae_decode: null argument");
-    if (!h->finalized) { set_error("vae_decode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
-    ACE_CHECK(B > 0 && T > 0, "vae_decode: empty problem");
-    hipStream_t s = (hipStream_t)stream;
-    const ace355_vae_config& c = h->cfg;
-    // largest activation: max over stages of L*C
-    size_t need_elems = (size_t)T * h->conv1.N;
-    {
-        long L = T;
-        for (const BlockW& Bk : h->blocks) {
-            L = (L - 1) * Bk.stride - 2 * Bk.pad + 2 * Bk.stride;
-            need_elems = std::max(need_elems, (size_t)L * Bk.cout);
-        }
+// Bytes of the three ping-pong activation buffers for a decode of `nb` items x `frames` latent frames (largest stage: L * C).
+static size_t decode_elems(const ace355_vae* h, long frames) {
+    size_t need = (size_t)frames * h->conv1.N;
+    long L = frames;
+    for (const BlockW& Bk : h->blocks) {
+        L = (L - 1) * Bk.stride - 2 * Bk.pad + 2 * Bk.stride;
+        need = std::max(need, (size_t)L * Bk.cout);
     }
-    need_elems *= (size_t)B;
-    if (need_elems > h->buf_elems) {
-        ACE_HIP(hipStreamSynchronize(s));
-        for (int i = 0; i < 3; ++i) {
-            if (h->buf[i]) hipFree(h->buf[i]);
-            h->buf[i] = nullptr;
-            ACE_HIP(hipMalloc((void**)&h->buf[i], need_elems * 2 + 256));
-        }
-        h->buf_elems = need_elems;
-    }
-    const size_t zel = (size_t)B * T * c.decoder_input_channels;
-    if (zel > h->zin_elems) {
-        ACE_HIP(hipStreamSynchronize(s));
-        if (h->zin) hipFree(h->zin);
-        ACE_HIP(hipMalloc((void**)&h->zin, zel * 2 + 256));
-        h->zin_elems = zel;
-    }
-    int rc = launch_ncl_to_nlc(z_dev, h->zin, B, c.decoder_input_channels, T, s);
-    if (rc) return rc;
+    return need;
+}
+static size_t decode_bytes(const ace355_vae* h, int nb, long frames) { return 3 * (decode_elems(h, frames) * (size_t)nb * 2 + 256); }
 
+// Receptive half-width of one output sample in LATENT frames: conv1 (k7) + per block {2-tap polyphase transposed conv at the input
+// rate, three k7 residual units with dilations 1 / 3 / 9 at the output rate} + the k7 output conv.  Everything further away from a
+// window edge than this is bit-identical to the whole-sequence decode (same per-element MFMA accumulation order).
+static int decode_receptive_frames(const ace355_vae* h) {
+    double rf = 3.0, rate = 1.0;
+    for (const BlockW& Bk : h->blocks) {
+        rf += 1.0 / rate;
+        rate *= Bk.stride;
+        rf += 3.0 * (1 + 3 + 9) / rate;
+    }
+    rf += 3.0 / rate;
+    return (int)ceil(rf);
+}
+
+// One decode window: `nb` items, latent frames [ws, we) of every item (zin rows; rows outside the window are treated as zero,
+// which is the true padding at the sequence ends and discarded halo elsewhere); the samples of frames [cs, ce) are written to wav.
+static int decode_window(ace355_vae* h, int b0, int nb, int T, int ws, int we, int cs, int ce, float* wav_out_dev, hipStream_t s) {
+    const ace355_vae_config& c = h->cfg;
+    const int Tw = we - ws;
     bf16_t *cur = h->buf[0], *nxt = h->buf[1], *tmp = h->buf[2];
-    long L = T;
+    long L = Tw;
+    int rc;
     ConvArgs a{};
     // conv1: k7, no snake (vae_model.py:224)
-    a = ConvArgs{};
-    a.x = h->zin; a.x_batch_stride = (long)T * c.decoder_input_channels; a.L_in = T; a.Cin = c.decoder_input_channels;
+    a.x = h->zin + ((size_t)b0 * T + ws) * c.decoder_input_channels; a.x_batch_stride = (long)T * c.decoder_input_channels; a.L_in = Tw;
+    a.Cin = c.decoder_input_channels;
     a.w = h->conv1.w; a.bias = h->conv1.bias;
-    a.y = cur; a.y_batch_stride = (long)T * h->conv1.N;
-    a.B = B; a.M = T; a.N = h->conv1.N; a.taps = 7; a.dil = 1; a.center = 3;
-    a.y_shift = 0; a.y_valid = (long)T * h->conv1.N; a.out_mode = 0;
+    a.y = cur; a.y_batch_stride = (long)Tw * h->conv1.N;
+    a.B = nb; a.M = Tw; a.N = h->conv1.N; a.taps = 7; a.dil = 1; a.center = 3;
+    a.y_shift = 0; a.y_valid = (long)Tw * h->conv1.N; a.out_mode = 0;
     if ((rc = run_conv(h, a, s))) return rc;
 
     for (const BlockW& Bk : h->blocks) {
@@ -605,22 +607,136 @@ int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wa
         a.x = cur; a.x_batch_stride = L * Bk.cin; a.L_in = (int)L; a.Cin = Bk.cin;
         a.w = Bk.ct.w; a.bias = Bk.ct.bias; a.alpha = Bk.s1.ea; a.beta = Bk.s1.ib;
         a.y = nxt; a.y_batch_stride = Lout * Bk.cout;
-        a.B = B; a.M = (int)L + 1; a.N = Bk.ct.N; a.taps = 2; a.dil = 1; a.center = 1;
+        a.B = nb; a.M = (int)L + 1; a.N = Bk.ct.N; a.taps = 2; a.dil = 1; a.center = 1;
         a.y_shift = -(long)Bk.pad * Bk.cout; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
         if ((rc = run_conv(h, a, s))) return rc;
         for (int j = 0; j < 3; ++j)  // x + conv_k1(snake2(conv_k7_dil(snake1(x)))), in place on the block state (vae_model.py:79-87)
-            if ((rc = run_res_unit(h, Bk.ru[j], nxt, tmp, B, Lout, Bk.cout, s))) return rc;
+            if ((rc = run_res_unit(h, Bk.ru[j], nxt, tmp, nb, Lout, Bk.cout, s))) return rc;
         std::swap(cur, nxt);
         L = Lout;
     }
-    // snake -> conv k7 -> [B, audio, L] fp32 (vae_model.py:228-229)
+    // snake -> conv k7 -> [B, audio, hop * T] fp32 (vae_model.py:228-229): the window's core samples go straight to their place
+    const long hop = h->hop, Lall = hop * T;
     a = ConvArgs{};
     a.x = cur; a.x_batch_stride = L * c.decoder_channels; a.L_in = (int)L; a.Cin = c.decoder_channels;
     a.w = h->conv2.w; a.bias = nullptr; a.alpha = h->s_out.ea; a.beta = h->s_out.ib;
-    a.y = wav_out_dev; a.y_batch_stride = L * c.audio_channels;
-    a.B = B; a.M = (int)L; a.N = c.audio_channels; a.taps = 7; a.dil = 1; a.center = 3;
+    a.y = wav_out_dev + (size_t)b0 * c.audio_channels * Lall; a.y_batch_stride = Lall * c.audio_channels;
+    a.B = nb; a.M = (int)L; a.N = c.audio_channels; a.taps = 7; a.dil = 1; a.center = 3;
     a.out_mode = 1; a.n_real = c.audio_channels;
+    a.ncl_ld = Lall; a.ncl_off = (long)cs * hop; a.ncl_m_lo = (int)((cs - ws) * hop); a.ncl_m_hi = (int)((ce - ws) * hop);
     return run_conv(h, a, s);
+}
+
+// Window plan of a decode under the activation budget (the reference bounds decode memory by policy: chunk sizes by free VRAM,
+// H/memory_utils.py:48-83, overlap-discard windows, H/vae_decode_chunks.py:51-112): whole batch and whole sequence when the three
+// ping-pong buffers fit; else fewer items per window (exact: items are independent); else windows of `tc` core frames with `ov`
+// halo frames on either side, the halo decoded and discarded.
+static int decode_plan(const ace355_vae* h, int B, int T, size_t budget, int* nb_out, int* tc_out, int* ov_out) {
+    const int rf = decode_receptive_frames(h);
+    int ov = h->decode_overlap > 0 ? h->decode_overlap : std::max(16, ((rf + 2 + 7) / 8) * 8);
+    ACE_CHECK(ov >= rf, "vae_decode: the window overlap must cover the decoder's receptive field");
+    int nb = B, tc = T;
+    if (decode_bytes(h, B, T) > budget) {
+        const size_t per_item = decode_bytes(h, 1, T);
+        if (per_item <= budget) nb = (int)std::max<size_t>(1, std::min<size_t>(B, budget / per_item));
+        else {
+            nb = 1;
+            // bytes grow linearly in the window length: largest window that fits, minus the two halos
+            const size_t per_frame = decode_bytes(h, 1, 1024) / 1024 + 1;
+            const long win = (long)(budget / per_frame);
+            tc = (int)std::min<long>(T, win - 2L * ov);
+            ACE_CHECK(tc >= ov, "vae_decode: the activation budget is smaller than one decode window (raise ACE355_VAE_BUDGET_MB)");
+            tc = (tc / 8) * 8;  // (whole 8-frame groups: window starts stay 16-byte aligned in the latent rows)
+            // several items per window when they fit
+            const size_t per_win = decode_bytes(h, 1, std::min<long>(T, tc + 2L * ov));
+            nb = (int)std::max<size_t>(1, std::min<size_t>(B, budget / per_win));
+        }
+    }
+    *nb_out = nb; *tc_out = tc; *ov_out = ov;
+    return 0;
+}
+
+int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream) {
+    RoctxRange r_dec("ace355.vae_decode");
+    ACE_CHECK(h && z_dev && wav_out_dev, "vae_decode: null argument");
+    if (!h->finalized) { set_error("vae_decode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && T > 0, "vae_decode: empty problem");
+    ACE_CHECK((long)T * h->hop < (1L << 31), "vae_decode: sequence too long (2^31 samples per item)");
+    hipStream_t s = (hipStream_t)stream;
+    const ace355_vae_config& c = h->cfg;
+    size_t budget = h->decode_budget;
+    int nb = B, tc = T, ov = 0;
+    // allocation with the reference's out-of-memory policy (H/vae_decode_chunks.py:40-81 retries smaller instead of failing):
+    // a refused hipMalloc halves the budget and re-plans, down to one minimal window
+    for (int attempt = 0;; ++attempt) {
+        int rc = decode_plan(h, B, T, budget, &nb, &tc, &ov);
+        if (rc) return rc;
+        const long win = std::min<long>(T, tc == T ? T : tc + 2L * ov);
+        const size_t need_elems = decode_elems(h, win) * (size_t)nb;
+        if (need_elems <= h->buf_elems) break;
+        ACE_HIP(hipStreamSynchronize(s));
+        bool ok = true;
+        for (int i = 0; i < 3; ++i) {
+            if (h->buf[i]) hipFree(h->buf[i]);
+            h->buf[i] = nullptr;
+        }
+        h->buf_elems = 0;
+        for (int i = 0; i < 3 && ok; ++i) ok = hipMalloc((void**)&h->buf[i], need_elems * 2 + 256) == hipSuccess;
+        if (ok) { h->buf_elems = need_elems; break; }
+        (void)hipGetLastError();
+        for (int i = 0; i < 3; ++i) { if (h->buf[i]) hipFree(h->buf[i]); h->buf[i] = nullptr; }
+        budget = std::min(budget, decode_bytes(h, nb, win)) / 2;
+        if (attempt >= 12 || budget < decode_bytes(h, 1, 3L * ov + 8)) {
+            set_error("vae_decode: out of device memory even for one minimal decode window");
+            return ACE355_ERR_HIP;
+        }
+    }
+    const size_t zel = (size_t)B * T * c.decoder_input_channels;
+    if (zel > h->zin_elems) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->zin) hipFree(h->zin);
+        h->zin = nullptr; h->zin_elems = 0;
+        ACE_HIP(hipMalloc((void**)&h->zin, zel * 2 + 256));
+        h->zin_elems = zel;
+    }
+    int rc = launch_ncl_to_nlc(z_dev, h->zin, B, c.decoder_input_channels, T, s);
+    if (rc) return rc;
+    h->last_plan[0] = nb; h->last_plan[1] = tc; h->last_plan[2] = ov;
+    for (int b0 = 0; b0 < B; b0 += nb) {
+        const int nbw = std::min(nb, B - b0);
+        for (int cs = 0; cs < T; cs += tc) {
+            const int ce = std::min(T, cs + tc);
+            const int ws = tc == T ? 0 : std::max(0, cs - ov), we = tc == T ? T : std::min(T, ce + ov);
+            if ((rc = decode_window(h, b0, nbw, T, ws, we, cs, ce, wav_out_dev, s))) return rc;
+        }
+    }
+    return ACE355_OK;
+}
+
+int ace355_vae_set_decode_budget(ace355_vae* h, int64_t bytes, int overlap_frames) {
+    ACE_CHECK(h, "vae_set_decode_budget: null handle");
+    ACE_CHECK(bytes >= 0 && overlap_frames >= 0, "vae_set_decode_budget: negative argument");
+    if (bytes > 0) h->decode_budget = (size_t)bytes;
+    if (overlap_frames > 0) {
+        ACE_CHECK(overlap_frames >= decode_receptive_frames(h) && overlap_frames % 8 == 0,
+                  "vae_set_decode_budget: the overlap must cover the receptive field and be a multiple of 8 frames");
+        h->decode_overlap = overlap_frames;
+    }
+    return ACE355_OK;
+}
+
+int ace355_vae_decode_plan(ace355_vae* h, int B, int T, int32_t* items_per_window, int32_t* core_frames, int32_t* overlap_frames,
+                           int64_t* activation_bytes) {
+    ACE_CHECK(h && B > 0 && T > 0, "vae_decode_plan: bad argument");
+    if (!h->finalized) { set_error("vae_decode_plan: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
+    int nb, tc, ov;
+    int rc = decode_plan(h, B, T, h->decode_budget, &nb, &tc, &ov);
+    if (rc) return rc;
+    if (items_per_window) *items_per_window = nb;
+    if (core_frames) *core_frames = tc;
+    if (overlap_frames) *overlap_frames = ov;
+    if (activation_bytes) *activation_bytes = (int64_t)decode_bytes(h, nb, std::min<long>(T, tc == T ? T : tc + 2L * ov));
+    return ACE355_OK;
 }
 
 int ace355_vae_encode(ace355_vae* h, const float* audio_dev, const float* noise_dev, int B, int64_t L, float* latents_out_dev,

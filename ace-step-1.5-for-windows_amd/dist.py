@@ -1,28 +1,41 @@
-"""Data-parallel runner pieces: one process per GPU, songs sharded across ranks, ONE collective per request.
+"""Data-parallel runner: one process per GPU, songs sharded across ranks, the conditioning bundle broadcast once per request.
 
 The reference has no multi-GPU inference; this is new functionality shaped by north_star:
 "batch-of-songs generation shards data-parallel across the 8 GPUs of one node with RCCL broadcast of text/LM
-conditioning over xGMI and per-rank independent samplers".  The conditioning bundle of one request
-(encoder states [L,D], null embedding [D], shared context latents [T,128], request scalars; a few MB) is produced once on
-rank 0 and broadcast; every rank then runs its own sampler over its slice of the seed list.  Per-item LM hints
-(``precomputed_lm_hints_25Hz [G,T,64]``, modeling_acestep_v15_base.py:1638-1649) are scattered instead: each rank receives
-only its rows.  No per-step collective exists.
+conditioning over xGMI and per-rank independent samplers".  The conditioning bundle of one request (distinct encoder-state
+rows [n, L, D], null embedding [D], context latents [1 | G, T, 128], per-item seeds, request knobs) is produced once on rank 0
+and broadcast at its exact size; every rank then runs the single-GPU path (sample -> decode -> normalise) over its contiguous
+slice of the song list.  Per-item LM hints (``precomputed_lm_hints_25Hz [G,T,64]``, modeling_acestep_v15_base.py:1638-1649) are
+scattered instead: each rank receives only its rows.  No per-step collective exists.
 
-Backend "nccl" is RCCL on PyTorch-ROCm; CPU tests use "gloo" (tests/test_dist_cpu.py).
+``run_request`` is the composition (broadcast -> shard -> execute -> gather); ``bench.py --gpus N``,
+``NativeHandler.generate_music(..., data_parallel=True)`` and tests/test_dist_cpu.py (gloo, world 2) all drive this one
+function with their own ``execute`` callable.
+
+Backend "nccl" is RCCL on PyTorch-ROCm; CPU tests use "gloo".
 """
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 _MAX_ITEMS = 16
 _MAX_DIMS = 4
-_HEADER = 2 + _MAX_ITEMS * (_MAX_DIMS + 1)      # int32 words: [magic, n_items, (ndim, d0..d3) x items]
+# header (int32 words): [magic, n_items | -1, payload bytes, error code, (dtype code, ndim, d0..d3) x items]
+_HEADER = 4 + _MAX_ITEMS * (_MAX_DIMS + 2)
 _MAGIC = 0x0ACE0355
-DEFAULT_CAPACITY_BYTES = 32 << 20               # covers L = 2305 encoder rows (18.9 MB) + a 600 s context (7.7 MB)
+_ALIGN = 16
+DEFAULT_CAPACITY_BYTES = 64 << 20   # upper bound a receiver accepts for one bundle (a 600 s request with L = 2305 is 13 MB in bf16)
+_DTYPES = [torch.float32, torch.bfloat16, torch.int64, torch.int32, torch.float64]
+_ERR_NONE, _ERR_TOO_BIG, _ERR_BAD_ITEM = 0, 1, 2
+
+# What travels in bf16: every tensor the native path rounds to bf16 on arrival anyway (encoder states and the null embedding in
+# ace355_dit_set_condition, context latents in pack_xin / set_xin_ctx; csrc/dit.hip) - the transport rounding (RNE, same as the
+# kernels') is the one rounding, so results are bit-identical to a single-GPU run of the same songs.
+BF16_KEYS = ("enc", "enc_rows", "null", "ctx", "ctx_non_cover", "enc_rows_non_cover")
 
 
 def init_from_env(backend: str = None) -> Tuple[int, int, int]:
@@ -51,63 +64,101 @@ def shard_seeds(seeds: List[int], world: int, rank: int) -> List[int]:
     return list(seeds[s:e])
 
 
-_bcast_buf: Dict[Tuple[str, int], torch.Tensor] = {}
+def _collective_device(device: Optional[torch.device], bundle: Dict[str, Any]) -> torch.device:
+    """Where the collective buffers live.  Under nccl / RCCL they must be GPU tensors on EVERY rank: a receiver that was handed
+    only None values (and no `device`) takes the current CUDA device, never the CPU (src would block forever on a mixed call)."""
+    if device is not None:
+        return torch.device(device)
+    for t in bundle.values():
+        if torch.is_tensor(t):
+            if dist.get_backend() != "nccl" or t.is_cuda:
+                return t.device
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
-def broadcast_conditioning(bundle: Dict[str, torch.Tensor], src: int = 0, capacity_bytes: int = DEFAULT_CAPACITY_BYTES,
-                           device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
-    """Broadcast a dict of fp32 tensors from `src` in ONE collective.
+def _pad(n: int) -> int:
+    return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
-    Only `src` knows the request (shapes included: L depends on the caption), so the other ranks cannot size a receive
-    buffer from a separate header without a second collective.  Instead every rank keeps one persistent buffer of
-    `capacity_bytes` (same value on every rank); `src` writes [header | payload] into it and the WHOLE buffer is
-    broadcast: shapes ride in the first words (int32 bit patterns next to the fp32 payload, no value conversion), the
-    unused tail costs ~0.2 ms of xGMI time per 32 MB against ~500 ms of compute per request.  Flat one-hop broadcast is the
-    right algorithm on the xGMI full mesh for MB-scale payloads.  Non-src ranks pass the KEYS (values
-    ignored, may be None); a bundle that does not fit raises on every rank (the error travels in the header) instead of
-    dead-locking the others.
-    """
+
+def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int = 0, capacity_bytes: int = DEFAULT_CAPACITY_BYTES,
+                           device: Optional[torch.device] = None, bf16_keys: Sequence[str] = BF16_KEYS) -> Dict[str, torch.Tensor]:
+    """Broadcast a dict of tensors from `src` at its EXACT size: a 0.4 KB header (shapes, dtypes, byte count - only `src` knows
+    the request: L depends on the caption) followed by one flat byte payload, 16-byte aligned items.  Keys in `bf16_keys` travel
+    as bf16 (see BF16_KEYS: lossless for this path), integer tensors as they are, the rest as fp32.  A 30 s request is 3.3 MB
+    (enc 769 x 2048 + ctx 750 x 128 in bf16) against the 32 MB fp32 buffer of round 2; flat one-hop broadcast is the right
+    algorithm on the xGMI full mesh for MB-scale payloads.
+
+    Non-src ranks pass the KEYS (values ignored, may be None).  Anything wrong with the bundle on `src` (too many items or
+    dimensions, larger than `capacity_bytes`) travels in the header and raises on EVERY rank instead of dead-locking the others.
+    Returned tensors keep their transport dtype (bf16 / int / fp32) and are private copies."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return bundle
     keys = list(bundle.keys())
-    assert len(keys) <= _MAX_ITEMS
     rank = dist.get_rank()
-    if device is None:
-        device = next((t.device for t in bundle.values() if torch.is_tensor(t)), torch.device("cpu"))
-    cap_words = capacity_bytes // 4
-    buf = _bcast_buf.get((str(device), cap_words))
-    if buf is None:
-        buf = torch.zeros(cap_words, dtype=torch.int32, device=device)
-        _bcast_buf[(str(device), cap_words)] = buf
+    dev = _collective_device(device, bundle)
+    head = torch.zeros(_HEADER, dtype=torch.int32, device=dev)
+    parts: List[torch.Tensor] = []
+    total = 0
     if rank == src:
-        h = [_MAGIC, len(keys)]
-        total = 0
-        for k in keys:
-            t = bundle[k]
-            assert t.dim() <= _MAX_DIMS
-            h += [t.dim()] + list(t.shape) + [0] * (_MAX_DIMS - t.dim())
-            total += t.numel()
-        if _HEADER + total > cap_words:
-            h[1] = -1  # does not fit: tell every rank
+        h = [_MAGIC, len(keys), 0, _ERR_NONE]
+        err = _ERR_NONE
+        if len(keys) > _MAX_ITEMS:
+            err = _ERR_BAD_ITEM
         else:
-            flat = torch.cat([bundle[k].detach().reshape(-1).to(device=device, dtype=torch.float32) for k in keys])
-            buf[_HEADER: _HEADER + total] = flat.view(torch.int32)
-        buf[: len(h)] = torch.tensor(h, dtype=torch.int32, device=device)
-    dist.broadcast(buf, src=src)
-    hl = buf[:_HEADER].tolist()
+            for k in keys:
+                t = bundle[k]
+                if not torch.is_tensor(t) or t.dim() > _MAX_DIMS:
+                    err = _ERR_BAD_ITEM
+                    break
+                t = t.detach()
+                if k in bf16_keys and t.is_floating_point():
+                    t = t.to(torch.bfloat16)
+                elif t.dtype not in _DTYPES:
+                    t = t.to(torch.float32) if t.is_floating_point() else t.to(torch.int64)
+                t = t.to(dev).contiguous()
+                h += [_DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (_MAX_DIMS - t.dim())
+                parts.append(t)
+                total += _pad(t.numel() * t.element_size())
+            if err == _ERR_NONE and total > capacity_bytes:
+                err = _ERR_TOO_BIG
+        if err != _ERR_NONE:
+            h = [_MAGIC, -1, 0, err]
+            parts, total = [], 0
+        else:
+            h[2] = total
+        head[: len(h)] = torch.tensor(h, dtype=torch.int32)
+    dist.broadcast(head, src=src)
+    hl = head.tolist()   # (the one host read of a request: receivers cannot slice the payload without the shapes)
     if hl[0] != _MAGIC:
-        raise RuntimeError("broadcast_conditioning: ranks disagree on the buffer layout (capacity_bytes must match)")
+        raise RuntimeError("broadcast_conditioning: ranks disagree on the header layout")
     if hl[1] < 0:
-        raise ValueError(f"broadcast_conditioning: the bundle does not fit the {capacity_bytes}-byte broadcast buffer")
+        if hl[3] == _ERR_TOO_BIG:
+            raise ValueError(f"broadcast_conditioning: the bundle does not fit the {capacity_bytes}-byte limit")
+        raise ValueError(f"broadcast_conditioning: at most {_MAX_ITEMS} tensors of at most {_MAX_DIMS} dimensions per bundle")
     if hl[1] != len(keys):
         raise RuntimeError("broadcast_conditioning: ranks passed different key lists")
-    out, off = {}, _HEADER
+    total = hl[2]
+    if total > capacity_bytes:
+        raise ValueError(f"broadcast_conditioning: the bundle does not fit the {capacity_bytes}-byte limit")
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    if rank == src:
+        off = 0
+        for t in parts:
+            nb = t.numel() * t.element_size()
+            buf[off: off + nb] = t.reshape(-1).view(torch.uint8)
+            off += _pad(nb)
+    if total:
+        dist.broadcast(buf, src=src)
+    out, off = {}, 0
     for i, k in enumerate(keys):
-        nd = hl[2 + i * (_MAX_DIMS + 1)]
-        shape = tuple(hl[3 + i * (_MAX_DIMS + 1): 3 + i * (_MAX_DIMS + 1) + nd])
-        n = int(torch.Size(shape).numel())
-        out[k] = buf[off: off + n].view(torch.float32).view(shape).clone()  # the buffer is reused by the next request
-        off += n
+        base = 4 + i * (_MAX_DIMS + 2)
+        dt, nd = _DTYPES[hl[base]], hl[base + 1]
+        shape = tuple(hl[base + 2: base + 2 + nd])
+        nb = int(torch.Size(shape).numel()) * torch.empty((), dtype=dt).element_size()
+        out[k] = buf[off: off + nb].view(dt).view(shape).clone() if rank != src else parts[i]
+        off += _pad(nb)
     return out
 
 
@@ -122,8 +173,7 @@ def scatter_lm_hints(hints: Optional[torch.Tensor], global_batch: int, T: int, c
         return hints
     world, rank = dist.get_world_size(), dist.get_rank()
     rows_max = -(-global_batch // world)
-    if device is None:
-        device = hints.device if hints is not None else torch.device("cpu")
+    device = _collective_device(device, {"hints": hints})
     recv = torch.empty(rows_max, T, channels, dtype=torch.float32, device=device)
     parts = None
     if rank == src:
@@ -158,4 +208,115 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0):
     for r in range(world):
         if r != dst and out[r].numel():
             dist.recv(out[r], src=r)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the request runner
+KNOBS = ("inference_steps", "guidance_scale", "shift", "cfg_interval_start", "cfg_interval_end", "use_adg", "infer_method_sde")
+_KNOB_DEFAULTS = {"inference_steps": 27, "guidance_scale": 7.0, "shift": 1.0, "cfg_interval_start": 0.0, "cfg_interval_end": 1.0,
+                  "use_adg": 0.0, "infer_method_sde": 0.0}
+
+
+def pack_request(encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor, seeds: Sequence[int],
+                 null_condition_emb: Optional[torch.Tensor] = None, **knobs) -> Dict[str, torch.Tensor]:
+    """The wire form of one generate_music request of G songs (rank 0): the DISTINCT rows of ``encoder_hidden_states [G | 1, L, D]``
+    with an index per song (the reference replicates one caption across the batch, handler/batch_prep.py:93-96: one row),
+    ``context_latents [G | 1, T, 128]`` collapsed to one row when every song shares it, per-song seeds, the request knobs."""
+    G = len(seeds)
+    enc = encoder_hidden_states if encoder_hidden_states.dim() == 3 else encoder_hidden_states[None]
+    rows: List[int] = []
+    idx: List[int] = []
+    for b in range(G):
+        e = enc[b if enc.shape[0] > 1 else 0]
+        for k, r in enumerate(rows):
+            if r == (b if enc.shape[0] > 1 else 0) or torch.equal(e, enc[r]):
+                idx.append(k)
+                break
+        else:
+            rows.append(b if enc.shape[0] > 1 else 0)
+            idx.append(len(rows) - 1)
+    ctx = context_latents if context_latents.dim() == 3 else context_latents[None]
+    if ctx.shape[0] > 1 and bool((ctx == ctx[:1]).all()):
+        ctx = ctx[:1]
+    unknown = set(knobs) - set(KNOBS)
+    if unknown:
+        raise ValueError(f"pack_request: unknown knobs {sorted(unknown)}")
+    kv = dict(_KNOB_DEFAULTS)
+    kv.update({k: float(v) for k, v in knobs.items()})
+    b = {"enc_rows": enc[rows].contiguous(), "enc_index": torch.tensor(idx, dtype=torch.int32),
+         "ctx": ctx.contiguous(), "seeds": torch.tensor([int(s) for s in seeds], dtype=torch.int64),
+         "knobs": torch.tensor([kv[k] for k in KNOBS], dtype=torch.float64)}
+    if null_condition_emb is not None:
+        b["null"] = null_condition_emb.reshape(-1).contiguous()
+    return b
+
+
+_REQUEST_KEYS = ("enc_rows", "enc_index", "ctx", "seeds", "knobs", "null")
+
+
+def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[Dict[str, Any]], Any], src: int = 0,
+                device: Optional[torch.device] = None, lm_hints: Optional[torch.Tensor] = None, use_lm_hints: bool = False,
+                gather: bool = False, capacity_bytes: int = DEFAULT_CAPACITY_BYTES) -> Dict[str, Any]:
+    """One generate_music request over all ranks: ONE exact-size broadcast of the packed request (`pack_request`, known on `src`
+    only; the others pass None), contiguous song slices (`shard_range`: 8/4/2/1 songs per rank for the metric's batch of 8 on
+    1/2/4/8 GPUs), `execute(local)` on every rank that owns a song, optional gather of what it returned.
+
+    `local` = {"encoder_hidden_states" [b, L, D], "context_latents" [b, T, 128], "null_condition_emb" [D] | None, "seeds" [b],
+    "knobs" {name: float}, "range" (s0, s1), "global_batch" G, "enc_rows", "enc_index"} - tensors in their transport dtype on
+    the collective device.  With `use_lm_hints` (same value on every rank) the per-song hints [G, T, 64] on `src` are scattered and
+    replace the source-latent half of each song's context (base.py:1646-1649).  Returns {"local": execute's result or None,
+    "range", "global_batch", "gathered": list per rank on `src` when `gather` (execute must then return a [b, ...] tensor)}."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if world > 1:
+        keys = list(_REQUEST_KEYS)
+        if rank == src:
+            if request is None:
+                raise ValueError("run_request: the source rank must hold the request")
+            # (a request without a null embedding still ships the key: every rank must pass the same key list)
+            req = {k: request.get(k) for k in keys}
+            if req["null"] is None:
+                req["null"] = torch.zeros(0)
+        else:
+            req = {k: None for k in keys}
+        b = broadcast_conditioning(req, src=src, capacity_bytes=capacity_bytes, device=device)
+    else:
+        if request is None:
+            raise ValueError("run_request: no request")
+        b = dict(request)
+        b.setdefault("null", None)
+    G = int(b["seeds"].numel())
+    s0, s1 = shard_range(G, world, rank)
+    knobs = dict(zip(KNOBS, [float(x) for x in b["knobs"].tolist()]))
+    seeds_all = [int(x) for x in b["seeds"].tolist()]
+    idx_all = [int(x) for x in b["enc_index"].tolist()]
+    ctx = b["ctx"]
+    T = ctx.shape[1]
+    mine_h = None
+    if use_lm_hints:
+        if world > 1:
+            mine_h = scatter_lm_hints(lm_hints, G, T, ctx.shape[-1] // 2, src=src, device=ctx.device)
+        else:
+            mine_h = lm_hints[s0:s1]
+    result = None
+    if s1 > s0:
+        ctx_l = (ctx[s0:s1] if ctx.shape[0] > 1 else ctx.expand(s1 - s0, -1, -1)).contiguous()
+        if mine_h is not None:
+            ctx_l = torch.cat([mine_h.to(ctx_l.dtype), ctx_l[..., ctx_l.shape[-1] // 2:]], -1).contiguous()
+        null = b.get("null")
+        local = {"encoder_hidden_states": b["enc_rows"][[idx_all[i] for i in range(s0, s1)]], "context_latents": ctx_l,
+                 "null_condition_emb": None if null is None or null.numel() == 0 else null, "seeds": seeds_all[s0:s1], "knobs": knobs,
+                 "range": (s0, s1), "global_batch": G, "enc_rows": b["enc_rows"], "enc_index": idx_all[s0:s1]}
+        result = execute(local)
+    out = {"local": result, "range": (s0, s1), "global_batch": G}
+    if gather:
+        if world > 1:
+            if result is None:   # this rank owns no song (G < world): it still takes part in the size exchange
+                counts = [torch.zeros(1, dtype=torch.int64, device=ctx.device) for _ in range(world)]
+                dist.all_gather(counts, torch.tensor([0], dtype=torch.int64, device=ctx.device))
+                out["gathered"] = None
+            else:
+                out["gathered"] = gather_waveforms(result, dst=src)
+        else:
+            out["gathered"] = [result]
     return out

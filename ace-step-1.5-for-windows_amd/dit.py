@@ -105,7 +105,9 @@ class NativeDit:
         with torch.cuda.device(self.device):
             native.check(self._lib.ace355_dit_set_condition(self._h, slot, native.ptr(enc), rows, L, native.current_stream_ptr()),
                          "dit_set_condition")
-            torch.cuda.current_stream().synchronize()  # enc may be freed by the caller after return
+            # (no host sync: `enc` is consumed by work queued on THIS stream, and torch's caching allocator only hands its block
+            #  to later work of the same stream - record_stream covers a caller that allocated it on another one)
+            enc.record_stream(torch.cuda.current_stream())
 
     # ------------------------------------------------------------------ compute
     def forward(self, x: torch.Tensor, ctx: torch.Tensor, t: Sequence[float], t_r: Sequence[float], slots: Sequence[int]) -> torch.Tensor:
@@ -171,6 +173,16 @@ class NativeDit:
         if return_step_ms:
             return out, list(ms)
         return out
+
+    def poll_errors(self) -> None:
+        """Raise if a queued call hit an asynchronous device-side condition (synchronises the current stream; include/ace355.h)."""
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_poll_errors(self._h, native.current_stream_ptr()), "dit_poll_errors")
+
+    def trim_slots(self, first_unused: int) -> None:
+        """Free the cross-K/V buffers of condition slots >= ``first_unused``."""
+        with torch.cuda.device(self.device):
+            native.check(self._lib.ace355_dit_trim_slots(self._h, int(first_unused)), "dit_trim_slots")
 
     # ------------------------------------------------------------------ precision of the four big projections
     def set_precision(self, precision: str) -> None:
@@ -239,7 +251,9 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
     def distinct(e):
         """Slot plan for a [B or 1, L, D] condition batch: (rows to upload, per-item index into them).  The reference handler
         replicates ONE caption across the batch (handler/batch_prep.py:93-96): identical rows share one cross-K/V slot."""
-        if e.shape[0] == 1 or bool((e == e[:1]).all()):
+        if e.shape[0] == 1 or e.stride(0) == 0:   # one row, or an expand()ed view of one row: nothing to compare, no device sync
+            return [0], [0] * B
+        if bool((e == e[:1]).all()):
             return [0], [0] * B
         rows, idx = [], []
         for b in range(B):
@@ -269,21 +283,25 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
     # slot layout of one call: [0, n_c) distinct cover / main conditions, n_c = null, then the distinct non-cover conditions
     rows_c, idx_c = distinct(enc)
     n_c = len(rows_c)
-    for k, r in enumerate(rows_c):
-        dit.set_condition(k, enc[r])
     do_cfg = diffusion_guidance_sale > 1.0
-    null_slot = n_c
-    if do_cfg:
-        dit.set_condition(null_slot, null_condition_emb.reshape(1, -1), L=enc.shape[1])
-    ctx_nc, nc_slots = None, None
+    rows_n, idx_n = [], []
     if cover_steps < steps:
         if enc_nc is None or context_latents_non_cover is None:
             raise ValueError("audio_cover_strength < 1 needs the non-cover conditions")
         if enc_nc.shape[1] != enc.shape[1]:
             raise NotImplementedError("ace355: cover / non-cover conditions must share the encoder length")
         rows_n, idx_n = distinct(enc_nc)
-        if n_c + 1 + len(rows_n) > native.MAX_SLOTS:
-            raise ValueError("too many distinct conditions for one call")
+    n_slots = n_c + 1 + len(rows_n)   # (the null slot keeps its place in the layout with CFG off)
+    if n_slots > native.MAX_SLOTS:    # checked BEFORE any cross-K/V build, for every path
+        raise ValueError(f"too many distinct conditions for one call: {n_c} + null + {len(rows_n)} non-cover > {native.MAX_SLOTS} slots")
+    dit.trim_slots(n_slots)           # slots a previous, larger request left resident (150 MB each) are released
+    for k, r in enumerate(rows_c):
+        dit.set_condition(k, enc[r])
+    null_slot = n_c
+    if do_cfg:
+        dit.set_condition(null_slot, null_condition_emb.reshape(1, -1), L=enc.shape[1])
+    ctx_nc, nc_slots = None, None
+    if cover_steps < steps:
         for k, r in enumerate(rows_n):
             dit.set_condition(n_c + 1 + k, enc_nc[r])
         nc_slots = [n_c + 1 + k for k in idx_n]
@@ -296,7 +314,7 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
                      use_adg, cond_slot=idx_c[0], null_slot=null_slot, cover_switch_step=cover_steps,
                      non_cover_slot=nc_slots[0] if nc_slots else 0, ctx_non_cover=ctx_nc, sde_noise=sde_noise,
                      cond_slots=idx_c, non_cover_slots=nc_slots, sde_next_from_schedule=sde_next_from_schedule)
-    torch.cuda.synchronize(dit.device)
+    dit.poll_errors()   # (synchronises: the reference's timing contract wants the diffusion done here anyway)
     t2 = time.time()
     return {"target_latents": out,
             "time_costs": {"encoder_time_cost": t1 - t0, "diffusion_time_cost": t2 - t1,

@@ -83,6 +83,8 @@ SIGNATURES = {
     "ace355_dit_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_norm_fold": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ace355_dit_poll_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ace355_dit_trim_slots": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_get_profile": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                          C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -92,6 +94,9 @@ SIGNATURES = {
     "ace355_vae_finalize": (C.c_int, [C.c_void_p]),
     "ace355_vae_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_vae_hop": (C.c_int, [C.c_void_p]),
+    "ace355_vae_set_decode_budget": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "ace355_vae_decode_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int64)]),
     "ace355_vae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "ace355_vae_latent_frames": (C.c_int, [C.c_void_p, C.c_int64]),
     "ace355_vae_set_profile": (C.c_int, [C.c_void_p, C.c_int]),

@@ -75,6 +75,17 @@ class NativeVae:
                          "vae_decode")
         return out
 
+    def set_decode_budget(self, budget_bytes: int = 0, overlap_frames: int = 0) -> None:
+        """Activation budget of ``decode`` (bytes; the reference sizes its chunks by free VRAM, handler/memory_utils.py:48-83)
+        and the halo per window side in latent frames (the reference's ``overlap``, handler/vae_decode.py:16); 0 = unchanged."""
+        native.check(self._lib.ace355_vae_set_decode_budget(self._h, int(budget_bytes), int(overlap_frames)), "vae_set_decode_budget")
+
+    def decode_plan(self, B: int, T: int) -> Dict[str, int]:
+        """How ``decode`` would split (B, T): items per window, core frames per window (== T: whole sequence), halo, bytes."""
+        nb, tc, ov, by = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        native.check(self._lib.ace355_vae_decode_plan(self._h, B, T, C.byref(nb), C.byref(tc), C.byref(ov), C.byref(by)), "vae_decode_plan")
+        return {"items_per_window": nb.value, "core_frames": tc.value, "overlap_frames": ov.value, "activation_bytes": by.value}
+
     def encode(self, audio: torch.Tensor, noise: torch.Tensor = None, generator: torch.Generator = None, sample: bool = True) -> torch.Tensor:
         """audio [B, 2, L] -> latents fp32 [B, 64, T] = ``vae.encode(audio).latent_dist.sample()`` (handler/vae_encode.py:66).
 

@@ -5,9 +5,11 @@ One "step" = one pass of the hot path over one batch of synthetic input on every
   RCCL broadcast of the conditioning bundle (N > 1) -> cross-K/V build for the cond / null slots ->
   27-step flow-matching sampler with CFG 7.0 + APG (2B sequences per DiT forward) -> Oobleck decode to
   48 kHz stereo fp32 -> peak normalise.   Workload at N=1: 30 s audio, 27 steps, batch 8 (the metric's config).
-Scaling: weak by default - every rank runs the reference's per-call cap of 8 songs (handler/service_generate_request.py:12);
-`--scaling strong` splits ONE global batch of `--batch` songs over the ranks in contiguous slices (8/4/2/1 songs
-per rank at 1/2/4/8 GPUs).  `python bench.py --gpus N` with N > 1 outside torchrun re-executes itself under
+Multi-GPU: `value` at N > 1 is the STRONG split of the metric's ONE batch of `--batch` (8) songs over the ranks in
+contiguous slices - 8/4/2/1 songs per rank at 1/2/4/8 GPUs - through `ace355.dist.run_request` (exact-size RCCL broadcast of the
+request -> shard -> per-rank sampler + decode); the weak number (the reference's per-call cap of 8 songs on EVERY rank,
+handler/service_generate_request.py:12) is measured in the same run and reported beside it under `weak`.  `--scaling weak` makes the
+weak number the headline instead.  `python bench.py --gpus N` with N > 1 outside torchrun re-executes itself under
 `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU over RCCL).
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job songs/s with inputs resident
@@ -38,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--duration", type=float, default=30.0, help="seconds of audio per song")
     ap.add_argument("--infer-steps", type=int, default=27)
-    ap.add_argument("--batch", type=int, default=8, help="songs per rank per step")
+    ap.add_argument("--batch", type=int, default=8, help="songs per request (strong: in total; weak: per rank)")
     ap.add_argument("--enc-len", type=int, default=769, help="encoder tokens (256 text + 512 lyric + 1 timbre)")
     ap.add_argument("--guidance", type=float, default=7.0)
     ap.add_argument("--no-vae", action="store_true", help="DiT-only (BASELINE configs 0/1)")
@@ -47,8 +49,9 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (smoke/debug only; result is not a benchmark)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4] precision: the four big projections on MXFP8 MFMA (not the headline metric, whose dtype is bf16)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="weak: --batch songs on EVERY rank; strong: --batch songs in total, split over the ranks (SURVEY 8e)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default, SURVEY 8e): --batch songs in total, split over the ranks, the weak number reported beside it; "
+                         "weak: --batch songs on EVERY rank")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / collective check WITHOUT a GPU: ranks over gloo on CPU tensors run broadcast -> (scatter) -> barrier "
                          "-> MAX-reduce and rank 0 prints a line marked dry_run (not a measurement; tests/test_dist_cpu.py drives it)")
@@ -248,9 +251,9 @@ def cpu_baseline(args, dcfg, vcfg, sd, vsd, enc_cpu, null_cpu, ctx_cpu, T, L):
 
 
 def dry_run(args, rank, world):
-    """The multi-rank control flow of main() with the compute replaced by a memcpy: same sharding, same collectives in the same
-    order, same barrier / MAX-over-ranks timing, same rank-0 JSON line - on CPU tensors over gloo.  Exists so that the
-    `--gpus N` launcher and the collective sequence can be exercised where there is no GPU; it measures nothing."""
+    """The multi-rank control flow of main() with the compute replaced by a memcpy: the same `ace355.dist.run_request` (exact-size
+    broadcast, sharding, LM-hint scatter), the same barrier / MAX-over-ranks timing, the same rank-0 JSON line - on CPU tensors over
+    gloo.  Exists so that the `--gpus N` launcher and the collective sequence can be exercised where there is no GPU; it measures nothing."""
     import torch.distributed as dist
     from ace355 import dist as a_dist
     if world > 1:
@@ -259,22 +262,34 @@ def dry_run(args, rank, world):
     dev = torch.device("cpu")
     G = args.batch * world if args.scaling == "weak" else args.batch
     s0, s1 = a_dist.shard_range(G, world, rank)
-    B, T, L, D = s1 - s0, int(round(args.duration * 25)), args.enc_len, 64
+    T, L, D = int(round(args.duration * 25)), args.enc_len, 64
     g = torch.Generator().manual_seed(99)
-    enc = torch.randn(L, D, generator=g)
-    ctx = torch.randn(T, 128, generator=g)
+    enc = torch.randn(1, L, D, generator=g)
+    ctx = torch.randn(1, T, 128, generator=g)
     hints = torch.randn(G, T, 64, generator=g)
+    seeds = [1000 + i for i in range(G)]
+    request = a_dist.pack_request(enc, ctx, seeds, torch.zeros(D), inference_steps=args.infer_steps, guidance_scale=args.guidance) if rank == 0 else None
     ok = True
+    seen = {}
+
+    def execute(local):
+        nonlocal ok
+        b = len(local["seeds"])
+        ok = ok and local["range"] == (s0, s1) and local["seeds"] == seeds[s0:s1] and local["global_batch"] == G
+        ok = ok and torch.equal(local["encoder_hidden_states"].float(), enc.to(torch.bfloat16).float().expand(b, -1, -1) if world > 1 else enc.expand(b, -1, -1))
+        want_ctx = ctx.to(torch.bfloat16).float() if world > 1 else ctx
+        got = local["context_latents"].float()
+        if args.lm_hints:
+            hh = hints[s0:s1].to(torch.bfloat16).float() if world > 1 else hints[s0:s1]
+            ok = ok and torch.equal(got[..., :64], hh) and torch.equal(got[..., 64:], want_ctx[..., 64:].expand(b, -1, -1))
+        else:
+            ok = ok and torch.equal(got, want_ctx.expand(b, -1, -1))
+        ok = ok and int(local["knobs"]["inference_steps"]) == args.infer_steps
+        seen["b"] = b
+        return got.clone()
 
     def one_pass():
-        nonlocal ok
-        b = a_dist.broadcast_conditioning({"enc": enc, "ctx": ctx} if rank == 0 else {"enc": None, "ctx": None}, src=0,
-                                          capacity_bytes=8 << 20, device=dev)
-        ok = ok and torch.equal(b["enc"], enc) and torch.equal(b["ctx"], ctx)
-        if args.lm_hints:
-            mine = a_dist.scatter_lm_hints(hints if rank == 0 else None, G, T, 64, src=0, device=dev)
-            ok = ok and torch.equal(mine, hints[s0:s1])
-        return b["ctx"][None].expand(max(B, 1), -1, -1).clone()
+        a_dist.run_request(request, execute, src=0, device=dev, lm_hints=hints if rank == 0 else None, use_lm_hints=args.lm_hints)
 
     for _ in range(args.warmup):
         one_pass()
@@ -291,7 +306,7 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps({"metric": "dry run (launcher + collectives only)", "dry_run": True, "value": G * args.steps / float(tt[0]),
                           "unit": "passes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling,
-                          "collectives_ok": bool(tt[1] == 0), "config": {"global_batch": G, "batch_rank0": B, "parallelism": f"dp{world}"}}))
+                          "collectives_ok": bool(tt[1] == 0), "config": {"global_batch": G, "batch_rank0": seen.get("b", 0), "parallelism": f"dp{world}"}}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -330,55 +345,32 @@ def main():
 
     dcfg, vcfg, dit, vae, sd, vsd = build_models(args, device)
     L = args.enc_len
-    # songs of this rank: weak = --batch on every rank; strong = contiguous slice of ONE global batch
-    G = args.batch * world if args.scaling == "weak" else args.batch
-    s0, s1 = a_dist.shard_range(G, world, rank)
-    B = s1 - s0
-    if B == 0:
-        raise SystemExit(f"bench.py: rank {rank} owns no song (global batch {G} over {world} ranks)")
     T = int(round(args.duration * 25))
     S = (T + 1) // 2
     D = dcfg.hidden_size
 
-    # synthetic request: one caption for the batch, per-item seeds
+    # synthetic request: one caption for the batch, per-item seeds; known on rank 0 only
     g = torch.Generator().manual_seed(99)
-    if rank == 0:
-        enc = torch.randn(L, D, generator=g).to(device)
-        null = torch.randn(D, generator=g).to(device)
-        ctx_shared = torch.cat([0.5 * torch.randn(T, 64, generator=g), torch.ones(T, 64)], -1).to(device)
-    else:
-        enc = torch.empty(L, D, device=device)
-        null = torch.empty(D, device=device)
-        ctx_shared = torch.empty(T, 128, device=device)
-    ts = schedule(args.infer_steps, 1.0)
-    seeds = [1000 + s0 + i for i in range(B)]   # the rank's slice of the request's seed list (a_dist.shard_seeds)
-    hints_all = None
-    if args.lm_hints and rank == 0:
-        hints_all = 0.5 * torch.randn(G, T, 64, generator=g).to(device)
-    noise = prepare_noise((B, T, 64), seeds).to(device)  # CPU generator (reference CPU stream), uploaded once
+    enc = torch.randn(L, D, generator=g).to(device)
+    null = torch.randn(D, generator=g).to(device)
+    ctx_shared = torch.cat([0.5 * torch.randn(T, 64, generator=g), torch.ones(T, 64)], -1).to(device)
 
-    last_bundle = {}
+    noise_cache = {}
+    last_local = {}
 
-    def one_pass(collective=True):
-        # collective=False (the rank-0-only profiled pass after the timed region) must not enter a broadcast the other
-        # ranks never join: it reuses the bundle of the last timed pass
-        if world > 1 and collective:
-            bundle = a_dist.broadcast_conditioning({"enc": enc, "null": null, "ctx": ctx_shared} if rank == 0 else
-                                                   {"enc": None, "null": None, "ctx": None}, src=0, device=device)
-            last_bundle.update(bundle)
-        elif world > 1:
-            bundle = last_bundle
-        else:
-            bundle = {"enc": enc, "null": null, "ctx": ctx_shared}
-        ctx = bundle["ctx"][None].expand(B, -1, -1).contiguous()
-        if args.lm_hints:  # per-item hints replace the source latents (base.py:1646-1649): scattered, not broadcast
-            mine = a_dist.scatter_lm_hints(hints_all, G, T, 64, src=0, device=device) if (world > 1 and collective) else \
-                (last_bundle["hints"] if world > 1 else hints_all[s0:s1])
-            last_bundle["hints"] = mine
-            ctx = torch.cat([mine, ctx[..., 64:]], -1).contiguous()
-        dit.set_condition(SLOT_COND, bundle["enc"])
-        dit.set_condition(SLOT_NULL, bundle["null"].reshape(1, -1), L=L)
-        lat = dit.sample(noise, ctx, ts, guidance_scale=args.guidance)
+    def execute(local):
+        """One rank's share of a request: cross-K/V build for the cond / null slots -> sampler -> decode -> peak normalise.  Inputs
+        resident in HBM: the per-song noise (CPU generator: the reference's stream, base.py:1733-1770) is uploaded once per seed list."""
+        last_local.clear()
+        last_local.update(local)
+        seeds = tuple(local["seeds"])
+        if seeds not in noise_cache:
+            noise_cache[seeds] = prepare_noise((len(seeds), T, 64), list(seeds)).to(device)
+        k = local["knobs"]
+        ts = schedule(int(k["inference_steps"]), k["shift"])
+        dit.set_condition(SLOT_COND, local["enc_rows"][0])
+        dit.set_condition(SLOT_NULL, local["null_condition_emb"].reshape(1, -1), L=L)
+        lat = dit.sample(noise_cache[seeds], local["context_latents"], ts, guidance_scale=k["guidance_scale"])
         if vae is None:
             return lat
         wav = vae.decode(lat.transpose(1, 2).contiguous())
@@ -390,34 +382,68 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = one_pass()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_pass()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert torch.isfinite(out).all(), "non-finite output"
+    def measure(scaling, steps, warmup):
+        """`steps` timed request passes under one scaling mode -> (global batch, songs of this rank, elapsed MAX over ranks, last output)."""
+        G = args.batch * world if scaling == "weak" else args.batch
+        s0, s1 = a_dist.shard_range(G, world, rank)
+        if G < world:
+            raise SystemExit(f"bench.py: global batch {G} over {world} ranks leaves a rank without a song")
+        request, hints_all = None, None
+        if rank == 0:
+            request = a_dist.pack_request(enc[None], ctx_shared[None], [1000 + i for i in range(G)], null, inference_steps=args.infer_steps,
+                                          guidance_scale=args.guidance)
+            if args.lm_hints:
+                hints_all = 0.5 * torch.randn(G, T, 64, generator=g).to(device)
+        out = None
+
+        def one_pass():
+            return a_dist.run_request(request, execute, src=0, device=device, lm_hints=hints_all, use_lm_hints=args.lm_hints)["local"]
+
+        for _ in range(warmup):
+            out = one_pass()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = one_pass()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        assert torch.isfinite(out).all(), "non-finite output"
+        return G, s1 - s0, elapsed
+
+    other = None
+    if world > 1:   # both modes in one run: the headline one last, so that the profiled pass below re-runs ITS per-rank shape
+        o_mode = "weak" if args.scaling == "strong" else "strong"
+        oG, oB, o_el = measure(o_mode, args.steps, max(1, args.warmup // 2))
+        other = {"scaling": o_mode, "value": oG * args.steps / o_el, "unit": "songs/s", "ms_per_step": 1000.0 * o_el / args.steps,
+                 "global_batch": oG, "batch_rank0": oB, "steps": args.steps}
+    G, B, elapsed = measure(args.scaling, args.steps, args.warmup)
 
     songs = G * args.steps
     value = songs / elapsed
     result = {
         "metric": (f"songs/sec ({args.duration:g} s audio @ {args.infer_steps} DiT steps, CFG {args.guidance:g} + APG, batch {args.batch} "
-                   + ("per GPU" if args.scaling == "weak" else "in total") + (", DiT + VAE decode)" if not args.no_vae else ", DiT-only)")),
+                   + ("per GPU" if args.scaling == "weak" and world > 1 else "in total") + (", DiT + VAE decode)" if not args.no_vae else ", DiT-only)")),
         "value": value, "unit": "songs/s", "rtf": value * args.duration, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "mxfp8 (four big projections) + bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"acestep-5Hz base DiT (24L/2048d, 1.575B params, random init) + Oobleck decoder, {args.duration:g} s audio "
-                               f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward), L={L}, "
-                               f"batch {B}/GPU" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
-                   "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "global_batch": G,
+                               f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward on rank 0), L={L}, "
+                               f"{G} songs per request over {world} GPU(s)" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
+                   "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "batch_rank0": B, "global_batch": G,
                    "parallelism": f"dp{world}", "tiny": bool(args.tiny)},
     }
+    if other is not None:
+        result[other["scaling"]] = other
+
+    def one_pass(collective=True):
+        # the rank-0-only profiled passes after the timed region must not enter a collective the other ranks never join: they
+        # re-run this rank's share of the last timed request
+        assert not collective
+        return execute(dict(last_local))
 
     if rank == 0 and not args.no_roofline:
         # dominant kernel = gemm_kernel: algorithmic FLOPs per launch / HIP-event launch time, one extra profiled pass
@@ -482,7 +508,8 @@ def main():
             import subprocess
             dit.set_condition(SLOT_COND, enc)
             dit.set_condition(SLOT_NULL, null.reshape(1, -1), L=L)
-            _ = dit.sample(noise, ctx_shared[None].expand(B, -1, -1).contiguous(), ts, guidance_scale=args.guidance)   # queued, not awaited
+            _ = dit.sample(noise_cache[tuple(last_local["seeds"])], ctx_shared[None].expand(B, -1, -1).contiguous(), schedule(args.infer_steps, 1.0),
+                           guidance_scale=args.guidance)   # queued, not awaited
             out_smi = subprocess.run(["rocm-smi", "-d", str(device.index or 0), "--showclocks", "--showpower"], capture_output=True, text=True,
                                      timeout=20).stdout
             torch.cuda.synchronize()

@@ -157,6 +157,13 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
  * tests compare the per-layer activations the golden fixtures hold, not only the final velocity. */
 int ace355_dit_set_tap(ace355_dit* h, int layer, float* dst_dev);
 
+/* Asynchronous device-side conditions of the calls queued so far on `stream` (synchronises it): today the ordered split-K of the
+ * small-M residual GEMMs, whose parts wait for their turn with a bound - a missed turn is counted on the device, reported here as
+ * ACE355_ERR_HIP and the turn counters are reset.  ACE355_OK otherwise.  The Python host calls it where it synchronises anyway. */
+int ace355_dit_poll_errors(ace355_dit* h, void* stream);
+/* Release the cross-K/V buffers of condition slots [first_unused, ACE355_MAX_SLOTS) (a request with many distinct conditions
+ * leaves up to 32 x 150 MB resident otherwise).  Synchronises the device when there is something to free. */
+int ace355_dit_trim_slots(ace355_dit* h, int first_unused);
 /* Work counters for roofline accounting: algorithmic FLOPs of the last forward (SURVEY.md section 8d formula)
  * and GEMM-only HIP-event time when profiling was enabled with ace355_dit_set_profile(h, 1). */
 int ace355_dit_set_profile(ace355_dit* h, int enable);
@@ -189,9 +196,20 @@ int ace355_vae_load_tensor(ace355_vae* h, const char* name, const void* data, in
 int ace355_vae_finalize(ace355_vae* h);
 /* Replaces vae.decode(z).sample at H/vae_decode_chunks.py:42,95 / H/generate_music_decode.py:172-177 and
  * _mlx_vae_decode (H/mlx_vae_decode_native.py:31-72).  z dev f32 [B,64,T] (the reference's
- * [B,C,T] layout); wav_out dev f32 [B,2,hop*T].  Whole-sequence decode: equals the reference's
- * overlap-discard tiling away from fp summation order. */
+ * [B,C,T] layout); wav_out dev f32 [B,2,hop*T].  Whole-sequence decode when the three activation buffers fit the decode
+ * budget: equals the reference's overlap-discard tiling away from fp summation order.  Above the
+ * budget the call splits itself: fewer items per pass first (exact), then overlap-discard windows in time whose halo covers
+ * the decoder's receptive field (bit-identical to the whole-sequence result); a refused allocation halves the budget and
+ * re-plans instead of failing (the reference's policy: H/memory_utils.py:48-83, H/vae_decode_chunks.py:40-112). */
 int ace355_vae_decode(ace355_vae* h, const float* z_dev, int B, int T, float* wav_out_dev, void* stream);
+/* Decode memory policy.  bytes > 0: budget of the three ping-pong activation buffers (default 96 GiB, or ACE355_VAE_BUDGET_MB at
+ * create); overlap_frames > 0: halo per window side in latent frames (multiple of 8, >= the receptive field; default
+ * max(16, receptive field + 2); the reference uses 64, H/vae_decode.py:16).  Zero leaves a setting unchanged. */
+int ace355_vae_set_decode_budget(ace355_vae* h, int64_t bytes, int overlap_frames);
+/* The window plan ace355_vae_decode would use for (B, T): items per window, core frames per window (== T: whole sequence),
+ * halo frames, bytes of the three activation buffers.  Any output pointer may be NULL. */
+int ace355_vae_decode_plan(ace355_vae* h, int B, int T, int32_t* items_per_window, int32_t* core_frames, int32_t* overlap_frames,
+                           int64_t* activation_bytes);
 int ace355_vae_hop(const ace355_vae* h);
 /* Encoder half (vae_model.py:92-116, 148-187, 285-310): available when the encoder.* keys of
  * AutoencoderOobleck.state_dict() were loaded before ace355_vae_finalize.  audio dev f32 [B, audio_channels, L];

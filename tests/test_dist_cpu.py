@@ -25,17 +25,60 @@ def _worker(rank, world, port, q):
     r, w, lr = a_dist.init_from_env("gloo")
     assert (r, w, lr) == (rank, world, rank)
     g = torch.Generator().manual_seed(123)
-    ref = {"enc": torch.randn(7, 16, generator=g), "null": torch.randn(16, generator=g), "ctx": torch.randn(5, 128, generator=g)}
-    mine = ref if rank == 0 else {"enc": None, "null": None, "ctx": None}  # only rank 0 knows the request: shapes travel in the payload
+    ref = {"enc": torch.randn(7, 16, generator=g), "null": torch.randn(16, generator=g), "ctx": torch.randn(5, 128, generator=g),
+           "aux": torch.randn(3, 2, 2, generator=g), "seeds": torch.arange(5, dtype=torch.int64) + (1 << 40), "knobs": torch.randn(4, generator=g).double()}
+    # what arrives: the bf16 keys in bf16 (the native path rounds them to bf16 anyway), everything else bit for bit
+    want = {k: (v.to(torch.bfloat16) if k in a_dist.BF16_KEYS else v) for k, v in ref.items()}
+    mine = ref if rank == 0 else {k: None for k in ref}  # only rank 0 knows the request: shapes travel in the header
     out = a_dist.broadcast_conditioning(mine, src=0, capacity_bytes=1 << 16)
-    ok = all(torch.equal(out[k], ref[k]) for k in ref)
-    out2 = a_dist.broadcast_conditioning(mine, src=0, capacity_bytes=1 << 16)  # the persistent buffer is reused: results are copies
-    ok = ok and all(torch.equal(out[k], ref[k]) and torch.equal(out2[k], ref[k]) for k in ref)
-    try:  # a bundle that does not fit raises on EVERY rank (no dead-lock)
-        a_dist.broadcast_conditioning({"big": torch.zeros(1 << 15) if rank == 0 else None}, src=0, capacity_bytes=1 << 16)
-        ok = False
-    except ValueError:
-        pass
+    ok = all(out[k].dtype == want[k].dtype and torch.equal(out[k], want[k]) for k in ref)
+    out2 = a_dist.broadcast_conditioning(mine, src=0, capacity_bytes=1 << 16)  # results are private copies
+    ok = ok and all(torch.equal(out[k], want[k]) and torch.equal(out2[k], want[k]) for k in ref)
+    for bad in ({"big": torch.zeros(1 << 15) if rank == 0 else None},                       # larger than the limit
+                {f"k{i}": (torch.zeros(1) if rank == 0 else None) for i in range(17)},       # too many items
+                {"deep": torch.zeros(1, 1, 1, 1, 1) if rank == 0 else None}):                # too many dimensions
+        try:  # a bundle the source cannot ship raises on EVERY rank (the error rides in the header: no dead-lock)
+            a_dist.broadcast_conditioning(bad, src=0, capacity_bytes=1 << 16)
+            ok = False
+        except ValueError:
+            pass
+    # run_request: broadcast -> shard -> execute -> gather, the function bench.py and NativeHandler.generate_music(data_parallel=True) call
+    G5 = 5
+    enc5 = torch.randn(1, 7, 16, generator=g).expand(G5, -1, -1).clone()
+    enc5[3] += 1.0                                            # songs 0,1,2,4 share a caption, song 3 has its own
+    ctx5 = torch.randn(1, 6, 128, generator=g)
+    seeds5 = [10, 11, 12, 13, 14]
+    req = a_dist.pack_request(enc5, ctx5.expand(G5, -1, -1), seeds5, torch.ones(16), inference_steps=9, guidance_scale=3.5) if rank == 0 else None
+    if rank == 0:
+        ok = ok and tuple(req["enc_rows"].shape) == (2, 7, 16) and req["enc_index"].tolist() == [0, 0, 0, 1, 0] and req["ctx"].shape[0] == 1
+    calls = []
+
+    def execute(local):
+        calls.append(local)
+        return local["encoder_hidden_states"].float().sum(dim=(1, 2)).reshape(-1, 1, 1) + torch.tensor(local["seeds"], dtype=torch.float32).reshape(-1, 1, 1)
+
+    res = a_dist.run_request(req, execute, src=0, device=torch.device("cpu"), gather=True)
+    s5, e5 = a_dist.shard_range(G5, world, rank)
+    loc = calls[0]
+    ok = ok and res["range"] == (s5, e5) and res["global_batch"] == G5 and loc["seeds"] == seeds5[s5:e5]
+    ok = ok and torch.equal(loc["encoder_hidden_states"].float(), enc5[s5:e5].to(torch.bfloat16).float())
+    ok = ok and tuple(loc["context_latents"].shape) == (e5 - s5, 6, 128) and loc["knobs"]["inference_steps"] == 9.0 and loc["knobs"]["guidance_scale"] == 3.5
+    ok = ok and loc["null_condition_emb"] is not None and float(loc["null_condition_emb"].float().sum()) == 16.0
+    if rank == 0:
+        allw = torch.cat(res["gathered"], 0).reshape(-1)
+        expect = enc5.to(torch.bfloat16).float().sum(dim=(1, 2)) + torch.tensor(seeds5, dtype=torch.float32)
+        ok = ok and torch.equal(allw, expect)
+    else:
+        ok = ok and res["gathered"] is None
+    # NativeHandler.generate_music(data_parallel=True) on handlers that were never initialised: the failure of every rank's share
+    # becomes the reference's error payload on EVERY rank (agreed by one all-reduce), nobody hangs in a collective
+    from ace355.backend import NativeHandler
+    hd = NativeHandler()
+    pay = hd.generate_music(enc5 if rank == 0 else None, ctx5.expand(G5, -1, -1) if rank == 0 else None, seed=seeds5 if rank == 0 else None,
+                            inference_steps=2, data_parallel=True)
+    ok = ok and pay["success"] is False and pay["audios"] == [] and isinstance(pay["error"], str)
+    pay = hd.generate_music(enc5 if rank == 0 else None, ctx5 if rank == 0 else None, seed=7, data_parallel=True)   # scalar seed: refused on rank 0, error everywhere
+    ok = ok and pay["success"] is False and ("seed" in pay["error"] or "another rank" in pay["error"])
     # per-item LM hints [G, T, 64] scattered by song ownership (G = 11 over 2 ranks: 6 + 5 rows)
     G, T = 11, 9
     hints = torch.arange(G * T * 64, dtype=torch.float32).view(G, T, 64) if rank == 0 else None
@@ -101,12 +144,12 @@ def test_bench_gpus_flag_spawns_ranks_dry_run():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    for scaling, want_g, want_b0 in (("weak", 16, 8), ("strong", 8, 4)):
+    for scaling, want_g, want_b0 in (("weak", 16, 8), ("strong", 8, 4), (None, 8, 4)):   # default = the section-8e split of ONE batch of 8
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run",
-                            "--lm-hints", "--scaling", scaling, "--duration", "2"], capture_output=True, text=True, timeout=300, env=env)
+                            "--lm-hints", "--duration", "2"] + (["--scaling", scaling] if scaling else []), capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout  # rank 0 only
         out = json.loads(lines[0])
-        assert out["n_gpus"] == 2 and out["dry_run"] and out["collectives_ok"] and out["scaling"] == scaling
+        assert out["n_gpus"] == 2 and out["dry_run"] and out["collectives_ok"] and out["scaling"] == (scaling or "strong")
         assert out["config"]["global_batch"] == want_g and out["config"]["batch_rank0"] == want_b0

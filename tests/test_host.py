@@ -225,6 +225,15 @@ def test_module_swap_on_a_real_nn_module_parent():
     assert p.encoder.in_features == 4  # attribute passthrough to the module it stands in for
     w2 = swap_in(p, "encoder", FakeNative, "cpu")  # re-entry keeps the ORIGINAL module as the fallback
     assert w2._reference is ref_mod
+    # the kept module is a real sub-module: strict load through the PARENT, dtype / device moves and parameters() reach it
+    sd = {k: v.clone() + 1.0 for k, v in p.state_dict().items()}
+    res = p.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(ref_mod.weight, sd["encoder.weight"]) and set(p.state_dict()) == keys
+    p.to(torch.float64)
+    assert ref_mod.weight.dtype == torch.float64 and sum(1 for _ in p.parameters()) == 2
+    p.to(torch.float32)
+    assert torch.allclose(p.encoder(x, mask=torch.ones(2)), ref_mod(x))
 
 
 def test_init_native_refuses_lora_quant_offload_and_never_raises():

@@ -203,8 +203,9 @@ def test_240s_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4
 
 
 @pytest.mark.parametrize("name,T,B,steps,precision", [
+    ("configs[2]: 120 s, batch 8 (N = 16 sequences, 24000 token rows)", 3000, 8, 2, "bf16"),
     ("configs[3] per-GPU share: 240 s, batch 4", 6000, 4, 2, "bf16"),
-    ("configs[4] per-GPU shape: 600 s, fp8 MFMA", 15000, 2, 2, "mxfp8")])
+    ("configs[4] per-GPU shape: 600 s, batch 8, fp8 MFMA (N = 16 sequences, 120000 token rows)", 15000, 8, 2, "mxfp8")])
 def test_long_config_sampler_properties(gpu_device, golden_dir, full_dit_seed4, name, T, B, steps, precision):
     """The two 8-GPU configurations of BASELINE.json at their per-GPU shapes (the fp32 oracle would need minutes per step there):
     size-independent properties of the sampler - finite, deterministic (same request twice is bit-identical), songs independent

@@ -127,6 +127,7 @@ static int hook_counters(GemmEpilogue& ep) {
 int ace355_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K, int out_dtype, const float* bias, void* stream) {
     ACE_CHECK(A && W && C, "gemm_bf16: null pointer");
     GemmEpilogue ep{out_dtype == ACE355_DTYPE_F32 ? 1 : 0, bias, nullptr, nullptr, 0, 0};
+    if (int rc = hook_counters(ep)) return rc;
     return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, C, N, M, N, K, ep, (hipStream_t)stream);
 }
 
@@ -177,6 +178,7 @@ int ace355_gemm_bf16_headnorm(const void* A, const void* W, void* out, int M, in
     GemmEpilogue ep{4, nullptr, nullptr, nullptr, 0, rows_per_seq};
     ep.hn_wq = wq; ep.hn_wk = wk; ep.hn_cos = cs; ep.hn_sin = sn;
     ep.hn_q_cols = q_cols; ep.hn_qk_cols = qk_cols; ep.hn_eps = eps;
+    if (int rc = hook_counters(ep)) return rc;
     return launch_gemm((const bf16_t*)A, K, Wuse, K, out, N, M, N, K, ep, s);
 }
 

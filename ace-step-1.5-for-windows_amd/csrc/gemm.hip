@@ -32,7 +32,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 
 // ACE355_GEMM_CLK=1 (diagnostic): workgroup 0 records shader-clock and 100 MHz wall-clock deltas around its K loop;
 // launch_gemm then prints the effective shader clock (DVFS) and the cycles per K-step to stderr.
-__device__ unsigned long long g_clk_probe[8];
+__device__ unsigned long long g_clk_probe[12];
 
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             kstep(kt, F{}, F{});                                 // last K step
             }
         }
-        if (probe) {
+        if (probe && (int)blockIdx.y == ep.kparts - 1) {
             g_clk_probe[0] = clock64() - c0;
             g_clk_probe[1] = wall_clock64() - w0;
             g_clk_probe[2] = (unsigned long long)nk;
@@ -964,6 +964,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's accumulators are in L2
                     __syncthreads();
                     if (tid == 0) atomicAdd(ep.sk_cnt + tile, 1);
+                    if (probe && blockIdx.y == 0) g_clk_probe[8] = clock64() - e0;   // park + signal
                     return;
                 }
                 if (tid == 0) {
@@ -972,6 +973,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                     if (spins >= (1 << 20)) atomicAdd(ep.sk_cnt + SK_MAX_TILES, 1);   // counted: gemm_splitk_poll turns it into an error
                 }
                 __syncthreads();
+                if (probe) g_clk_probe[6] = clock64() - e0;   // wait for the other parts
                 const float4* src = reinterpret_cast<const float4*>(ep.sk_slab) + (long)tile * nparts * (VEC * NTH) + tid;
                 for (int pp = 0; pp < nparts; ++pp) {   // part order: one summation order whatever the arrival order
                     float4 v[VEC];
@@ -988,6 +990,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                             }
                 }
                 if (tid == 0) atomicExch(ep.sk_cnt + tile, 0);   // (only this workgroup looks at the counter from here on)
+                if (probe) g_clk_probe[7] = clock64() - e0;   // ... + reduction
             }
         }
         if constexpr (MODE == 2 && !PERS && !FP8) {
@@ -1191,17 +1194,18 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 && t192 <= 320))) { mt = 3; bn = 128; big = 2; }
     }
     // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every
-    // workgroup alone on its CU with a long serial K loop.  Slab split-K: the 8-wave 192x128 tile (two waves per SIMD: ~87 % MFMA issue
-    // against 68 % for a lone 4-wave workgroup), K cut into as many parts as it takes to put ~one workgroup on every CU; parts exchange
-    // raw accumulators through the XCD's L2 and the last one runs the epilogue (GemmEpilogue::sk_slab).  Every mode but SwiGLU (whose
-    // epilogue pairs two column tiles per wave: NTW = 2).
+    // workgroup alone on its CU with a long serial K loop.  Slab split-K (ACE355_GEMM_SLAB=1, OFF by default): the 8-wave 192x128 tile, K
+    // cut into as many parts as it takes to put ~one workgroup on every CU; parts exchange raw accumulators through the XCD's L2 and the
+    // last one runs the epilogue (GemmEpilogue::sk_slab).  Every mode but SwiGLU (whose epilogue pairs two column tiles per wave).
+    // Measured in round 3: correct and bit-reproducible, but the exchange (park 1.2 us + wait 2-4 us + 1 us per
+    // partial) costs what the shorter K loops save - 157.4 vs 149.9 ms per batch-1 request - so it stays a switch.
     ep.kparts = 1;
     float* slab = ep.sk_slab;
     ep.sk_slab = nullptr;
     if (variant != 1 && big == 0 && slab && ep.sk_cnt && g_splitk_ok == 1 && ep.mode != 3 && ep.wide_ok && N % 128 == 0) {
         static int slab_env = -1, slab_ks = 0, slab_mink = 4, slab_maxwg = 256;
         if (slab_env < 0) {
-            slab_env = env_int("ACE355_GEMM_SLAB", 1);          // 0: round-2 small-M paths (A/B)
+            slab_env = env_int("ACE355_GEMM_SLAB", 0);          // 1: slab split-K for the small-M launches (measured slower: see above)
             slab_ks = env_int("ACE355_GEMM_SLAB_KS", 0);        // force the part count
             slab_mink = env_int("ACE355_GEMM_SLAB_MINK", 4);    // fewest K steps a part may own
             slab_maxwg = env_int("ACE355_GEMM_SLAB_MAXWG", 256);
@@ -1290,13 +1294,15 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     }
     ACE_LAUNCH_CHECK();
     if (ep.clk_probe) {
-        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long h[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         ACE_HIP(hipStreamSynchronize(s));
         ACE_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_probe), sizeof(h)));
-        if (h[1]) fprintf(stderr, "[ace355 gemm clk] M=%d N=%d K=%d mode=%d: %.3f GHz shader clock, %.0f cycles / K-step (%.3f us); prologue %.0f, "
-                          "epilogue issue %.0f / acked %.0f cycles (last tile of workgroup 0)\n", M, N, K, ep.mode,
-                          (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2],
-                          (double)h[5], (double)h[3], (double)h[4]);
+        if (h[1]) fprintf(stderr, "[ace355 gemm clk] M=%d N=%d K=%d mode=%d kparts=%d tiles=%d: %.3f GHz shader clock, %.0f cycles / K-step (%.3f us) x %llu; prologue %.0f, "
+                          "epilogue issue %.0f / acked %.0f cycles (last tile of workgroup 0)%s\n", M, N, K, ep.mode, ep.kparts, nwg,
+                          (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2], h[2],
+                          (double)h[5], (double)h[3], (double)h[4], "");
+        if (h[1] && ep.sk_slab) fprintf(stderr, "[ace355 gemm clk]   slab: part 0 park + signal %llu cycles; last part: wait %llu, wait + reduce %llu cycles (then the epilogue)\n",
+                                        h[8], h[6], h[7]);
     }
     return 0;
 }

@@ -144,6 +144,55 @@ def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_
     assert res[True][0] < GATE_G15 and res[False][0] < GATE_G15, res
 
 
+def test_bench_request_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
+    """G16: the EXACT request bench.py times - 8 songs x 30 s, CFG 7 + APG, the whole 27-step schedule at full size (N = 16 sequences,
+    6000 token rows: 192x256 persistent tiles, folded RMSNorm, 12-wave attention) - against the reference's generate_audio
+    (677 s of reference CPU time), folded and with the norms as kernels."""
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g16_bench_request_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    assert abs(wsum - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    _, ctx1 = _inputs(B, T)
+    assert _close(float(ctx1.double().abs().sum()), float(G["ctx_sum"]))
+    ref = torch.from_numpy(G["out"])
+    res = {}
+    try:
+        for fold in (True, False):
+            dit.set_norm_fold(fold)
+            out = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G["seeds"].tolist(),
+                                   infer_steps=int(G["steps"]), diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
+            res[fold] = (_rel(out, ref), max(_rel(out[i], ref[i]) for i in range(B)))
+            assert torch.isfinite(out).all()
+    finally:
+        dit.set_norm_fold(True)
+    print(f"bench-request sampler (B=8, 27 steps, CFG 7 + APG) vs reference fp32: folded {res[True][0]:.3e} (per item max {res[True][1]:.3e}), "
+          f"norms as kernels {res[False][0]:.3e} (per item max {res[False][1]:.3e})")
+    assert res[True][0] < GATE_G15 and res[False][0] < GATE_G15, res
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_small_batch_request_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4, B):
+    """BASELINE configs[1] (30 s, 27 steps, batch 1) and the 2-song share of a 4-GPU split of the metric batch: the small-M
+    launch regime (M = 750 / 1500 token rows: 4-wave deep-pipeline tiles, ordered split-K, split-KV attention).  Songs are independent
+    (per-item seeds, one caption), so items 0.. of G16 ARE the reference's answer for the smaller request; run twice: bit-reproducible."""
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g16_bench_request_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    T = 750
+    _, ctx1 = _inputs(B, T)
+    ref = torch.from_numpy(G["out"])[:B]
+    kw = dict(seed=G["seeds"].tolist()[:B], infer_steps=int(G["steps"]), diffusion_guidance_sale=float(G["guidance"]))
+    a = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), **kw)["target_latents"].cpu()
+    b = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), **kw)["target_latents"].cpu()
+    r = _rel(a, ref)
+    print(f"batch-{B} request (27 steps, CFG 7 + APG) vs the reference's items of G16: rel L2 {r:.3e}")
+    assert torch.isfinite(a).all() and r < GATE_G15, r
+    assert torch.equal(a, b), "same request twice must be bit-identical"
+
+
 def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, full_dit_seed4):
     """G13 / BASELINE configs[2] (120 s, T = 3000, S = 1500): a CFG pair vs the reference (attn3_kernel<4>: 32 (seq, head) pairs do
     not fill the chip with 256-row blocks), then the same pair inside a batch of N = 16, where launch_attention switches to

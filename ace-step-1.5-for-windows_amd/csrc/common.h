@@ -226,6 +226,10 @@ int launch_vmean(const bf16_t* x, int ld, int col0, int N, int S, int heads, bf1
 // table (row_src[r] == -1: zero row, < -1: leave dst row r untouched)
 // out[(r*P + p)][c] = emb[r][c] + special[p][c]   (f32)
 int launch_expand_add(const float* emb, const float* special, float* out, long rows, int P, int D, hipStream_t s);
+// audio tokenizer helpers (elementwise.hip): zero-padded bf16 rows, [special | P frames] sequences, token 0 of every sequence
+int launch_pad_rows_bf16(const float* x, bf16_t* out, long rows, int cols, int ld, hipStream_t s);
+int launch_prepend_special(const float* emb, const float* special, float* out, long rows, int P, int D, hipStream_t s);
+int launch_take_token0(const bf16_t* x, float* out, long rows, int S, int D, hipStream_t s);
 int launch_gather_rows_bf16_f32(const bf16_t* src, long src_ld, const int* row_src, float* dst, long dst_ld, long rows, int cols, hipStream_t s);
 
 struct TVals { float t[64]; };

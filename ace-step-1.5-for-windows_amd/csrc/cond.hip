@@ -78,6 +78,18 @@ struct ace355_detok : EncBase {
     float* b_out = nullptr;
 };
 
+// AceStepAudioTokenizer up to the quantizer (base.py:1181-1223): audio_acoustic_proj + AttentionPooler (base.py:734-859)
+struct ace355_tok : EncBase {
+    ace355_tok_config cfg;
+    EncoderW enc;              // attention_pooler.embed_tokens / layers / norm
+    float* special = nullptr;  // attention_pooler.special_token [D]
+    bf16_t* w_in = nullptr;    // audio_acoustic_proj.weight [D][in_pad] (K padded to a multiple of 64)
+    float* b_in = nullptr;
+    int in_pad = 64;
+    bf16_t* proj = nullptr;    // workspace: projected frames bf16 [R][D]
+    long proj_rows = 0;
+};
+
 namespace {
 
 template <typename T>
@@ -611,6 +623,148 @@ int ace355_detok_run(ace355_detok* h, const float* x_dev, int B, int T5, float* 
     if (rc) return rc;
     ep = GemmEpilogue{1, h->b_out, nullptr, nullptr, 0, 0};
     return launch_gemm(h->xn, D, h->w_out, D, out_dev, OD, (int)R, OD, D, ep, s);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ audio tokenizer (N2, the other direction)
+// AceStepAudioTokenizer.forward up to the quantizer (base.py:1206-1218): x [B, T5, P, 64] -> audio_acoustic_proj (Linear 64 -> D) ->
+// AttentionPooler: embed_tokens (Linear D -> D), one special token in FRONT of every window of P frames, the (B T5) sequences of P + 1
+// tokens through the encoder layers + norm, token 0 of each sequence is the pooled 5 Hz representation [B, T5, D].  Reached by
+// prepare_condition for cover tasks without precomputed hints (base.py:1645).  The ResidualFSQ behind it is a [n, D] x [D, 6]
+// product + rounding and stays with the caller (lmhints.py).
+namespace {
+
+bool resolve_tok(ace355_tok* h, const std::string& name, Dest* d) {
+    const long D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+    auto rows = [&](void* dst, int bf, long r, long c, long ld, long row0) {
+        *d = Dest{dst, bf, PACK_ROWS, r, c, ld, row0, 0, false};
+        return true;
+    };
+    if (name == "audio_acoustic_proj.weight") return rows(h->w_in, 1, D, h->cfg.out_dim, h->in_pad, 0);
+    if (name == "audio_acoustic_proj.bias") return rows(h->b_in, 0, 1, D, D, 0);
+    const std::string p = "attention_pooler.";
+    if (name.rfind(p, 0) != 0) return false;
+    const std::string r = name.substr(p.size());
+    EncoderW& E = h->enc;
+    if (r == "embed_tokens.weight") return rows(E.w_embed, 1, D, D, D, 0);
+    if (r == "embed_tokens.bias") return rows(E.b_embed, 0, 1, D, D, 0);
+    if (r == "norm.weight") return rows(E.norm, 0, 1, D, D, 0);
+    if (r == "special_token") return rows(h->special, 0, 1, D, D, 0);
+    if (r.rfind("layers.", 0) != 0) return false;
+    const size_t dot = r.find('.', 7);
+    if (dot == std::string::npos) return false;
+    const int li = atoi(r.substr(7, dot - 7).c_str());
+    if (li < 0 || li >= E.n_layers) return false;
+    EncLayerW& L = E.layers[li];
+    const std::string q = r.substr(dot + 1);
+    if (q == "input_layernorm.weight") return rows(L.n_in, 0, 1, D, D, 0);
+    if (q == "post_attention_layernorm.weight") return rows(L.n_post, 0, 1, D, D, 0);
+    if (q == "self_attn.q_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, QD, D, D, 0, 0, false}; return true; }
+    if (q == "self_attn.k_proj.weight") { *d = Dest{L.wqkv, 1, PACK_ROWS_HEADPAIR, KVD, D, D, QD, 0, false}; return true; }
+    if (q == "self_attn.v_proj.weight") return rows(L.wqkv, 1, KVD, D, D, QD + KVD);
+    if (q == "self_attn.o_proj.weight") return rows(L.wo, 1, D, QD, QD, 0);
+    if (q == "self_attn.q_norm.weight") return rows(L.qn, 0, 1, 128, 128, 0);
+    if (q == "self_attn.k_norm.weight") return rows(L.kn, 0, 1, 128, 128, 0);
+    if (q == "mlp.gate_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 0, false}; return true; }
+    if (q == "mlp.up_proj.weight") { *d = Dest{L.wgu, 1, PACK_ROWS_IL32, F, D, D, 0, 1, false}; return true; }
+    if (q == "mlp.down_proj.weight") return rows(L.wdown, 1, D, F, F, 0);
+    return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ace355_tok_create(const ace355_tok_config* cfg, ace355_tok** out) {
+    ACE_CHECK(cfg && out, "tok_create: null argument");
+    ACE_CHECK(cfg->head_dim == 128, "tok_create: head_dim must be 128");
+    ACE_CHECK(cfg->hidden_size % 256 == 0 && cfg->intermediate_size % 64 == 0, "tok_create: hidden/intermediate size");
+    ACE_CHECK(cfg->num_heads % cfg->num_kv_heads == 0, "tok_create: heads % kv_heads");
+    ACE_CHECK(cfg->num_layers >= 0 && cfg->num_layers <= 64 && cfg->pool_window_size >= 1 && cfg->pool_window_size <= 63 &&
+                  cfg->out_dim >= 1 && cfg->out_dim <= 4096, "tok_create: layer count / pool window / acoustic dim");
+    ace355_tok* h = new ace355_tok();
+    h->cfg = *cfg;
+    h->D = cfg->hidden_size; h->F = cfg->intermediate_size; h->HQ = cfg->num_heads; h->KVH = cfg->num_kv_heads;
+    h->QD = cfg->num_heads * 128; h->KVD = cfg->num_kv_heads * 128;
+    h->sliding_window = cfg->sliding_window; h->sliding_layer_mask = cfg->sliding_layer_mask;
+    h->eps = cfg->rms_norm_eps; h->theta = cfg->rope_theta;
+    h->in_pad = ((cfg->out_dim + 63) / 64) * 64;
+    int rc = alloc_encoder(h, h->enc, cfg->num_layers, cfg->hidden_size);
+    if (!rc) rc = dev_alloc(h->allocs, &h->special, (size_t)h->D);
+    if (!rc) rc = dev_alloc(h->allocs, &h->w_in, (size_t)h->D * h->in_pad);
+    if (!rc) rc = dev_alloc(h->allocs, &h->b_in, (size_t)h->D);
+    if (!rc && hipMemset(h->w_in, 0, (size_t)h->D * h->in_pad * sizeof(bf16_t)) != hipSuccess) rc = ACE355_ERR_HIP;
+    if (rc) { ace355_tok_destroy(h); return rc; }
+    h->expected_tensors = 6 + (size_t)cfg->num_layers * 11;
+    *out = h;
+    return ACE355_OK;
+}
+
+void ace355_tok_destroy(ace355_tok* h) {
+    if (!h) return;
+    hipDeviceSynchronize();
+    for (void* p : h->allocs) hipFree(p);
+    for (void* p : h->ws_allocs) hipFree(p);
+    if (h->proj) hipFree(h->proj);
+    if (h->stage) hipFree(h->stage);
+    delete h;
+}
+
+int ace355_tok_load_tensor(ace355_tok* h, const char* name, const void* data, int dtype, int64_t numel, int is_device) {
+    ACE_CHECK(h && name && data, "tok_load_tensor: null argument");
+    ACE_CHECK(dtype == ACE355_DTYPE_F32 || dtype == ACE355_DTYPE_BF16, "tok_load_tensor: dtype");
+    Dest d;
+    if (!resolve_tok(h, name, &d)) {
+        set_error(std::string("tok_load_tensor: unknown tensor name '") + name + "'");
+        return ACE355_ERR_INVALID;
+    }
+    return load_packed(h, d, name, data, dtype, numel, is_device, "tok_load_tensor");
+}
+
+int ace355_tok_finalize(ace355_tok* h) {
+    ACE_CHECK(h, "tok_finalize: null handle");
+    if (h->loaded.size() != h->expected_tensors) {
+        set_error("tok_finalize: " + std::to_string(h->loaded.size()) + " of " + std::to_string(h->expected_tensors) + " tensors loaded");
+        return ACE355_ERR_STATE;
+    }
+    if (h->stage) { hipFree(h->stage); h->stage = nullptr; h->stage_bytes = 0; }
+    h->finalized = true;
+    return ACE355_OK;
+}
+
+int ace355_tok_run(ace355_tok* h, const float* x_dev, int B, int T5, float* out_dev, void* stream) {
+    ACE_CHECK(h && x_dev && out_dev, "tok_run: null argument");
+    if (!h->finalized) { set_error("tok_run: call ace355_tok_finalize first"); return ACE355_ERR_STATE; }
+    ACE_CHECK(B > 0 && T5 > 0 && (long)B * T5 <= (1L << 20), "tok_run: sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->D, P = h->cfg.pool_window_size, A = h->cfg.out_dim, S = P + 1;
+    const long R5 = (long)B * T5, R = R5 * P, RS = R5 * S;  // 5 Hz tokens, 25 Hz frames, rows of the (P + 1)-token sequences
+    const long vt_elems = R5 * h->KVD * (((S + 63) / 64) * 64);
+    int rc = ensure_workspace(h, RS, R * h->in_pad, (int)R5, vt_elems, s);
+    if (rc) return rc;
+    if (R > h->proj_rows) {
+        ACE_HIP(hipStreamSynchronize(s));
+        if (h->proj) hipFree(h->proj);
+        h->proj = nullptr; h->proj_rows = 0;
+        ACE_HIP(hipMalloc((void**)&h->proj, (size_t)R * D * sizeof(bf16_t) + 256));
+        h->proj_rows = R;
+    }
+    // frames -> bf16 rows of in_pad columns (zero beyond the acoustic width), audio_acoustic_proj (base.py:1213), embed_tokens (:768)
+    rc = launch_pad_rows_bf16(x_dev, h->in_bf, R, A, h->in_pad, s);
+    if (rc) return rc;
+    GemmEpilogue ep{0, h->b_in, nullptr, nullptr, 0, 0};
+    rc = launch_gemm(h->in_bf, h->in_pad, h->w_in, h->in_pad, h->proj, D, (int)R, D, h->in_pad, ep, s);
+    if (rc) return rc;
+    ep = GemmEpilogue{1, h->enc.b_embed, nullptr, nullptr, 0, 0};
+    rc = launch_gemm(h->proj, D, h->enc.w_embed, D, h->emb, D, (int)R, D, D, ep, s);
+    if (rc) return rc;
+    // [special | P frames] per window (:769-771), the (b t) sequences through the layers + norm (:773-853), token 0 of each (:856-858)
+    rc = launch_prepend_special(h->emb, h->special, h->h, R5, P, D, s);
+    if (rc) return rc;
+    rc = encoder_layers(h, h->enc, (int)R5, S, nullptr, h->xn, s);
+    if (rc) return rc;
+    return launch_take_token0(h->xn, out_dev, R5, S, D, s);
 }
 
 }  // extern "C"

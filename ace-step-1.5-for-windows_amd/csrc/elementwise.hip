@@ -720,6 +720,35 @@ __global__ void expand_add_kernel(const float* __restrict__ emb, const float* __
     *reinterpret_cast<float4*>(out + rp * D + c) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+// AceStepAudioTokenizer helpers (cond.hip: ace355_tok_run).  pad_rows: f32 [rows, cols] -> bf16 [rows, ld] with zeros beyond `cols`.
+__global__ void pad_rows_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long rows, int cols, int ld) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ld) return;
+    const long r = i / ld;
+    const int c = (int)(i - r * ld);
+    out[i] = c < cols ? f2bf(x[r * cols + c]) : (bf16_t)0;
+}
+// AttentionPooler (base.py:769-771): out[r * (P + 1)] = special, out[r * (P + 1) + 1 + p] = emb[r * P + p]
+__global__ void prepend_special_kernel(const float* __restrict__ emb, const float* __restrict__ special, float* __restrict__ out, long rows,
+                                       int P, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int d4 = D / 4;
+    if (i >= rows * (P + 1) * d4) return;
+    const long rp = i / d4;
+    const int c = (int)(i - rp * d4) * 4;
+    const long r = rp / (P + 1);
+    const int p = (int)(rp - r * (P + 1));
+    const float4 v = p == 0 ? *reinterpret_cast<const float4*>(special + c) : *reinterpret_cast<const float4*>(emb + (r * P + p - 1) * D + c);
+    *reinterpret_cast<float4*>(out + rp * D + c) = v;
+}
+// pooled output (base.py:856-858): out[r][:] = f32(x[r * S][:])
+__global__ void take_token0_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long rows, int S, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const long r = i / D;
+    out[i] = bf2f(x[r * S * D + (i - r * D)]);
+}
+
 inline int blocks_for(long n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
@@ -792,6 +821,23 @@ int launch_expand_add(const float* emb, const float* special, float* out, long r
     ACE_CHECK(D % 4 == 0, "expand_add: D must be a multiple of 4");
     const long n = rows * P * (D / 4);
     hipLaunchKernelGGL(expand_add_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, emb, special, out, rows, P, D);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_pad_rows_bf16(const float* x, bf16_t* out, long rows, int cols, int ld, hipStream_t s) {
+    hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3(blocks_for(rows * ld, 256)), dim3(256), 0, s, x, out, rows, cols, ld);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_prepend_special(const float* emb, const float* special, float* out, long rows, int P, int D, hipStream_t s) {
+    ACE_CHECK(D % 4 == 0, "prepend_special: D must be a multiple of 4");
+    hipLaunchKernelGGL(prepend_special_kernel, dim3(blocks_for(rows * (P + 1) * (D / 4), 256)), dim3(256), 0, s, emb, special, out, rows, P, D);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+int launch_take_token0(const bf16_t* x, float* out, long rows, int S, int D, hipStream_t s) {
+    hipLaunchKernelGGL(take_token0_kernel, dim3(blocks_for(rows * D, 256)), dim3(256), 0, s, x, out, rows, S, D);
     ACE_LAUNCH_CHECK();
     return 0;
 }

@@ -109,6 +109,11 @@ SIGNATURES = {
     "ace355_cond_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_int,
                                      C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int32),
                                      C.c_void_p]),
+    "ace355_tok_create": (C.c_int, [C.POINTER(DetokConfigC), C.POINTER(C.c_void_p)]),
+    "ace355_tok_destroy": (None, [C.c_void_p]),
+    "ace355_tok_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),
+    "ace355_tok_finalize": (C.c_int, [C.c_void_p]),
+    "ace355_tok_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ace355_detok_create": (C.c_int, [C.POINTER(DetokConfigC), C.POINTER(C.c_void_p)]),
     "ace355_detok_destroy": (None, [C.c_void_p]),
     "ace355_detok_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int64, C.c_int]),

@@ -296,6 +296,26 @@ int ace355_detok_finalize(ace355_detok* h);
 /* x dev f32 [B, T5, hidden] -> out dev f32 [B, T5 * pool_window_size, out_dim]. */
 int ace355_detok_run(ace355_detok* h, const float* x_dev, int B, int T5, float* out_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Audio tokenizer, the opposite direction of the same row: AceStepAudioTokenizer.forward up to its quantizer
+ * (base.py:1181-1218) = audio_acoustic_proj (Linear 64 -> hidden) + AttentionPooler (base.py:734-859: embed_tokens, one
+ * special token in front of every window of pool_window_size frames, num_layers encoder layers over the (B T5) sequences
+ * of pool_window_size + 1 tokens, norm, token 0).  Replaces `self.tokenizer(x)` of model.tokenize (base.py:1580-1591), which
+ * prepare_condition reaches for cover tasks without precomputed hints (base.py:1645).  The ResidualFSQ behind the pooler
+ * (third-party vector_quantize_pytorch: Linear hidden -> 6, bounded rounding, Linear 6 -> hidden) stays with the caller
+ * (ace355/lmhints.py).  Same configuration fields as the detokenizer; `out_dim` is the acoustic width (64).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ace355_tok ace355_tok;
+typedef ace355_detok_config ace355_tok_config;
+int ace355_tok_create(const ace355_tok_config* cfg, ace355_tok** out);
+void ace355_tok_destroy(ace355_tok* h);
+/* name = a key of AceStepAudioTokenizer.state_dict() (`model.tokenizer`) outside `quantizer.`: "audio_acoustic_proj.*",
+ * "attention_pooler.*". */
+int ace355_tok_load_tensor(ace355_tok* h, const char* name, const void* data, int dtype, int64_t numel, int is_device);
+int ace355_tok_finalize(ace355_tok* h);
+/* x dev f32 [B, T5 * pool_window_size, out_dim] (25 Hz frames, whole windows) -> out dev f32 [B, T5, hidden]. */
+int ace355_tok_run(ace355_tok* h, const float* x_dev, int B, int T5, float* out_dev, void* stream);
+
 /* Post-decode peak clip, H/generate_music_decode.py:191-195: per item, if any peak > 1 divide
  * every item by clamp(peak, min=1).  wav dev f32 [B, per_item]. */
 int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream);

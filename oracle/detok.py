@@ -123,3 +123,60 @@ def detok_weight_shapes(cfg: DetokConfig) -> Dict[str, tuple]:
         s[q + "mlp.up_proj.weight"] = (F_, D)
         s[q + "mlp.down_proj.weight"] = (D, F_)
     return s
+
+
+# ------------------------------------------------------------------------------------------------ audio tokenizer
+# AceStepAudioTokenizer (base.py:1181-1223), the opposite direction: 25 Hz acoustic frames -> 5 Hz quantised tokens.
+#   * ``tokenizer_pool`` (audio_acoustic_proj + AttentionPooler, base.py:734-859, 1213-1215) is PINNED against the imported
+#     reference by tests/golden/make_golden.py (fixture G17).
+#   * ``fsq_quantize`` is **parity unpinned** for the reason given in the header (vector_quantize_pytorch absent): restated from
+#     the published algorithm - ResidualFSQ(num_quantizers=1): project_in Linear(dim -> 6); FSQ.bound: half_l = (L - 1)(1 + eps)/2
+#     with eps = 1e-3, offset = 0.5 for even L, shift = atanh(offset / half_l), z_b = tanh(z + shift) half_l - offset; round;
+#     codes = round(z_b) / floor(L / 2); index = sum((round(z_b) + floor(L/2)) * basis); project_out Linear(6 -> dim).
+
+def tokenizer_pool(cfg: DetokConfig, w: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """x [B, T5, P, 64] -> pooled [B, T5, D]: AceStepAudioTokenizer.forward up to the quantizer."""
+    B, T, P, _ = x.shape
+    D = cfg.hidden_size
+    h = F.linear(x, w["audio_acoustic_proj.weight"], w["audio_acoustic_proj.bias"])
+    a = "attention_pooler."
+    h = F.linear(h, w[a + "embed_tokens.weight"], w[a + "embed_tokens.bias"])
+    h = torch.cat([w[a + "special_token"].expand(B, T, 1, -1), h], dim=2).reshape(B * T, P + 1, D)
+    S = P + 1
+    cos, sin = o_dit.rope_cos_sin(S, cfg.head_dim, cfg.rope_theta)
+    full = o_cond.mask_4d(S, None, None)
+    slide = o_cond.mask_4d(S, None, cfg.sliding_window)
+    for li in range(cfg.num_attention_pooler_hidden_layers):
+        m = slide if cfg.layer_types[li] == "sliding_attention" else full
+        h = o_cond.encoder_layer(cfg, w, f"{a}layers.{li}.", h, cos, sin, m)
+    h = o_dit.rms_norm(h, w[a + "norm.weight"], cfg.rms_norm_eps)
+    return h[:, 0, :].reshape(B, T, D)
+
+
+def fsq_quantize(z: Tensor, levels: Sequence[int], project_in_w: Tensor, project_in_b: Optional[Tensor], project_out_w: Tensor,
+                 project_out_b: Optional[Tensor], eps: float = 1e-3):
+    """ResidualFSQ(num_quantizers=1).forward: z [..., dim] -> (quantized [..., dim], indices [..., 1])  (parity unpinned)."""
+    lv = torch.tensor(list(levels), dtype=torch.float32)
+    y = F.linear(z, project_in_w, project_in_b)
+    half_l = (lv - 1) * (1 + eps) / 2
+    offset = torch.where(lv.to(torch.int64) % 2 == 0, torch.tensor(0.5), torch.tensor(0.0))
+    shift = torch.atanh(offset / half_l)
+    q = torch.round(torch.tanh(y + shift) * half_l - offset)
+    half_w = torch.floor(lv / 2)
+    codes = q / half_w
+    lvi = lv.to(torch.int64)
+    basis = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.int64), lvi[:-1]]), dim=0)
+    idx = ((q + half_w).to(torch.int64) * basis).sum(-1, keepdim=True)
+    return F.linear(codes, project_out_w, project_out_b), idx
+
+
+def tok_weight_shapes(cfg: DetokConfig) -> Dict[str, tuple]:
+    """Names/shapes of AceStepAudioTokenizer.state_dict() (``model.tokenizer``) outside ``quantizer.``."""
+    D = cfg.hidden_size
+    s = {"audio_acoustic_proj.weight": (D, cfg.audio_acoustic_hidden_dim), "audio_acoustic_proj.bias": (D,),
+         "attention_pooler.embed_tokens.weight": (D, D), "attention_pooler.embed_tokens.bias": (D,),
+         "attention_pooler.norm.weight": (D,), "attention_pooler.special_token": (1, 1, D)}
+    for k, v in detok_weight_shapes(cfg).items():
+        if k.startswith("layers."):
+            s["attention_pooler." + k] = v
+    return s

@@ -56,3 +56,67 @@ def test_detokenizer_full_size_vs_oracle_and_code_path(gpu_device):
     assert decode_audio_codes_to_latents("no codes here", det, pw, pb) is None
     with pytest.raises(ValueError):
         det(torch.zeros(1, 4, cfg.hidden_size), attention_mask=torch.ones(1, 4))
+
+
+def test_audio_tokenizer_vs_reference_golden(gpu_device, golden_dir):
+    """G17: AceStepAudioTokenizer up to its quantizer (audio_acoustic_proj + AttentionPooler, base.py:734-859, 1181-1218) through
+    ace355_tok_* against the vector captured from the imported reference."""
+    import ace355
+    from ace355 import weightgen
+    from ace355.lmhints import NativeAudioTokenizer
+    from oracle import detok as o_detok
+    G = np.load(f"{golden_dir}/g17_audio_tokenizer.npz")
+    cfg = ace355.DetokConfig(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
+    o_cfg = o_detok.DetokConfig(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
+    w = weightgen.make_dit_weights(o_detok.tok_weight_shapes(o_cfg), cfg.hidden_size, seed=int(G["seed"]), mode="test")
+    assert abs(weightgen.checksum(w) - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    tok = NativeAudioTokenizer(cfg, gpu_device)
+    tok.load_state_dict(w)
+    y = tok.pool(torch.from_numpy(G["x"]))
+    ref = torch.from_numpy(G["y"])
+    assert y.shape == ref.shape
+    r = _rel(y.cpu(), ref)
+    print(f"audio tokenizer (tiny; projection + attention pooler) vs reference fp32: rel L2 {r:.3e}")
+    assert r < 2e-2, r   # measured 6.9e-3
+    with pytest.raises(RuntimeError, match="quantizer"):
+        tok(torch.from_numpy(G["x"]))   # no quantizer.* weights were loaded
+    with pytest.raises(ValueError):
+        tok.pool(torch.zeros(1, 7, 64))  # not whole windows
+
+
+def test_audio_tokenizer_full_size_round_trip_through_the_detokenizer(gpu_device):
+    """Real architecture: 10 s of latents -> NativeAudioTokenizer (pooler native, FSQ restated) -> NativeDetokenizer, the chain
+    prepare_condition runs for a cover task without precomputed hints (base.py:1645-1649), against the oracle's chain."""
+    import ace355
+    from ace355 import weightgen
+    from ace355.lmhints import NativeAudioTokenizer, NativeDetokenizer, fsq_output_from_indices
+    from oracle import detok as o_detok
+    cfg = ace355.DetokConfig()
+    o_cfg = o_detok.DetokConfig()
+    wt = weightgen.make_dit_weights(o_detok.tok_weight_shapes(o_cfg), cfg.hidden_size, seed=21, mode="test")
+    wd = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=22, mode="test")
+    g = torch.Generator().manual_seed(9)
+    q = {"quantizer.project_in.weight": 0.05 * torch.randn(6, cfg.hidden_size, generator=g), "quantizer.project_in.bias": 0.1 * torch.randn(6, generator=g),
+         "quantizer.project_out.weight": 0.5 * torch.randn(cfg.hidden_size, 6, generator=g), "quantizer.project_out.bias": 0.1 * torch.randn(cfg.hidden_size, generator=g)}
+    tok = NativeAudioTokenizer(cfg, gpu_device)
+    tok.load_state_dict({**wt, **q})
+    det = NativeDetokenizer(cfg, gpu_device)
+    det.load_state_dict(wd)
+    x = torch.randn(2, 250, 64, generator=g)
+    pooled = tok.pool(x)
+    ref_pool = o_detok.tokenizer_pool(o_cfg, wt, x.reshape(2, 50, 5, 64))
+    rp = _rel(pooled.cpu(), ref_pool)
+    quant, idx = tok.tokenize(x)
+    assert quant.shape == (2, 50, cfg.hidden_size) and idx.shape == (2, 50, 1) and int(idx.min()) >= 0 and int(idx.max()) < 64000
+    # the two FSQ restatements agree with each other: decoding the indices gives the quantised output back
+    back = fsq_output_from_indices(idx, q["quantizer.project_out.weight"].to(gpu_device), q["quantizer.project_out.bias"].to(gpu_device))
+    assert float((back - quant).abs().max()) < 1e-5
+    # the same rounding decisions as the oracle's quantizer wherever the pooled value is not within bf16 noise of a rounding boundary
+    oq, oidx = o_detok.fsq_quantize(ref_pool, o_detok.FSQ_LEVELS if hasattr(o_detok, "FSQ_LEVELS") else (8, 8, 8, 5, 5, 5), q["quantizer.project_in.weight"],
+                                    q["quantizer.project_in.bias"], q["quantizer.project_out.weight"], q["quantizer.project_out.bias"])
+    agree = float((oidx == idx.cpu()).float().mean())
+    hints = det(quant)
+    assert hints.shape == (2, 250, 64) and bool(torch.isfinite(hints).all())
+    print(f"audio tokenizer (full size): pooled rel L2 vs fp32 oracle {rp:.3e}; {100 * agree:.0f} % of the 100 tokens get the oracle's code index")
+    assert rp < 2.5e-2, rp        # measured 1.07e-2 (two plain-residual layers + one more bf16 operand than the detokenizer)
+    assert agree > 0.7, agree     # measured 0.93

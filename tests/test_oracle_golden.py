@@ -165,6 +165,30 @@ def test_g8_detokenizer_and_code_parser(golden_dir):
     assert len({tuple(r.tolist()) for r in o_detok.fsq_codes_from_indices(torch.arange(64000), (8, 8, 8, 5, 5, 5))}) == 64000
 
 
+def test_g17_audio_tokenizer(golden_dir):
+    """The other direction of row N2: AceStepAudioTokenizer up to its quantizer (acoustic projection + AttentionPooler) vs the
+    imported reference; the FSQ restatement behind it is parity unpinned - structural checks: indices and codes are consistent,
+    every level is reachable, the bound keeps every digit in range."""
+    G = np.load(f"{golden_dir}/g17_audio_tokenizer.npz")
+    cfg = o_detok.DetokConfig(hidden_size=256, intermediate_size=768, num_attention_heads=2, num_key_value_heads=1, head_dim=128)
+    w = weightgen.make_dit_weights(o_detok.tok_weight_shapes(cfg), cfg.hidden_size, seed=int(G["seed"]), mode="test")
+    assert abs(weightgen.checksum(w) - float(G["wsum"])) < 1e-6 * float(G["wsum"])
+    x = T(G["x"])
+    y = o_detok.tokenizer_pool(cfg, w, x.reshape(x.shape[0], -1, cfg.pool_window_size, x.shape[-1]))
+    assert float((y - T(G["y"])).abs().max()) < 2e-5
+    g = torch.Generator().manual_seed(1)
+    lv = (8, 8, 8, 5, 5, 5)
+    pin, pout = torch.eye(6), torch.eye(6)
+    z = 3.0 * torch.randn(4000, 6, generator=g)
+    quant, idx = o_detok.fsq_quantize(z, lv, pin, None, pout, None)
+    assert int(idx.min()) >= 0 and int(idx.max()) < 64000
+    assert torch.allclose(o_detok.fsq_codes_from_indices(idx[..., 0], lv), quant)          # index <-> code consistency
+    for i, L in enumerate(lv):
+        assert len(torch.unique(quant[:, i])) == L                                          # every level reachable, none outside
+    big = o_detok.fsq_quantize(torch.full((1, 6), 50.0), lv, pin, None, pout, None)[0]
+    assert torch.allclose(big, torch.tensor([[0.75, 0.75, 0.75, 1.0, 1.0, 1.0]]))          # saturation = the top level
+
+
 @pytest.mark.parametrize("name", ["shift3", "shift1", "snap", "explicit", "cover", "sde_shift3"])
 def test_g9_turbo_sampler(golden_dir, name):
     """The turbo model's 8-step loop (turbo.py:1780-1995) vs the imported turbo reference; "sde_shift3" replays the reference's

@@ -43,8 +43,11 @@ class NativeDitMixin:
     def _init_native_dit(self) -> bool:
         """Counterpart of ``_init_mlx_dit``: convert weights from the already-loaded PyTorch module. Never raises."""
         try:
-            if getattr(self, "use_lora", False) or getattr(self, "quantization", None) or getattr(self, "offload_to_cpu", False):
-                logger.info("[native-dit] LoRA / quantization / CPU offload active; keeping the PyTorch path")
+            quant = getattr(self, "quantization", None)
+            # the reference's quantization knob (init_service_loader.py:89-113): "fp8_weight_only" has a native counterpart (same
+            # numerics: per-channel e4m3 weights, bf16 arithmetic); the int8 schemes do not
+            if getattr(self, "use_lora", False) or (quant and quant != "fp8_weight_only") or getattr(self, "offload_to_cpu", False):
+                logger.info("[native-dit] LoRA / int8 quantization / CPU offload active; keeping the PyTorch path")
                 self.use_native_dit, self.native_dit = False, None
                 return False
             from .dit import NativeDit
@@ -52,6 +55,8 @@ class NativeDitMixin:
                 else self.model.config
             dit = NativeDit(cfg, self.device)
             dit.load_state_dict(self.model.decoder.state_dict())
+            if quant == "fp8_weight_only":
+                dit.set_precision("fp8_weight_only")
             self.native_dit, self.use_native_dit = dit, True
             logger.info("[native-dit] decoder packed for gfx950 (%d layers, hidden %d)", cfg.num_hidden_layers, cfg.hidden_size)
             return True

@@ -158,6 +158,8 @@ int gemm_verify_splitk_placement();   // one-time XCD placement check behind the
 bool gemm_fold_supported();   // the folded-RMSNorm epilogue hooks exist in the kernels launch_gemm will use (not the v1 bring-up kernel)
 // x bf16 [M, K] (row stride ld) -> q fp8 e4m3 [M, K] + scales uint32 [K / 128][rows_pad] (rows_pad >= M, multiple of 4)
 int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t* scales, int rows_pad, hipStream_t s);
+// rows of a packed bf16 weight matrix through e4m3 with one scale per row and back (fp8 weight-only semantics; elementwise.hip)
+int launch_fp8_weight_roundtrip(bf16_t* w, long ld, int N, int K, hipStream_t s);
 inline int mx_rows_pad(int rows) { return ((rows + 255) / 256) * 256 + 256; }
 
 constexpr int SK_MAX_TILES = 4096;

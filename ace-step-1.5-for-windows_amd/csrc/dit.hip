@@ -88,6 +88,7 @@ struct ace355_dit {
     size_t g_ctx_nc_n = 0, g_sde_n = 0;            // re-allocated per call: their addresses must not be part of the graph)
     // MXFP8 mode (BASELINE configs[4] "fp8 MFMA"): the four big projections of every layer run on v_mfma_scale_f32_32x32x64_f8f6f4
     int precision = 0;                 // ACE355_PRECISION_*
+    bool weights_fp8wo = false;        // the Linear weights went through the fp8 weight-only round trip (one way: reload to undo)
     std::vector<void*> mx_allocs;      // weight copies
     uint8_t* xq = nullptr;             // activation operand of the current MX GEMM, fp8 [M, max(D, F)]
     uint32_t* xs = nullptr;            // its scales [max(D, F) / 128][xs_pad]
@@ -857,6 +858,7 @@ int ace355_dit_load_tensor(ace355_dit* h, const char* name, const void* data, in
     ACE_HIP(hipDeviceSynchronize());
     h->loaded.insert(name);
     h->finalized = false;
+    h->weights_fp8wo = false;   // (fresh weights: the round trip, if wanted, is applied again by set_precision)
     return ACE355_OK;
 }
 
@@ -1099,9 +1101,47 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
 
 int ace355_dit_set_precision(ace355_dit* h, int precision) {
     ACE_CHECK(h, "set_precision: null handle");
-    ACE_CHECK(precision == ACE355_PRECISION_BF16 || precision == ACE355_PRECISION_MXFP8, "set_precision: unknown precision");
+    ACE_CHECK(precision == ACE355_PRECISION_BF16 || precision == ACE355_PRECISION_MXFP8 || precision == ACE355_PRECISION_FP8_WEIGHT_ONLY,
+              "set_precision: unknown precision");
     if (!h->finalized) { set_error("set_precision: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
     ACE_HIP(hipDeviceSynchronize());
+    if (h->weights_fp8wo && precision != ACE355_PRECISION_FP8_WEIGHT_ONLY) {
+        set_error("set_precision: the weights were rounded through fp8 (fp8_weight_only); load them again before selecting another precision");
+        return ACE355_ERR_STATE;
+    }
+    if (precision == ACE355_PRECISION_FP8_WEIGHT_ONLY) {
+        // every nn.Linear of the decoder (the reference's filter keeps all Linears outside tokenizer / detokenizer, init_service_loader.py:
+        // 104-113; proj_in / proj_out are Conv1d / ConvTranspose1d and stay): per-output-channel e4m3 + fp32 scale, dequantised to bf16 -
+        // applied once, in place, to the packed weights (row packing commutes with a per-row quantiser); the kernels are the bf16 ones
+        if (!h->weights_fp8wo) {
+            ACE_CHECK(h->mx_allocs.empty(), "set_precision: fp8_weight_only after mxfp8 would round already-copied weights; use a fresh handle");
+            const int D = h->D, F = h->F, QD = h->QD, KVD = h->KVD;
+            int rc = 0;
+            for (LayerW& L : h->layers) {
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wqkv, D, QD + 2 * KVD, D, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wo, QD, D, QD, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wq_c, D, QD, D, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wkv_c, D, 2 * KVD, D, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wo_c, QD, D, QD, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wgu, D, 2 * F, D, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(L.wdown, F, D, F, nullptr);
+            }
+            for (int e = 0; e < 2 && !rc; ++e) {
+                rc = launch_fp8_weight_roundtrip(h->te[e].l1, 256, D, 256, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(h->te[e].l2, D, D, D, nullptr);
+                if (!rc) rc = launch_fp8_weight_roundtrip(h->te[e].tp, D, 6 * D, D, nullptr);
+            }
+            if (!rc) rc = launch_fp8_weight_roundtrip(h->w_cond, D, D, D, nullptr);
+            if (rc) return rc;
+            ACE_HIP(hipDeviceSynchronize());
+            h->weights_fp8wo = true;
+            h->nf.key.clear();        // embedding / bias tables are functions of the weights
+            for (CondSlot& c : h->slots) c.valid = false;   // cross K/V were projected with the unrounded weights
+        }
+        h->precision = ACE355_PRECISION_BF16;   // (compute path: the bf16 kernels)
+        h->ws_epoch++;
+        return ACE355_OK;
+    }
     if (precision == ACE355_PRECISION_MXFP8 && h->mx_allocs.empty()) {
         // block-quantise the four big packed projections of every layer once (rows keep their packed order: head-pair q / k rows,
         // [32 gate | 32 up] interleave - quantisation is per row, so the packing commutes with it)

@@ -876,6 +876,37 @@ int launch_mx_quant(const bf16_t* x, long ld, int M, int K, uint8_t* q, uint32_t
     return 0;
 }
 
+// fp8 weight-only semantics (the reference's `quantization="fp8_weight_only"`: torchao Float8WeightOnlyConfig, handler/
+// init_service_loader.py:95-97): every Linear weight is held as e4m3 with one fp32 scale per output channel and dequantised to the
+// activation dtype for the matmul.  There is no MFMA for bf16 x fp8, so the numerics are applied to the packed bf16 weights in place:
+// w[n][:] <- bf16( e4m3_rne( w[n][:] / s_n ) * s_n ),  s_n = max(amax_n, 1e-12) / 448.  One wave per row.
+__global__ __launch_bounds__(256) void fp8_weight_roundtrip_kernel(bf16_t* __restrict__ w, long ld, int N, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    bf16_t* wr = w + (long)row * ld;
+    float amax = 0.f;
+    for (int c = lane * 2; c < K; c += 128) {
+        const uint32_t p = *reinterpret_cast<const uint32_t*>(wr + c);
+        amax = fmaxf(amax, fmaxf(fabsf(bf_lo(p)), fabsf(bf_hi(p))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float scale = fmaxf(amax, 1e-12f) / 448.f;
+    for (int c = lane * 2; c < K; c += 128) {
+        const uint32_t p = *reinterpret_cast<const uint32_t*>(wr + c);
+        const float a0 = fminf(fmaxf(bf_lo(p) / scale, -448.f), 448.f), a1 = fminf(fmaxf(bf_hi(p) / scale, -448.f), 448.f);
+        const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, 0, false);
+        const float q0 = __builtin_amdgcn_cvt_f32_fp8(pk, 0), q1 = __builtin_amdgcn_cvt_f32_fp8(pk, 1);
+        *reinterpret_cast<uint32_t*>(wr + c) = pack_bf2(q0 * scale, q1 * scale);
+    }
+}
+int launch_fp8_weight_roundtrip(bf16_t* w, long ld, int N, int K, hipStream_t s) {
+    ACE_CHECK(K % 2 == 0 && ld % 2 == 0, "fp8_weight_roundtrip: even row length");
+    hipLaunchKernelGGL(fp8_weight_roundtrip_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, ld, N, K);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_rope_table(float* cos_tab, float* sin_tab, int S, float theta, hipStream_t s) {
     std::vector<float> c((size_t)S * 64), sn((size_t)S * 64);
     float inv[64];

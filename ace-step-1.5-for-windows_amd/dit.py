@@ -186,11 +186,12 @@ class NativeDit:
 
     # ------------------------------------------------------------------ precision of the four big projections
     def set_precision(self, precision: str) -> None:
-        """"bf16" (default, the reference GPU path's dtype) or "mxfp8" (OCP MXFP8 operands on the scaled fp8 MFMA; BASELINE
-        configs[4]; the reference's knob is torchao `fp8_weight_only` / `w8a8_dynamic`, init_service_loader.py:89-113)."""
-        code = {"bf16": 0, "mxfp8": 1}.get(precision)
+        """"bf16" (default, the reference GPU path's dtype), "mxfp8" (OCP MXFP8 operands on the scaled fp8 MFMA; BASELINE
+        configs[4]) or "fp8_weight_only" (the reference's `quantization="fp8_weight_only"` numerics: every Linear weight rounded
+        through per-channel e4m3 once, bf16 kernels; init_service_loader.py:89-113; one way - reload the weights to undo)."""
+        code = {"bf16": 0, "mxfp8": 1, "fp8_weight_only": 2}.get(precision)
         if code is None:
-            raise ValueError(f"unknown precision '{precision}' (bf16 | mxfp8)")
+            raise ValueError(f"unknown precision '{precision}' (bf16 | mxfp8 | fp8_weight_only)")
         with torch.cuda.device(self.device):
             native.check(self._lib.ace355_dit_set_precision(self._h, code), "dit_set_precision")
 

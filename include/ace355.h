@@ -132,9 +132,14 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
  * path's dtype.  MXFP8 = BASELINE configs[4] "fp8 MFMA": OCP MXFP8 operands (e4m3, one E8M0 scale per 32 K elements; weights
  * quantised once here, activations per launch) on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate, same epilogues; launches with
  * fewer than 1536 token rows keep the bf16 kernels.  The reference's counterpart is torchao fp8 on the DiT Linears
- * (handler/init_service_loader.py:89-113; absent here: parity unpinned, tolerance stated in DESIGN.md).  Call after finalize. */
+ * (handler/init_service_loader.py:89-113; absent here: parity unpinned, tolerance stated in DESIGN.md).  Call after finalize.
+ * FP8_WEIGHT_ONLY = the reference's default fp8 knob (`quantization="fp8_weight_only"`, torchao Float8WeightOnlyConfig,
+ * init_service_loader.py:95-97): weights as e4m3 with one fp32 scale per output channel, activations and arithmetic bf16.  gfx950 has
+ * no bf16 x fp8 MFMA, so this mode applies the NUMERICS (every Linear weight rounded through per-channel e4m3 once, in place) and
+ * runs the bf16 kernels: same speed and memory as BF16.  One way: load the weights again to go back. */
 #define ACE355_PRECISION_BF16 0
 #define ACE355_PRECISION_MXFP8 1
+#define ACE355_PRECISION_FP8_WEIGHT_ONLY 2
 int ace355_dit_set_precision(ace355_dit* h, int precision);
 
 /* hipGraph replay of the sampling loop: with enable != 0, ace355_dit_sample captures its launch

@@ -45,3 +45,22 @@ def pack_scales(sb: torch.Tensor, rows_pad: int) -> torch.Tensor:
     out = torch.zeros(nb // 4, rows_pad, dtype=torch.int64)
     out[:, :M] = word.t()
     return out
+
+
+def fp8_weight_only_roundtrip(weights: dict) -> dict:
+    """The numerics of the reference's `quantization="fp8_weight_only"` (torchao Float8WeightOnlyConfig on every nn.Linear of the DiT
+    outside tokenizer / detokenizer, init_service_loader.py:95-113; torchao absent: **parity unpinned**, restated from its documented
+    scheme): per output channel scale s = max(amax, 1e-12) / 448 in fp32, q = e4m3_rne(w / s), dequantised weight = bf16(q * s).
+    Returns a copy of a decoder state dict with every Linear weight replaced; Conv1d / ConvTranspose1d (proj_in / proj_out), norms,
+    biases and the scale-shift tables are not Linears and stay."""
+    out = {}
+    for k, v in weights.items():
+        is_linear = v.dim() == 2 and k.endswith(".weight") and not k.startswith("proj_in") and not k.startswith("proj_out") and "norm" not in k
+        if not is_linear:
+            out[k] = v
+            continue
+        w = v.detach().to(torch.bfloat16).to(torch.float32)
+        s = w.abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / 448.0
+        q = (w / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+        out[k] = (q * s).to(torch.bfloat16).to(torch.float32)
+    return out

@@ -146,3 +146,46 @@ def test_mxfp8_forward_and_sampler_at_the_metric_shape(gpu_device, golden_dir, f
     assert torch.isfinite(v).all() and not torch.equal(v, v_bf16)   # the mode is really on
     assert r < 8e-2 and rs < 8e-2, (r, rs)
     assert _rel(dit.forward(*args).cpu(), v_bf16.cpu()) == 0.0     # and really off again
+
+
+def test_fp8_weight_only_semantics(gpu_device, golden_dir):
+    """`set_precision("fp8_weight_only")` = the reference's default fp8 knob (torchao Float8WeightOnlyConfig: e4m3 weights with one
+    scale per output channel, bf16 arithmetic; init_service_loader.py:95-97) as NUMERICS on the bf16 kernels.  The native tiny sampler in
+    that mode against the oracle run on weights that went through the same round trip in torch (oracle/mx.py; unpinned vs torchao,
+    which is absent), and the mode's own distance from the unquantised reference golden; switching back without a reload is refused."""
+    import numpy as np
+    import ace355
+    from ace355 import weightgen
+    from ace355.dit import NativeDit, generate_latents
+    from oracle import dit as o_dit, mx as o_mx, sampler as o_sampler
+    G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
+    kw = dict(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1)
+    cfg = ace355.DitConfig(**kw)
+    w = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=int(G["seed"]), mode="test")
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=int(G["seed"]))
+    n = "cfg7_shift1"
+    enc, ctx = torch.from_numpy(G[n + "_enc"]), torch.from_numpy(G[n + "_ctx"])
+    lo, hi = G[n + "_interval"].tolist()
+    args = dict(seed=G[n + "_seeds"].tolist(), infer_steps=int(G[n + "_steps"]), diffusion_guidance_sale=float(G[n + "_guidance"]),
+                cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[n + "_shift"]))
+    dit = NativeDit(cfg, gpu_device)
+    dit.load_state_dict(w)
+    base = generate_latents(dit, null, enc.expand(ctx.shape[0], -1, -1), ctx, **args)["target_latents"].cpu()
+    dit.set_precision("fp8_weight_only")
+    out = generate_latents(dit, null, enc.expand(ctx.shape[0], -1, -1), ctx, **args)["target_latents"].cpu()
+    wq = o_mx.fp8_weight_only_roundtrip(w)
+    changed = [k for k in w if not torch.equal(w[k], wq[k])]
+    assert any("q_proj" in k for k in changed) and any("time_proj" in k for k in changed) and any(k == "condition_embedder.weight" for k in changed)
+    assert not any(k.startswith("proj_in") or k.startswith("proj_out") or "norm" in k or k.endswith(".bias") for k in changed)
+    ref_q = o_sampler.generate_audio(o_dit.DitConfig(**kw), wq, null, enc.expand(ctx.shape[0], -1, -1), ctx, **args)
+    ref = torch.from_numpy(G[n + "_out"])
+    r_same, r_mode, r_base = _rel(out, ref_q), _rel(out, ref), _rel(base, ref)
+    print(f"fp8_weight_only (tiny 27-step CFG sampler): native vs the oracle on round-tripped weights {r_same:.3e}; the mode vs the unquantised "
+          f"reference golden {r_mode:.3e} (bf16 mode: {r_base:.3e})")
+    assert r_same < 5e-3, r_same          # same gate as the bf16 path against its golden (measured there 0.7-1.7e-3)
+    assert r_base < r_mode < 2e-1         # the mode is on, and is what weight quantisation costs - not a broken path
+    with pytest.raises(RuntimeError, match="load them again"):
+        dit.set_precision("bf16")
+    dit.load_state_dict(w)                # fresh weights: back to plain bf16
+    again = generate_latents(dit, null, enc.expand(ctx.shape[0], -1, -1), ctx, **args)["target_latents"].cpu()
+    assert torch.equal(again, base)

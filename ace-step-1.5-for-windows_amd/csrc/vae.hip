@@ -739,13 +739,33 @@ int ace355_vae_decode_plan(ace355_vae* h, int B, int T, int32_t* items_per_windo
     return ACE355_OK;
 }
 
+static int encode_group(ace355_vae* h, const float* audio_dev, const float* noise_dev, int B, int64_t L, float* latents_out_dev, hipStream_t s);
+
 int ace355_vae_encode(ace355_vae* h, const float* audio_dev, const float* noise_dev, int B, int64_t L, float* latents_out_dev,
                       void* stream) {
     ACE_CHECK(h && audio_dev && latents_out_dev, "vae_encode: null argument");
     if (!h->finalized) { set_error("vae_encode: call ace355_vae_finalize first"); return ACE355_ERR_STATE; }
     if (!h->has_encoder) { set_error("vae_encode: no encoder.* tensors were loaded"); return ACE355_ERR_STATE; }
     ACE_CHECK(B > 0 && L > 0 && L < (1L << 30), "vae_encode: sizes");
-    hipStream_t s = (hipStream_t)stream;
+    // same activation budget as the decode (ace355_vae_set_decode_budget): above it the batch is encoded in groups of items (exact:
+    // items are independent; the reference's 30 s / 2 s-overlap encode tiling, H/vae_encode.py:47-86, is the same kind of memory bound)
+    const ace355_vae_config& c = h->cfg;
+    const int EH = 2 * c.decoder_input_channels, Z = c.decoder_input_channels;
+    const size_t per_item = (size_t)L * EH * 2 * 3 + (size_t)L * 64 * 2;
+    int nb = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, h->decode_budget / std::max<size_t>(per_item, 1)));
+    long T = L;
+    for (const EncBlockW& Bk : h->e_blocks) T = (T + 2 * Bk.pad - 2 * Bk.stride) / Bk.stride + 1;
+    ACE_CHECK(T > 0, "vae_encode: audio shorter than one latent frame");
+    for (int b0 = 0; b0 < B; b0 += nb) {
+        const int n = std::min(nb, B - b0);
+        int rc = encode_group(h, audio_dev + (size_t)b0 * c.audio_channels * L, noise_dev ? noise_dev + (size_t)b0 * Z * T : nullptr, n, L,
+                              latents_out_dev + (size_t)b0 * Z * T, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return ACE355_OK;
+}
+
+static int encode_group(ace355_vae* h, const float* audio_dev, const float* noise_dev, int B, int64_t L, float* latents_out_dev, hipStream_t s) {
     const ace355_vae_config& c = h->cfg;
     const int EH = 2 * c.decoder_input_channels, Z = c.decoder_input_channels;
     // stage lengths: Conv1d(k = 2s, stride s, pad ceil(s/2)): L_out = floor((L + 2 pad - 2 s) / s) + 1

@@ -150,3 +150,23 @@ def test_encode_requires_encoder_weights(gpu_device):
     cfg, w, vae = _build(dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6)), gpu_device)
     with pytest.raises(RuntimeError, match="encoder"):
         vae.encode(torch.zeros(1, 2, cfg.hop * 4))
+
+
+def test_encode_in_item_groups_under_a_small_budget(gpu_device):
+    """The encoder shares the decode's activation budget: above it the batch runs in groups of items - exact, items are independent
+    (the reference bounds encode memory by tiling, handler/vae_encode.py:47-86)."""
+    import ace355
+    from ace355 import weightgen
+    from ace355.vae import NativeVae
+    cfg = ace355.VaeConfig()
+    w = weightgen.make_vae_weights({**cfg.weight_shapes(), **cfg.encoder_weight_shapes()}, seed=2, mode="test")
+    audio = 0.3 * torch.randn(3, 2, cfg.hop * 20, generator=torch.Generator().manual_seed(5))
+    outs = []
+    for budget in (0, 3 * (cfg.hop * 20) * 128 * 2 * 3 // 2):   # default; then room for one item at a time
+        vae = NativeVae(cfg, gpu_device)
+        vae.load_state_dict(w)
+        if budget:
+            vae.set_decode_budget(budget)
+        outs.append(vae.encode(audio, sample=False).cpu())
+        vae.close()
+    assert outs[0].shape == (3, 64, 20) and torch.equal(outs[0], outs[1])

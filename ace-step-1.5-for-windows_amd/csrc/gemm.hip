@@ -1190,7 +1190,9 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         static int bigenv = -1;
         if (bigenv < 0) bigenv = env_int("ACE355_GEMM_BIG", 1);  // 0 never, 1 heuristic, 2 always
         const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
-        if (bigenv == 2 || (bigenv == 1 && tbig >= 200 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
+        // (>= 180 tiles: three quarters of the CUs with one 8-wave workgroup each beat the same work as 384 four-wave workgroups on 512
+        //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
         else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 && t192 <= 320))) { mt = 3; bn = 128; big = 2; }
     }
     // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every

@@ -157,19 +157,22 @@ def vae_flops_per_frame(vcfg):
     return f
 
 
-def pmc_traffic_bytes_per_launch():
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (profiles/*.json,
+def pmc_traffic_bytes_per_launch(with_source=False):
+    """L2-miss-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (profiles/*.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950 tallies
-    128-B requests at 64 B; both counters are in KiB).  None when no profile is present: bench.py cannot collect PMCs."""
+    128-B requests at 64 B; both counters are in KiB).  These counters sit between the XCDs' L2s and the fabric: the bytes
+    include Infinity-Cache hits, i.e. they bound HBM traffic from above.  None when no profile is present: bench.py cannot
+    collect PMCs in its own process."""
     try:
         import glob
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")))[-1]
         w = f.replace("FETCH_SIZE", "WRITE_SIZE")
         fetch = json.load(open(f))["gemm"]["FETCH_SIZE"]["per_launch"]
         write = json.load(open(w))["gemm"]["WRITE_SIZE"]["per_launch"]
-        return (2.0 * fetch + write) * 1024.0
+        b = (2.0 * fetch + write) * 1024.0
+        return (b, os.path.relpath(f, ROOT)) if with_source else b
     except Exception:
-        return None
+        return (None, None) if with_source else None
 
 
 def usable_cpus() -> int:
@@ -487,8 +490,10 @@ def main():
                            "the standalone rmsnorm kernels (13.0 + 13.0 + 7.3 us per layer) are gone from the pass",
                 "gemm_ms_per_pass_norms_as_kernels": q["gemm_ms"], "achieved_norms_as_kernels": q_tf, "frac_norms_as_kernels": q_tf / peak}
         tr = result["roofline"]["traffic"]
-        # HBM-side GB/s of the dominant kernel = PMC bytes per launch (committed profile of this command) / live launch time
+        # L2-miss-side GB/s of the dominant kernel = PMC bytes per launch (committed profile of this command) / live launch time
         result["roofline"]["hbm_gbps"] = (tr / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9) if tr else None
+        result["roofline"]["traffic_source"] = (f"{pmc_traffic_bytes_per_launch(True)[1]} + WRITE_SIZE twin: rocprofv3 --pmc passes of this command, committed "
+                                                "(not collected live); fabric-side of the L2s, so Infinity-Cache hits are included: an upper bound on HBM bytes")
         do_cfg = args.guidance > 1.0
         alg = B * ((2 if do_cfg else 1) * args.infer_steps * dit_flops_per_forward_per_seq(dcfg, S, L) + (0 if args.no_vae else T * vae_flops_per_frame(vcfg)))
         result["algorithmic_tflop_per_step"] = alg / 1e12

@@ -143,6 +143,11 @@ struct GemmEpilogue {
     // (ksplit stays 1: no atomics, no serialised read-modify-writes of H).  kparts / sk_slab are set by launch_gemm; the caller lends
     // sk_slab_cap floats.
     float* sk_slab; long sk_slab_cap; int kparts;
+    // mode 4, v tiles (columns >= hn_qk_cols): written TRANSPOSED straight from the accumulators, vt[seq][head][d][s] (row pitch vt_ld,
+    // s = row % rows_per_seq), instead of as rows of C - the separate transpose_v launch of a small-M forward disappears (2-byte stores,
+    // 32 consecutive key positions per half wave: fine for the few tiles of a small-M launch, too slow for the big tiles, so launch_gemm
+    // clears vt_out for those and reports through *vt_done what it did).  Pad positions [S, vt_ld) are the caller's to keep zero.
+    bf16_t* vt_out; int vt_ld; int vt_heads; int* vt_done;
     unsigned long long* nf_sqA; unsigned long long* nf_sqB;   // 2^-24 fixed point: integer adds commute, so the sums (and with them
     const unsigned long long* nc_rowsq; const float* nc_bias;  // every result) do not depend on the order the atomics arrive in
     float nc_inv_d, nc_eps;

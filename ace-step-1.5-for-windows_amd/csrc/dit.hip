@@ -61,6 +61,7 @@ struct ace355_dit {
 
     // workspace
     int ws_N = 0, ws_T = 0;
+    int vt_key_N = -1, vt_key_S = -1;   // (N, S) the pad columns of vt were last zeroed for
     std::vector<void*> ws_allocs;
     bf16_t *xin = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr;
     float *h = nullptr, *vpad = nullptr, *tfreq = nullptr, *ta1 = nullptr, *temb = nullptr, *tsilu = nullptr, *tproj = nullptr;
@@ -340,6 +341,7 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
     }
     h->ws_N = capN;
     h->ws_T = capT;
+    h->vt_key_N = h->vt_key_S = -1;
     h->ws_epoch++;
     return 0;
 }
@@ -485,6 +487,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     const int Nc = N - n_sc, Mc = Nc * S;
     const float* cconst = n_sc ? h->slots[slots[N - 1]].cross_const : nullptr;
 
+    if (h->vt_key_N != N || h->vt_key_S != S) {   // V^T layout [N][KVH][128][Sp] changed: pad positions [S, Sp) must read as zero
+        ACE_HIP(hipMemsetAsync(h->vt, 0, (size_t)N * h->KVH * 128 * Sp * sizeof(bf16_t), s));
+        h->vt_key_N = N; h->vt_key_S = S;
+    }
     const long gs_stride = temb_rows == 1 ? 0 : (long)h->NL * 4 * D;
     // folded RMSNorm (sampler path): row sums of squares of the 3 NL norm inputs accumulate during this forward
     const bool fold = h->nf.on && temb_rows == 1 && M <= h->nf.cap_M;
@@ -533,12 +539,16 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             ep.nc_rowsq = rowsq(li, 0); ep.nc_bias = nf.bias_qkv + ((size_t)li * nf.rows + nf.step) * QKV;
             ep.nc_inv_d = inv_d; ep.nc_eps = eps;
         }
+        int vt_done = 0;   // small-M launches write V^T from the QKV epilogue (GemmEpilogue::vt_out): no transpose_v launch
+        ep.vt_out = h->vt; ep.vt_ld = Sp; ep.vt_heads = h->KVH; ep.vt_done = &vt_done;
         if (mx_qkv) rc = gemm_mx(h, nullptr, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
         if (rc) return rc;
-        rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
-        if (rc) return rc;
+        if (!vt_done) {
+            rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
+            if (rc) return rc;
+        }
         bool ao_is_mx = false;
         {
             AttnArgs a{};

@@ -88,6 +88,33 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         // mode 4, q / k tiles (workgroup-uniform): per-row sum of squares over the head's 128 columns = this wave's 64 (two
         // half-rows in lanes l and l^32) + the neighbouring wave's 64, swapped through `xw`; then w * (v * rstd) and the
         // rotation of the adjacent (d, d+64) pairs, all on the fp32 accumulators (one bf16 rounding instead of two)
+        if constexpr (MODE == 4) {
+            if (ep.vt_out && nw0 >= ep.hn_qk_cols) {   // v tile -> V^T (workgroup-uniform: q | k | v boundaries fall on tile edges)
+                const int rps = ep.rows_per_seq;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int m = mw0 + i * 32 + frow;
+                    const int sq = m / rps, sp = m - sq * rps;
+                    bf16_t* base = ep.vt_out + (long)sq * ep.vt_heads * 128 * ep.vt_ld + sp;
+                    const bool ok = ROWS_FULL || m < M;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bq = fold_bias(j, g);
+                            const int c = nw0 - ep.hn_qk_cols + j * 32 + 8 * g + 4 * fhalf;   // head * 128 + d of this lane's 4 columns
+                            bf16_t* col = base + (long)c * ep.vt_ld;
+                            if (ok) {
+                                col[0] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 0], rs_in[i], bq.x));
+                                col[ep.vt_ld] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 1], rs_in[i], bq.y));
+                                col[2 * (long)ep.vt_ld] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 2], rs_in[i], bq.z));
+                                col[3 * (long)ep.vt_ld] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 3], rs_in[i], bq.w));
+                            }
+                        }
+                }
+                return;
+            }
+        }
         float rstd[MT];
         const bool hn = (MODE == 4) && (nw0 < ep.hn_qk_cols);
         const float* hw = nullptr;
@@ -1279,6 +1306,11 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
             const int tw = big == 1 ? 256 : 128;  // tile width: q | k | v boundaries must fall on tile edges
             const bool fused = fuse && variant != 1 && (big != 2 || mid_ns4 == 3) && ep.wide_ok && N % tw == 0 && ep.hn_q_cols % tw == 0 &&
                                ep.hn_qk_cols % tw == 0;
+            static int vt_env = -1;
+            if (vt_env < 0) vt_env = env_int("ACE355_GEMM_VT", 1);   // 0: always the separate transpose_v launch (A/B)
+            // V^T from the epilogue: only where the v tiles are few (4-wave / mid tiles of the small-M launches)
+            if (!(fused && vt_env && big != 1 && ep.vt_out && ep.vt_ld > 0 && ep.vt_heads > 0 && (N - ep.hn_qk_cols) == ep.vt_heads * 128)) ep.vt_out = nullptr;
+            if (ep.vt_done) *ep.vt_done = ep.vt_out ? 1 : 0;
             if (fused) {
                 launch_mode<4>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);
             } else {  // two kernels; with a table the q / k columns are in head-pair order (PACK_ROWS_HEADPAIR), without in plain order
@@ -1364,6 +1396,8 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
     ep.kparts = 1;
     ep.sk_slab = nullptr;
     ep.sk_ord = 0;
+    ep.vt_out = nullptr;
+    if (ep.vt_done) *ep.vt_done = 0;
     ep.mx_sa = sa; ep.mx_sw = sw; ep.mx_sa_ld = sa_ld; ep.mx_sw_ld = sw_ld;
     if (ep.mode == 4)
         ACE_CHECK(ep.hn_wq && ep.hn_wk && (!ep.hn_cos == !ep.hn_sin) && ep.rows_per_seq > 0 && ep.hn_q_cols % 256 == 0 && ep.hn_qk_cols % 256 == 0 &&

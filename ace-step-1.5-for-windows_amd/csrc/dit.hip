@@ -103,8 +103,9 @@ struct ace355_dit {
     // shift's projection (shift W^T, precomputed for every step of the schedule at the start of the call) to its accumulators.
     struct NormFold {
         int enabled = 1;                 // ACE355_NORM_FOLD (default on)
-        int min_rows = 1536;             // ACE355_NORM_FOLD_MIN_ROWS: token rows below which the norms stay kernels (measured: at
-                                         // M = 750 folding costs 1.2 %: 5 us norm launches are cheaper than the producers' extra work)
+        int min_rows = 64;               // ACE355_NORM_FOLD_MIN_ROWS: token rows below which the norms stay kernels.  Round 2 kept the small-M
+                                         // launches unfolded (1536: at M = 750 folding cost 1.2 % then); with round 3's epilogues it wins
+                                         // there too (batch-1 request 149.1 -> 147.9 ms, configs[0] 49.1 -> 48.7 ms in ABAB runs)
         bool on = false;                 // the current sampler call runs folded
         bool emb_on = false;             // the current sampler call reads its per-step timestep embeddings / norm vectors from the tables
         bool bias_ok = false;            // bias tables match `key`

@@ -97,8 +97,9 @@ def test_tiny_sampler_vs_reference_golden(gpu_device, golden_dir, name):
 
 
 def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
-    """The folded-RMSNorm path on the small-M launches (set_norm_fold(2): 4-wave tiles, ordered split-K where only the last K part emits
-    the next norm's operand) against the reference's 27-step golden and against the default path of the same call."""
+    """The folded-RMSNorm path on the small-M launches (4-wave tiles, ordered split-K where only the last K part emits the next norm's
+    operand; the default since round 3, forced here with set_norm_fold(2)) against the reference's 27-step golden and against the same
+    call with the norms as kernels (set_norm_fold(0))."""
     from ace355 import weightgen
     from ace355.dit import generate_latents
     G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
@@ -112,12 +113,13 @@ def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
     kw = dict(seed=G[f"{name}_seeds"].tolist(), infer_steps=int(G[f"{name}_steps"]), diffusion_guidance_sale=float(G[f"{name}_guidance"]),
               cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=G[f"{name}_timesteps"].tolist() or None)
     ref = torch.from_numpy(G[f"{name}_out"])
+    dit.set_norm_fold(0)
     plain = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
     dit.set_norm_fold(2)
     folded = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
     again = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
     r_f, r_p, r_x = _rel(folded, ref), _rel(plain, ref), _rel(folded, plain)
-    print(f"tiny sampler, norm fold forced: folded vs reference {r_f:.3e}, default vs reference {r_p:.3e}, folded vs default {r_x:.3e}")
+    print(f"tiny sampler, norm fold forced: folded vs reference {r_f:.3e}, norms as kernels vs reference {r_p:.3e}, folded vs kernels {r_x:.3e}")
     assert r_f < 5e-3 and r_p < 5e-3, (r_f, r_p)
     assert torch.equal(folded, again) and not torch.equal(folded, plain)
 
@@ -369,7 +371,9 @@ def test_schedule_tables_equal_per_step_embeddings(gpu_device, golden_dir, tmp_p
     outs = {}
     for flag in ("1", "0"):
         out = str(tmp_path / f"lat{flag}.npy")
-        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ACE355_SCHED_TABLES=flag), timeout=600)
+        # (the folded norms need the tables, so ACE355_SCHED_TABLES=0 also switches the fold off: norms as kernels in BOTH runs, so that
+        #  the comparison isolates the tables)
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ACE355_SCHED_TABLES=flag, ACE355_NORM_FOLD="0"), timeout=600)
         outs[flag] = torch.from_numpy(np.load(out))
     ref = torch.from_numpy(np.load(f"{golden_dir}/g3_tiny_sampler.npz")["cfg7_shift1_out"])
     print(f"schedule tables on / off vs reference: {_rel(outs['1'], ref):.3e} / {_rel(outs['0'], ref):.3e}; on vs off max abs {float((outs['1'] - outs['0']).abs().max()):.1e}")

@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of the attention kernels at the probe's four shapes (8 launches each, in order): ACE355_ATTN_PIPE=0 | 1 under the kernel tracer.
+cd /tmp && export TMPDIR=/tmp
+for st in 0 1; do echo "== ACE355_ATTN_PIPE=$st"; rm -rf /tmp/at$st; ACE355_ATTN_PIPE=$st rocprofv3 --kernel-trace --output-format csv -d /tmp/at$st -- python $GRAFT_REPO_ROOT/tools/attn_probe.py 2>&1 | grep "rel L2"; python - /tmp/at$st <<PY
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted((r for r in csv.DictReader(open(f)) if "attn" in r["Kernel_Name"] and "merge" not in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+for g in range(0, len(rows), 8):
+    grp = rows[g:g + 8]
+    d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in grp[2:])
+    name = grp[0]["Kernel_Name"].split("(")[0].split("::")[-1].replace("void ", "")
+    print(f"  shape {g // 8}: {name} grid {int(grp[0]['Grid_Size_X']) // int(grp[0]['Workgroup_Size_X'])} x {grp[0]['Workgroup_Size_X']}: median {d[len(d) // 2]:.1f} us")
+PY
+done

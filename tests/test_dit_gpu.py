@@ -417,6 +417,40 @@ def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_pat
     assert r1 < 8e-3 and r0 < 8e-3 and rx < 2.5e-3, (r1, r0, rx)  # measured 3.1e-3, 3.1e-3, 7.8e-4
 
 
+def test_vt_from_the_qkv_epilogue_equals_the_transpose_kernel(gpu_device, golden_dir, tmp_path):
+    """Small-M QKV GEMMs write V^T straight from their accumulators (GemmEpilogue::vt_out; ACE355_GEMM_VT=0 keeps the transpose_v launch).
+    The values are the same bf16 roundings of the same accumulators either way: the reference golden forward in one fresh process per
+    setting must agree BIT for bit (odd S = 33 keys per sequence in case "a": pad positions and sequence boundaries inside a tile)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import ace355\n"
+        "from ace355 import weightgen\n"
+        "from ace355.dit import NativeDit\n"
+        "G = np.load(%r)\n"
+        "outs = []\n"
+        "for case in ('a', 'b'):\n"
+        "    cfg = ace355.DitConfig(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,\n"
+        "                           head_dim=128, sliding_window=int(G[case + '_window']))\n"
+        "    dit = NativeDit(cfg, 'cuda:0')\n"
+        "    dit.load_state_dict(weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=int(G['seed']), mode='test'))\n"
+        "    x, ctx, enc, t = (torch.from_numpy(G[case + '_' + k]) for k in ('x', 'ctx', 'enc', 't'))\n"
+        "    for n in range(x.shape[0]): dit.set_condition(n, enc[n])\n"
+        "    for rep in range(2):\n"
+        "        outs.append(dit.forward(x, ctx, t.tolist(), t.tolist(), list(range(x.shape[0]))).float().cpu().reshape(-1))\n"
+        "np.save(sys.argv[1], torch.cat(outs).numpy())\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f"{golden_dir}/g2_tiny_forward.npz")
+    outs = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"vt{flag}.npy")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ACE355_GEMM_VT=flag), timeout=600)
+        outs[flag] = torch.from_numpy(np.load(out))
+    assert torch.isfinite(outs["1"]).all() and torch.equal(outs["1"], outs["0"])
+
+
 def test_torch_library_ops_match_direct_calls(gpu_device):
     """torch.ops.ace355.dit_sample / vae_decode / peak_normalize are the same native calls in dispatcher-visible form."""
     import ace355

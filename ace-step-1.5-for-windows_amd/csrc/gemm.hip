@@ -307,6 +307,41 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         float nf_rs[NT];  // this lane group's row sums of h_new^2 over the wave's columns
 #pragma unroll
         for (int t = 0; t < NT; ++t) nf_rs[t] = 0.f;
+        // Small tile (128x128, the launches of one- and two-song requests): EVERY load of both column halves is requested before
+        // anything is stored.  vmcnt retires in order and counts stores, so a half whose loads sit behind the other half's stores
+        // waits for those stores to be acknowledged and then for its own round trip: two serial memory latencies per epilogue, and
+        // under the ordered split-K the next part waits for all of it (M = 750: 22 k cycles for the pair of parts; ACE355_GEMM_CLK).
+        // The 192x256 tile keeps one half in flight (48 more registers there cost more than the round trip, see below).
+        constexpr bool PRE = (MODE == 2 && MT == 2 && NTW == 2);
+        constexpr int NPJ = PRE ? NTW : 1;
+        float4 hvp[NPJ][NT], g1p[NPJ], a2p[NPJ], b2p[NPJ], cvp[NPJ], ngAp[NPJ], ngBp[NPJ];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = nw0 + j * 32 + slot * 4;
+                const float* hp = reinterpret_cast<const float*>(Cv) + n;
+                if (ep.ksplit <= 1 || ep.sk_ord) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int m = mw0 + t * 8 + rsub;
+                        hvp[j][t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = nw0 + j * 32 + slot * 4;
+                cvp[j] = {0.f, 0.f, 0.f, 0.f};
+                if (ep.cvec && (ep.ksplit <= 1 || blockIdx.y == 0)) cvp[j] = ldf4(ep.cvec + n);
+                if (ep.g1) {
+                    const int seqA = mw0 / rps, last = (M - 1) / rps;
+                    g1p[j] = ldf4(ep.g1 + n);
+                    a2p[j] = ldf4(ep.g2 + (long)min(seqA, last) * ep.g2_stride + n);
+                    b2p[j] = ldf4(ep.g2 + (long)min(seqA + 1, last) * ep.g2_stride + n);
+                }
+                if (nf_on) { ngAp[j] = ldf4(ep.nf_gA + n); ngBp[j] = ldf4(ep.nf_gB + n); }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
 #pragma unroll
@@ -338,6 +373,17 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 // them: one memory round trip per half instead of three (each gate sum used to wait for its own loads
                 // before the H loads were even issued)
                 float4 hv[NT];
+                if constexpr (PRE) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) hv[t] = hvp[j][t];
+                    cv = cvp[j];
+                    if (ep.g1) {
+                        g1 = g1p[j];
+                        remA = mw0 - (mw0 / rps) * rps;
+                        gA = {g1.x + a2p[j].x, g1.y + a2p[j].y, g1.z + a2p[j].z, g1.w + a2p[j].w};
+                        gB = {g1.x + b2p[j].x, g1.y + b2p[j].y, g1.z + b2p[j].z, g1.w + b2p[j].w};
+                    }
+                } else {
                 if (ep.ksplit <= 1 || ep.sk_ord) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -354,6 +400,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     const float4 b2 = ldf4(ep.g2 + (long)min(seqA + 1, last) * ep.g2_stride + n);
                     gA = {g1.x + a2.x, g1.y + a2.y, g1.z + a2.z, g1.w + a2.w};
                     gB = {g1.x + b2.x, g1.y + b2.y, g1.z + b2.z, g1.w + b2.w};
+                }
                 }
                 if (ep.ksplit > 1 && !ep.sk_ord) {
                     // (Requesting the old H values of both column halves before the barrier / staging - one memory round
@@ -391,7 +438,11 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 // load still left an `s_waitcnt vmcnt(0)` at the join, and vmcnt counts stores too - every 16-byte store of the
                 // residual update waited for the previous one's acknowledgement (25-28 k cycles per tile).
                 float4 ngA = {0.f, 0.f, 0.f, 0.f}, ngB = ngA;
-                if (nf_on) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
+                if constexpr (PRE) {
+                    if (nf_on) { ngA = ngAp[j]; ngB = ngBp[j]; }
+                } else {
+                    if (nf_on) { ngA = ldf4(ep.nf_gA + n); ngB = ldf4(ep.nf_gB + n); }
+                }
                 // the next norm's operand leaves with the row: xg = bf16(h_new * g) (8 lanes x 8 bytes = a 64-byte half line per row),
                 // the sum of h_new^2 over these 32 columns = the 8 lanes of the row adds up in nf_rs.  (Keeping the packed values until
                 // both column halves are done and writing whole 128-byte rows through the staging image costs 48 registers: the 192x256

@@ -6,7 +6,7 @@ import ace355
 from ace355 import native
 lib = native.lib(); dev = torch.device("cuda:0"); P = native.ptr
 s = torch.cuda.current_stream().cuda_stream
-M = 6000
+M = int(os.environ.get("GEMM_CLK_M", "6000"))
 for name, N, K, mode in [("qkv store", 4096, 2048, "store"), ("o_proj resid", 2048, 2048, "resid"), ("gate_up swiglu", 12288, 2048, "swiglu"), ("down resid", 2048, 6144, "resid")]:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16); W = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     print(name, file=sys.stderr, flush=True)

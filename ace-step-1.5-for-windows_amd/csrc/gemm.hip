@@ -63,6 +63,8 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
                                                    int wave = 0, int wnw = 1) {
     const int frow = lane & 31, fhalf = lane >> 5;
+    const bool eprobe = ep.clk_probe && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0;   // ACE355_GEMM_CLK: phases of this epilogue
+    const unsigned long long ep0 = eprobe ? clock64() : 0ull;
     if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
         // Folded RMSNorm, consumer side: the A operand was h * g (bf16); the row's rstd and the shift's projection complete
         // rmsnorm(h) * g + shift on the fp32 accumulators: t = acc * rs_in[row] + nc_bias[col], applied WHERE a value is consumed (the
@@ -151,6 +153,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     for (int k = 0; k < HW; ++k) tot += xw[((wave & ~(HW - 1)) + k) * (MT * 32) + i * 32 + frow];
                     rstd[i] = rsqrtf(tot * (1.f / 128.f) + ep.hn_eps);
                 }
+                if (eprobe) g_clk_probe[9] = clock64() - ep0;    // row scales + head sums of squares exchanged
             }
         }
         // lane's columns c = (nw0 & 127) + j*32 + 8g + 4*fhalf .. c+3 in pair order = dims (t, t+64), (t+1, t+65), t = c / 2.
@@ -225,36 +228,47 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                     *reinterpret_cast<uint2*>(stg + stage_off<RB>(i * 32 + frow, j * 4 + g) + 8 * fhalf) = pk;
                 }
             }
+        if (eprobe) g_clk_probe[10] = clock64() - ep0;   // ... + staged
         constexpr int LPR = RB / 16, RPI = 64 / LPR;  // lanes per staged row, rows per store instruction
         const int rsub = lane / LPR, slot = lane % LPR;
         bf16_t* out = reinterpret_cast<bf16_t*>(Cv) + (MODE == 3 ? (nw0 >> 1) : nw0) + slot * 8;
         constexpr int NTI = MT * 32 / RPI;  // read-back iterations
         if (MODE == 4 && hn && rope) {
-            // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path);
-            // table rows requested four iterations at a time, ahead of the arithmetic
+            // ... rotation here: this lane's 8 columns are the pairs t..t+3 of row m (same two roundings as the unfused path).
+            // Table rows come in batches of NB iterations, and batch b+1 is requested BEFORE batch b's stores (vmcnt retires in order
+            // and counts stores: table loads issued behind a batch of stores wait for those stores' acknowledgements first).  All 12
+            // iterations' rows at once = 96 registers: the persistent kernel spills.  Measured neutral at M = 6000 (ABAB 515.0 vs 514.9
+            // ms per pass): with two waves per SIMD this epilogue is VALU bound - in-pass phase probe (ACE355_GEMM_CLK), cycles from
+            // its start: sums of squares exchanged 4.4 k, normalised + staged 10 k, rotated + stored 16 k (plain store epilogue: 4.8 k).
             constexpr int NB = NTI % 4 == 0 ? 4 : (NTI % 3 == 0 ? 3 : 1);
+            constexpr int NBAT = NTI / NB;
             const int pc = ((nw0 & 127) >> 1) + slot * 4;
-#pragma unroll
-            for (int t0 = 0; t0 < NTI; t0 += NB) {
-                f32x4 cs[NB], sn[NB];
-                u32x4e v[NB];
+            f32x4 cs[2][NB], sn[2][NB];
+            auto table_rows = [&](int b, f32x4 (&c)[NB], f32x4 (&sv)[NB]) {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int row = (t0 + u) * RPI + rsub;
+                    const int row = (b * NB + u) * RPI + rsub;
                     const long po = (long)((mw0 + row) % ep.rows_per_seq) * 64 + pc;
-                    cs[u] = *reinterpret_cast<const f32x4*>(ep.hn_cos + po);
-                    sn[u] = *reinterpret_cast<const f32x4*>(ep.hn_sin + po);
-                    v[u] = *reinterpret_cast<const u32x4e*>(stg + stage_off<RB>(row, slot));
+                    c[u] = *reinterpret_cast<const f32x4*>(ep.hn_cos + po);
+                    sv[u] = *reinterpret_cast<const f32x4*>(ep.hn_sin + po);
                 }
+            };
+            table_rows(0, cs[0], sn[0]);
+#pragma unroll
+            for (int b = 0; b < NBAT; ++b) {
+                if (b + 1 < NBAT) table_rows(b + 1, cs[(b + 1) & 1], sn[(b + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // (keeps the next batch's requests ahead of this batch's stores)
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int m = mw0 + (t0 + u) * RPI + rsub;
+                    const int row = (b * NB + u) * RPI + rsub;
+                    const int m = mw0 + row;
+                    u32x4e v = *reinterpret_cast<const u32x4e*>(stg + stage_off<RB>(row, slot));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float a = bf_lo(v[u][e]), b = bf_hi(v[u][e]);
-                        v[u][e] = pack_bf2(a * cs[u][e] - b * sn[u][e], b * cs[u][e] + a * sn[u][e]);
+                        const float a = bf_lo(v[e]), bb2 = bf_hi(v[e]);
+                        v[e] = pack_bf2(a * cs[b & 1][u][e] - bb2 * sn[b & 1][u][e], bb2 * cs[b & 1][u][e] + a * sn[b & 1][u][e]);
                     }
-                    if (ROWS_FULL || m < M) *reinterpret_cast<u32x4e*>(out + (long)m * ldc) = v[u];
+                    if (ROWS_FULL || m < M) *reinterpret_cast<u32x4e*>(out + (long)m * ldc) = v;
                 }
             }
         } else if (MODE == 3 && ep.mxo_scales) {
@@ -1386,6 +1400,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
                           "epilogue issue %.0f / acked %.0f cycles (last tile of workgroup 0)%s\n", M, N, K, ep.mode, ep.kparts, nwg,
                           (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2], h[2],
                           (double)h[5], (double)h[3], (double)h[4], "");
+        if (h[1] && (ep.mode == 4 || ep.mode == 0 || ep.mode == 3) && h[10]) fprintf(stderr, "[ace355 gemm clk]   epilogue phases (wave 0): sums exchanged %llu, staged %llu cycles\n", h[9], h[10]);
         if (h[1] && ep.sk_slab) fprintf(stderr, "[ace355 gemm clk]   slab: part 0 park + signal %llu cycles; last part: wait %llu, wait + reduce %llu cycles (then the epilogue)\n",
                                         h[8], h[6], h[7]);
     }

@@ -6,6 +6,8 @@ N = 16 and attn3_kernel<8> at S = 1500.  Inputs are regenerated from seeds (CPU 
 
 Gates are 2-3x the values measured on MI355X (printed by every test; DESIGN.md section 3 lists them).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -228,7 +230,9 @@ def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, fu
           f"vs the N=2 run {rx:.3e}")
     assert torch.isfinite(v16).all()
     assert r2 < 1.5e-2 and r16 < 1.5e-2 and r23 < 1.2e-2, (r2, r16, r23)  # measured 5.9e-3, 5.9e-3, 4.2e-3
-    assert rx < 2e-3, rx  # measured 0.0: the same arithmetic per wave whatever the block / tile shape
+    # measured 0.0: the same arithmetic per wave whatever the block / tile shape.  (The opt-in slab split-K sums a tile's K parts in
+    #  another order at M = 3000 only: 3.0e-3 between the two runs, both still at the reference's distance.)
+    assert rx < (5e-3 if os.environ.get("ACE355_GEMM_SLAB", "0") not in ("", "0") else 2e-3), rx
     assert _rel(v16[2], v16[3]) > 0.3  # other seeds really are other songs
 
 

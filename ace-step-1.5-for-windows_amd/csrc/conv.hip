@@ -13,7 +13,8 @@
 // gfx950 design: workgroup tile = 128 positions x BN outputs, K loop over 64-channel chunks; per chunk the input
 // window (128 + (taps-1)*dil rows) is loaded ONCE, Snake applied in registers (fp32), and parked in LDS (swizzled);
 // every tap then reads its shifted rows from LDS, so Snake costs (1 + halo) instead of `taps` evaluations and x is
-// read from HBM/L2 once per chunk.  Weight tiles stream through a 2-stage LDS ring, one barrier per tap.
+// read from HBM/L2 once per chunk.  Weight tiles stream L2 -> LDS by DMA (global_load_lds) through a 2-stage ring, one barrier per tap
+// (until round 3 they were staged global -> registers -> ds_write: 16 VGPRs and 4 LDS writes per thread per tap).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -37,6 +38,17 @@ __device__ __forceinline__ u32x4 ld_u32x4(const void* p) {
 }
 
 constexpr int HALO_MAX = 64;  // (taps-1)*dil <= 6*9 = 54 rows of halo at most
+
+// Weight tiles go L2 -> LDS by DMA (global_load_lds, issued from asm like the GEMM's: hipcc would drain a builtin DMA before the
+// next ds_read): address = uniform 64-bit base (SGPR pair: the tap / channel-chunk offset) + a loop-invariant per-lane byte offset.
+// A piece is 8 rows x 128 B, lane-linear in LDS; the XOR swizzle of lds_off is applied to the SOURCE chunk a lane fetches.
+__device__ __forceinline__ void conv_glds16(unsigned voff, const void* sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
 
 // TM = positions per workgroup, one wave per 64 x 64 (BN = 128) sub-tile: 128 -> 4 waves, 256 -> 8 waves.  The 8-wave
 // form shares each weight tile between twice as many MFMAs, shrinks the Snake halo from 1.42x to 1.21x of the tile and puts
@@ -73,16 +85,29 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sslot = tid & 7;
-    // weight staging addresses: chunk c = tid + i*NTHR -> row = c>>3 (i-th: + NTHR/8*i), slot = tid&7
-    const bf16_t* wsrc[WCH];
-    int wst[WCH];
+    // weight tile = BN rows x 128 B = BN / 8 DMA pieces; wave w issues pieces w, w + NW, ...: row = 8 piece + (lane >> 3), and the lane
+    // fetches the logical 16-byte slot that lds_off puts at ITS physical position (slot' = lane & 7)
+    constexpr int NWV = NTHR / 64;
+    static_assert(WCH * NWV * 8 == BN, "pieces split evenly over the waves");
+    unsigned w_voff[WCH];
+    int wst[WCH];   // (register-staged form of the same tile: the fused k = 1 stage's w2 chunks)
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
-        const int row = (tid >> 3) + (NTHR / 8) * i;
-        wsrc[i] = a.w + (long)min(n0 + row, a.N - 1) * wrow + sslot * 8;
-        wst[i] = lds_off(row, sslot);
+        const int prow = 8 * (wave + NWV * i) + (lane >> 3);
+        const int ls = (lane & 7) ^ ((prow >> 1) & 7);
+        w_voff[i] = (unsigned)(((long)min(n0 + prow, a.N - 1) * wrow + ls * 8) * 2);
+        wst[i] = lds_off((tid >> 3) + (NTHR / 8) * i, sslot);
     }
-    u32x4 rw[WCH];
+    const unsigned wlds0 = (unsigned)(uintptr_t)Wbase + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    auto w_piece = [&](int i, int tap, int ci0, int buf) {   // piece i of tile (tap, chunk) -> weight buffer `buf`
+        const bf16_t* sb = a.w + (long)tap * Cin + ci0;   // uniform
+        const unsigned lb = (unsigned)__builtin_amdgcn_readfirstlane((int)(wlds0 + (unsigned)buf * (BN * 128)));
+        conv_glds16(w_voff[i], sb, lb + (unsigned)i * (NWV * 1024));
+    };
+    auto w_issue = [&](int tap, int ci0, int buf) {
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) w_piece(i, tap, ci0, buf);
+    };
 
     // Input window of one 64-channel chunk: all of a thread's (up to 6) 16-byte loads are issued back to back into
     // registers - and, for the next chunk, before the tap loop of the current one - so a workgroup pays one memory latency
@@ -141,20 +166,19 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         __syncthreads();  // previous chunk fully consumed
         win_store(ci0);   // Snake in fp32 registers, parked in LDS once per chunk
         if (PREFETCH && ci0 + 64 < Cin) win_load(ci0 + 64);
-        // ---- weight tile for tap 0 of this chunk
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) rw[i] = ld_u32x4(wsrc[i] + ci0);
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(Wbase + wst[i]) = rw[i];
+        // ---- weight tile for tap 0 of this chunk (buffer 0: its last reader, the previous chunk's last tap, is behind the barrier above)
+        w_issue(0, ci0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the DMA is invisible to hipcc's own waits)
         __syncthreads();
         if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
 
         for (int tap = 0; tap < taps; ++tap) {
             const bool more = (tap + 1) < taps;
-            if (more) {
-#pragma unroll
-                for (int i = 0; i < WCH; ++i) rw[i] = ld_u32x4(wsrc[i] + (long)(tap + 1) * Cin + ci0);
-            }
+            // the next tap's tile lands under this tap's MFMAs (every wave left that buffer at the last barrier).  All pieces up front:
+            // one piece behind each kk group of MFMAs (ILV, the GEMM's placement) measured 43.6 vs 42.8 ms per 8-song decode here - with
+            // two workgroups per CU the other workgroup's MFMAs already cover the issue cost, and the late pieces land later.
+            constexpr bool ILV = false;
+            if (!ILV && more) w_issue(tap + 1, ci0, (tap + 1) & 1);
             const char* Ws = Wbase + (tap & 1) * (BN * 128);
             const int arow = wm * (MT * 32) + tap * dil + lq;
 #pragma unroll
@@ -170,11 +194,10 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);  // swapped: lane = one output row, 4 consecutive channels per register quad
+                if (ILV && more && kk < WCH) w_piece(kk, tap + 1, ci0, (tap + 1) & 1);
             }
             if (more) {
-                char* Wd = Wbase + ((tap + 1) & 1) * (BN * 128);
-#pragma unroll
-                for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(Wd + wst[i]) = rw[i];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
         }

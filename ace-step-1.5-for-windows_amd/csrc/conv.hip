@@ -411,6 +411,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     ACE_CHECK(a.Cin % 64 == 0, "conv: Cin must be a multiple of 64");
     ACE_CHECK(a.taps >= 1 && (a.taps - 1) * a.dil <= HALO_MAX && a.dil >= 1, "conv: window too large");
     ACE_CHECK(a.B > 0 && a.M > 0 && a.N > 0, "conv: empty problem");
+    ACE_CHECK((long)a.N * a.taps * a.Cin * 2 < (1L << 32) && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
+              "conv: the weight tensor must be 16-byte aligned and smaller than 4 GB (32-bit DMA offsets)");
     ACE_CHECK(a.x_valid ? (a.x_shift % 8 == 0 && a.x_valid % 8 == 0) : a.x_shift == 0, "conv: x_shift / x_valid must be multiples of 8 (and x_shift needs x_valid)");
     ACE_CHECK(!a.w2 || (a.Cin == 128 && a.N == 128 && !a.x_valid && a.out_mode == 0 && a.alpha2 && a.beta2 &&
                         (reinterpret_cast<uintptr_t>(a.alpha2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.beta2) & 15) == 0 &&

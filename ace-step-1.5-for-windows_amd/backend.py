@@ -342,7 +342,9 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         initialised handler): rank 0 passes the request of G songs (one seed per song), the other ranks pass ``None`` tensors;
         the request is broadcast once, each rank generates its contiguous slice (``ace355.dist.run_request``: 8/4/2/1 songs
         per rank for a batch of 8 on 1/2/4/8 GPUs) and rank 0 returns the payload with all G songs in order (the other ranks
-        return theirs).  The per-call cap of 8 (handler/service_generate_request.py:12) then holds per rank."""
+        return theirs).  Every per-request setting (steps, guidance, shift, CFG interval, ADG, ode / sde, explicit timesteps, tiled
+        decode, latent shift / rescale) is rank 0's and travels with the request; ``extra_outputs`` (pred_latents, src_latents, ...)
+        describe the RETURNING rank's slice ``extra_outputs["song_range"]``, ``audios`` on rank 0 all G songs.  The per-call cap of 8 (handler/service_generate_request.py:12) then holds per rank."""
         if data_parallel:
             import torch.distributed as dist
             if dist.is_initialized() and dist.get_world_size() > 1:
@@ -430,22 +432,32 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
                                      "independent of the rank it runs on; a scalar seed couples the batch, base.py:1733-1770)")
                 if G > MAX_BATCH_SIZE * world:
                     raise ValueError(f"batch size {G} exceeds the per-call cap of {MAX_BATCH_SIZE} on {world} ranks")
-                request = a_dist.pack_request(encoder_hidden_states, context_latents, [int(s) for s in seed], None, **knobs)
+                shipped = ("timesteps", "use_tiled_decode", "latent_shift", "latent_rescale")
+                extra = {kk: v for kk, v in local_kwargs.items() if kk not in shipped and v is not None}
+                if extra:
+                    # cover strength / non-cover conditions / source latents are per-call tensors of rank 0 only: the other ranks would
+                    # run their songs without them (advisor r3) - refused on every rank rather than silently diverging
+                    raise ValueError(f"data_parallel: these arguments are not part of the broadcast request: {sorted(extra)}")
+                request = a_dist.pack_request(encoder_hidden_states, context_latents, [int(s) for s in seed], None,
+                                              timesteps=local_kwargs.get("timesteps"), use_tiled_decode=float(bool(local_kwargs.get("use_tiled_decode", True))),
+                                              latent_shift=float(local_kwargs.get("latent_shift", 0.0)),
+                                              latent_rescale=float(local_kwargs.get("latent_rescale", 1.0)), **knobs)
         except Exception as exc:
             err = exc
         # (rank 0 could not even build the request: the others learn it from an empty one)
         if rank == 0 and request is None:
             request = {"enc_rows": torch.zeros(0, 1, 1), "enc_index": torch.zeros(0, dtype=torch.int32), "ctx": torch.zeros(1, 1, 2),
-                       "seeds": torch.zeros(0, dtype=torch.int64), "knobs": torch.zeros(len(a_dist.KNOBS), dtype=torch.float64)}
+                       "seeds": torch.zeros(0, dtype=torch.int64), "knobs": torch.zeros(len(a_dist.KNOBS), dtype=torch.float64),
+                       "timesteps": torch.zeros(0)}
 
         def execute(local):
             k = local["knobs"]
+            # every setting comes from the BROADCAST request (rank 0's call), none from this rank's own arguments
             payload, wavs = self._generate_music_local(
                 local["encoder_hidden_states"], local["context_latents"], local["seeds"], int(k["inference_steps"]), k["guidance_scale"],
-                k["shift"], "sde" if k["infer_method_sde"] else "ode", local_kwargs.get("timesteps"), local_kwargs.get("use_tiled_decode", True),
-                local_kwargs.get("latent_shift", 0.0), local_kwargs.get("latent_rescale", 1.0), k["cfg_interval_start"], k["cfg_interval_end"],
-                bool(k["use_adg"]), progress if rank == 0 else None,
-                {kk: v for kk, v in local_kwargs.items() if kk not in ("timesteps", "use_tiled_decode", "latent_shift", "latent_rescale")})
+                k["shift"], "sde" if k["infer_method_sde"] else "ode", local["timesteps"], bool(k["use_tiled_decode"]),
+                k["latent_shift"], k["latent_rescale"], k["cfg_interval_start"], k["cfg_interval_end"],
+                bool(k["use_adg"]), progress if rank == 0 else None, {})
             state["payload"] = payload
             return wavs
 

@@ -116,7 +116,7 @@ static int hook_counters(GemmEpilogue& ep) {
     if (!cnt) {
         ACE_HIP(hipMalloc((void**)&cnt, SK_CNT_INTS * sizeof(int)));
         ACE_HIP(hipMemset(cnt, 0, SK_CNT_INTS * sizeof(int)));
-        ACE_HIP(hipMalloc((void**)&slab, SK_SLAB_FLOATS * sizeof(float)));
+        if (gemm_slab_wanted()) ACE_HIP(hipMalloc((void**)&slab, SK_SLAB_FLOATS * sizeof(float)));
         if (int rc = gemm_verify_splitk_placement()) return rc;
     }
     ep.sk_cnt = cnt;

@@ -151,6 +151,11 @@ struct GemmEpilogue {
     unsigned long long* nf_sqA; unsigned long long* nf_sqB;   // 2^-24 fixed point: integer adds commute, so the sums (and with them
     const unsigned long long* nc_rowsq; const float* nc_bias;  // every result) do not depend on the order the atomics arrive in
     float nc_inv_d, nc_eps;
+    // host-side launch hints (launch_gemm; the kernels ignore them).  tile_hint 1: the 8-wave 192x256 tile whatever the tile count
+    // (two concurrent half-batch launches of the CFG fork fill the chip together, dit.hip forward_core); no_pers 1: one workgroup per
+    // tile even for multi-round launches (a persistent grid keeps every CU it was given until its last tile: nothing for a kernel of
+    // another stream to slip into)
+    int tile_hint; int no_pers;
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
@@ -174,6 +179,7 @@ constexpr int SK_CNT_INTS = SK_MAX_TILES + 8;   // size of a turn-counter array:
 // goes ahead so the device cannot hang, but counts the event in sk_cnt[SK_MAX_TILES]: gemm_splitk_poll reads it (stream sync), and on a
 // non-zero count re-zeroes the counters and reports an error - the residual stream of that call is not trustworthy.
 int gemm_splitk_poll(int* sk_cnt, hipStream_t s);
+bool gemm_slab_wanted();   // ACE355_GEMM_SLAB != 0: the handles allocate the 32 MB slab only then (the path is off by default; advisor r3)
 
 struct AttnArgs {
     const bf16_t* q; long q_seq_stride; int q_row_stride;           // q[n][s][h*128 + d]

@@ -169,7 +169,7 @@ int ensure_rope(EncBase* h, int S, hipStream_t s) {
     h->rope_S = cap;
     if (!h->sk_cnt) {
         ALLOC(h->allocs, h->sk_cnt, SK_CNT_INTS);
-        ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
+        if (gemm_slab_wanted()) ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
         ACE_HIP(hipMemsetAsync(h->sk_cnt, 0, SK_CNT_INTS * sizeof(int), s));
         if (int prc = gemm_verify_splitk_placement()) return prc;
     }

@@ -122,6 +122,23 @@ struct ace355_dit {
         hipStream_t key_stream = nullptr; // ... and the stream that built them (another stream is not ordered behind it)
     } nf;
 
+    // CFG fork (round 4): inside a layer the conditional rows' cross-attention chain (cross-q GEMM -> attention ->
+    // cross-o GEMM: one-tile-deep launches on the conditional half only) and the MLP of the rows that skip cross-attention (the CFG null
+    // branch, whose cross term is a constant) are independent until the next layer's QKV projection: the null rows' gate|up / down GEMMs
+    // go to a side stream between two events.  Sequences are independent through a layer (base.py:515-539), the CFG doubling is only a
+    // cat (base.py:1905-1911).  Results are bit-identical to the single-stream order (every output element is the same accumulation
+    // whatever launch it lands in; the row sums are integer atomics).
+    struct CfgFork {
+        int mode = 1;                 // ACE355_CFG_FORK / ace355_dit_set_cfg_fork: 0 off, 1 default (big bf16 sampler launches), 2 every eligible call (tests)
+        int min_rows = 1536;          // both halves must take the big tiles (no split-K counters shared between the streams)
+        int down_big = 1;             // ACE355_FORK_DOWN_BIG: the two half-batch down projections on the 192x256 tile (128 workgroups each)
+        int no_pers = 0;              // ACE355_FORK_NOPERS: side-stream gate|up without persistent workgroups
+        hipStream_t side = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        int* sk_cnt = nullptr;        // the side stream's own split-K turn counters (two concurrent launches must not share tile counters)
+        long forks = 0;               // layers that took the fork so far (tests)
+    } fk;
+
     int* sk_cnt = nullptr;   // split-K counters lent to launch_gemm (GemmEpilogue::sk_cnt)
     float* sk_slab = nullptr;   // slab split-K scratch lent to launch_gemm (GemmEpilogue::sk_slab, SK_SLAB_FLOATS)
     float* attn_part = nullptr;   // split-KV scratch lent to launch_attention (AttnArgs::part): small problems only
@@ -247,8 +264,9 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
         h->gemm_launches++;
     }
     GemmEpilogue e2 = ep;
-    e2.sk_cnt = h->sk_cnt;
-    e2.sk_slab = h->sk_slab; e2.sk_slab_cap = SK_SLAB_FLOATS;
+    const bool side = h->fk.side && s == h->fk.side;
+    e2.sk_cnt = side ? h->fk.sk_cnt : h->sk_cnt;
+    e2.sk_slab = side ? nullptr : h->sk_slab; e2.sk_slab_cap = SK_SLAB_FLOATS;
     return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, e2, s);
 }
 
@@ -516,6 +534,35 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     rc = gemm(h, h->xin, 2 * h->cfg.in_channels, h->w_in, 2 * h->cfg.in_channels, h->h, D, M, D, 2 * h->cfg.in_channels, ep, s);
     if (rc) return rc;
 
+    // CFG fork eligibility: a sampler forward (one shared timestep row: per-row gate / norm vectors have stride 0), bf16 kernels,
+    // both halves present and big enough for the big tiles
+    const int fk_min = h->fk.mode >= 2 ? 64 : h->fk.min_rows;
+    const bool fork_ok = h->fk.mode > 0 && h->fk.side && temb_rows == 1 && n_sc > 0 && Nc > 0 && Mc >= fk_min && M - Mc >= fk_min &&
+                         h->precision != ACE355_PRECISION_MXFP8;
+    // SwiGLU MLP (base.py:530-533) of token rows [r0, r0 + nr) on stream st (bf16 kernels): [norm] -> gate|up + SwiGLU -> down + gated residual
+    auto mlp_rows = [&](int li, int r0, int nr, hipStream_t st) -> int {
+        const LayerW& W = h->layers[li];
+        const float* g_mlp = gs_p + (size_t)(li * 2 + 1) * 2 * D;
+        int rc2 = 0;
+        if (!fold) rc2 = launch_rmsnorm_gs(h->h + (size_t)r0 * D, g_mlp, g_mlp + D, h->xn + (size_t)r0 * D, nr, D, eps, 0, S, st);
+        if (rc2) return rc2;
+        GemmEpilogue e3{3, nullptr, nullptr, nullptr, 0, 0};
+        if (fold) {
+            e3.nc_rowsq = rowsq(li, 2) + r0; e3.nc_bias = nf.bias_gu + ((size_t)li * nf.rows + nf.step) * 2 * F;
+            e3.nc_inv_d = inv_d; e3.nc_eps = eps;
+        }
+        if (st != s) e3.no_pers = h->fk.no_pers;
+        rc2 = gemm(h, h->xn + (size_t)r0 * D, D, W.wgu, D, h->act + (size_t)r0 * F, F, nr, 2 * F, D, e3, st);
+        if (rc2) return rc2;
+        GemmEpilogue e2{2, nullptr, W.sst + 5 * D, tproj_p + 5 * D, 0, S};
+        if (fold && li + 1 < h->NL) {  // the next layer's self-attention norm operand
+            e2.nf_xg = h->xn + (size_t)r0 * D; e2.nf_ldx = D; e2.nf_split = 0;
+            e2.nf_gA = e2.nf_gB = gs_p + (size_t)((li + 1) * 2 + 0) * 2 * D; e2.nf_sqA = e2.nf_sqB = rowsq(li + 1, 0) + r0;
+        }
+        e2.tile_hint = h->fk.down_big;
+        return gemm(h, h->act + (size_t)r0 * F, F, W.wdown, F, h->h + (size_t)r0 * D, D, nr, D, F, e2, st);
+    };
+
     RoctxRange r_fwd("ace355.dit_forward");
     for (int li = 0; li < h->NL; ++li) {
         RoctxRange r_layer("ace355.dit_layer");
@@ -591,6 +638,17 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
 
+        // ---- CFG fork: the rows that skip cross-attention go on to their MLP on the side stream while the conditional rows run
+        // the cross-attention chain on this one (joined before the next layer's QKV projection)
+        const bool forked = fork_ok;
+        if (forked) {
+            ACE_HIP(hipEventRecord(h->fk.ev_fork, s));
+            ACE_HIP(hipStreamWaitEvent(h->fk.side, h->fk.ev_fork, 0));
+            rc = mlp_rows(li, Mc, M - Mc, h->fk.side);
+            if (rc) return rc;
+            ACE_HIP(hipEventRecord(h->fk.ev_join, h->fk.side));
+            h->fk.forks++;
+        }
         // ---- cross attention (base.py:515-526): un-modulated norm, plain residual, cached K/V, no RoPE
         if (Nc > 0) {
         static int mx_cross = -1;
@@ -643,6 +701,13 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         }
 
         // ---- SwiGLU MLP (base.py:530-533)
+        if (forked) {   // the null rows' MLP is already queued on the side stream; here the conditional rows', then the join
+            rc = mlp_rows(li, 0, Mc, s);
+            if (rc) return rc;
+            ACE_HIP(hipStreamWaitEvent(s, h->fk.ev_join, 0));
+            if (h->tap_dst[li]) ACE_HIP(hipMemcpyAsync(h->tap_dst[li], h->h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+            continue;
+        }
         const bool mx_gu = mx_usable(h, W.mx_gu, M, 2 * F, D, 3) && D == 2048;
         if (fold) rc = 0;
         else if (mx_gu)
@@ -791,13 +856,29 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->sst_out, 2 * D);
     ALLOC(h->allocs, h->flags_dev, 4);
     ALLOC(h->allocs, h->sk_cnt, SK_CNT_INTS);
-    ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
+    if (gemm_slab_wanted()) ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
+    ALLOC(h->allocs, h->fk.sk_cnt, SK_CNT_INTS);
+    ACE_HIP(hipMemset(h->fk.sk_cnt, 0, SK_CNT_INTS * sizeof(int)));
     h->attn_part_floats = 16L << 20;   // 64 MB: 8 parts of a 2 x 16 x 375-row problem (12.7 M floats); larger problems do not split
     ALLOC(h->allocs, h->attn_part, (size_t)h->attn_part_floats);
     ACE_HIP(hipMemset(h->sk_cnt, 0, SK_CNT_INTS * sizeof(int)));
     if (int prc = gemm_verify_splitk_placement()) return prc;
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
+    if (const char* e = getenv("ACE355_CFG_FORK")) h->fk.mode = atoi(e);
+    if (const char* e = getenv("ACE355_CFG_FORK_MIN_ROWS")) h->fk.min_rows = atoi(e);
+    if (const char* e = getenv("ACE355_FORK_DOWN_BIG")) h->fk.down_big = atoi(e);
+    if (const char* e = getenv("ACE355_FORK_NOPERS")) h->fk.no_pers = atoi(e);
+    {
+        int lo = 0, hi = 0;   // (numerically: hi <= 0 <= lo; the greatest value is the lowest priority)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        int prio = 0;         // ACE355_FORK_PRIO: -1 side stream above the caller's, 0 same, 1 below
+        if (const char* e = getenv("ACE355_FORK_PRIO")) prio = atoi(e);
+        prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
+        ACE_HIP(hipStreamCreateWithPriority(&h->fk.side, hipStreamNonBlocking, prio));
+        ACE_HIP(hipEventCreateWithFlags(&h->fk.ev_fork, hipEventDisableTiming));
+        ACE_HIP(hipEventCreateWithFlags(&h->fk.ev_join, hipEventDisableTiming));
+    }
     if (const char* e = getenv("ACE355_NORM_FOLD")) h->nf.enabled = atoi(e);
     if (const char* e = getenv("ACE355_NORM_FOLD_MIN_ROWS")) h->nf.min_rows = atoi(e);
     *out = h;
@@ -819,6 +900,9 @@ void ace355_dit_destroy(ace355_dit* h) {
     if (h->g_ctx_nc) hipFree(h->g_ctx_nc);
     if (h->g_sde) hipFree(h->g_sde);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->fk.side) hipStreamDestroy(h->fk.side);
+    if (h->fk.ev_fork) hipEventDestroy(h->fk.ev_fork);
+    if (h->fk.ev_join) hipEventDestroy(h->fk.ev_join);
     if (h->graph_stream) hipStreamDestroy(h->graph_stream);
     if (h->graph_in) hipEventDestroy(h->graph_in);
     if (h->graph_out) hipEventDestroy(h->graph_out);
@@ -973,6 +1057,7 @@ int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, 
     if (!h->finalized) { set_error("dit_forward: call ace355_dit_finalize first"); return ACE355_ERR_STATE; }
     ACE_CHECK(N > 0 && N <= ACE355_MAX_SEQS && T > 0, "dit_forward: N in [1,64], T > 0");
     hipStream_t s = (hipStream_t)stream;
+    h->vt_key_N = h->vt_key_S = -1;   // (see ace355_dit_sample)
     int rc = ensure_workspace(h, N, T, s);
     if (rc) return rc;
     const int Tpad = 2 * ((T + 1) / 2);
@@ -999,6 +1084,10 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     ACE_CHECK(N <= ACE355_MAX_SEQS, "dit_sample: at most 64 sequences per call");
     hipStream_t s = (hipStream_t)stream;
     RoctxRange r_sample("ace355.dit_sample");
+    // the pad columns [S, Sp) of V^T are zeroed by the first forward of EVERY call (12.6 MB at the metric shape), also inside a captured
+    // graph: a replay skips forward_core, so a key that survived across calls could describe a buffer another shape had since written
+    // (stale - possibly non-finite - V values under zero attention weights; advisor r3)
+    h->vt_key_N = h->vt_key_S = -1;
     int rc = ensure_workspace(h, N, T, s);
     if (rc) return rc;
     rc = normfold_reserve(h, p->num_steps, N, T, s);
@@ -1183,7 +1272,8 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
 
 int ace355_dit_poll_errors(ace355_dit* h, void* stream) {
     ACE_CHECK(h, "poll_errors: null handle");
-    return gemm_splitk_poll(h->sk_cnt, (hipStream_t)stream);
+    if (int rc = gemm_splitk_poll(h->sk_cnt, (hipStream_t)stream)) return rc;
+    return gemm_splitk_poll(h->fk.sk_cnt, (hipStream_t)stream);   // (the side stream's launches were joined into `stream` before it could be idle)
 }
 
 int ace355_dit_trim_slots(ace355_dit* h, int first_unused) {
@@ -1207,6 +1297,19 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable) {
     ACE_CHECK(h, "set_norm_fold: null handle");
     h->nf.enabled = enable;   // 0 off, 1 default (big-M calls), 2 every call the kernels support (tests)
     h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_set_cfg_fork(ace355_dit* h, int mode) {
+    ACE_CHECK(h && mode >= 0 && mode <= 2, "set_cfg_fork: mode must be 0, 1 or 2");
+    h->fk.mode = mode;
+    h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks) {
+    ACE_CHECK(h && forks, "cfg_fork_count: null argument");
+    *forks = h->fk.forks;
     return ACE355_OK;
 }
 

@@ -1178,6 +1178,11 @@ static int gemm_variant() {
     return v;
 }
 bool gemm_fold_supported() { return gemm_variant() != 1; }
+bool gemm_slab_wanted() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ACE355_GEMM_SLAB"); v = (e && atoi(e) != 0) ? 1 : 0; }
+    return v == 1;
+}
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -1220,7 +1225,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
         if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
-        else if (big && pers && region > 32) {
+        else if (big && pers && !ep.no_pers && region > 32) {
             const dim3 pgrid(8 * 32);
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
@@ -1236,7 +1241,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
             if (mid_ns == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
             else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
         }
-    } else if (big && pers && region > 32 && (MODE != 2 || pers >= 2)) {
+    } else if (big && pers && !ep.no_pers && region > 32 && (MODE != 2 || pers >= 2)) {
         const dim3 pgrid(8 * 32);
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
@@ -1284,7 +1289,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
         // (>= 180 tiles: three quarters of the CUs with one 8-wave workgroup each beat the same work as 384 four-wave workgroups on 512
         //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
-        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 && (N % 256 == 0 || N >= 1024)) || (ep.tile_hint == 1 && bigenv != 0 && N % 256 == 0)) { mt = 3; bn = 256; big = 1; }
         else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 && t192 <= 320))) { mt = 3; bn = 128; big = 2; }
     }
     // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every
@@ -1348,6 +1353,12 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         ep.ksplit = ks;
         ep.kparts = ks;
         ep.sk_ord = (ord && ks > 1) ? 1 : 0;
+    }
+    if ((ep.nf_xg || ep.nc_rowsq) && ep.ksplit > 1 && !ep.sk_ord) {
+        // a folded-norm producer needs the FINISHED h in one part's hands: with the ordered turns that is the last part, with fp32 atomics
+        // in arrival order (ACE355_GEMM_SKORD=0, or no counters lent) nobody - such a launch keeps its K range whole (advisor r3)
+        ep.ksplit = 1;
+        ep.kparts = 1;
     }
     if (ep.nf_xg || ep.nc_rowsq) {  // folded RMSNorm (dit.hip): lives in the wide epilogue only, whole tiles, no split-K
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

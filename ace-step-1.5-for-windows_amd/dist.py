@@ -24,13 +24,24 @@ import torch.distributed as dist
 
 _MAX_ITEMS = 16
 _MAX_DIMS = 4
-# header (int32 words): [magic, n_items | -1, payload bytes, error code, (dtype code, ndim, d0..d3) x items]
-_HEADER = 4 + _MAX_ITEMS * (_MAX_DIMS + 2)
-_MAGIC = 0x0ACE0355
+# header (int32 words): [magic, n_items | -1, payload bytes, error code, (dtype code, ndim, d0..d3) x items, host area]
+# An item whose dtype code is >= _IN_HEADER travels INSIDE the header's host area (its words in item order) instead of in the
+# payload: the small per-request scalars (seeds, caption index, knobs, explicit timesteps) are read on the host by every rank anyway,
+# and the header is the one tensor a receiver reads back - so a request costs ONE device -> host read, not one per scalar tensor
+# (round 3 read three small tensors back with .tolist(): three more stream syncs per request at N > 1).
+_ITEMS_END = 4 + _MAX_ITEMS * (_MAX_DIMS + 2)
+_HOST_WORDS = 1024
+_HEADER = _ITEMS_END + _HOST_WORDS
+_IN_HEADER = 100
+_MAGIC = 0x0ACE0356
 _ALIGN = 16
-DEFAULT_CAPACITY_BYTES = 64 << 20   # upper bound a receiver accepts for one bundle (a 600 s request with L = 2305 is 13 MB in bf16)
+# Sanity bound a receiver accepts for one bundle, not a feature limit: a 600 s request with L = 2305 is 13 MB in bf16, 64 songs x 240 s
+# with per-song contexts (LM hints, cover sources) 98 MB (advisor r3: the round-3 value of 64 MB refused that request on every rank).
+DEFAULT_CAPACITY_BYTES = 1 << 30
 _DTYPES = [torch.float32, torch.bfloat16, torch.int64, torch.int32, torch.float64]
-_ERR_NONE, _ERR_TOO_BIG, _ERR_BAD_ITEM = 0, 1, 2
+_ERR_NONE, _ERR_TOO_BIG, _ERR_BAD_ITEM, _ERR_NO_REQUEST = 0, 1, 2, 3
+# keys whose (small) tensors ride in the header and come back as CPU tensors on every rank
+HOST_KEYS = ("seeds", "enc_index", "knobs", "timesteps")
 
 # What travels in bf16: every tensor the native path rounds to bf16 on arrival anyway (encoder states and the null embedding in
 # ace355_dit_set_condition, context latents in pack_xin / set_xin_ctx; csrc/dit.hip) - the transport rounding (RNE, same as the
@@ -82,8 +93,23 @@ def _pad(n: int) -> int:
     return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
 
+def _to_words(t: torch.Tensor) -> List[int]:
+    """A small CPU tensor of one of _DTYPES (not bf16) as int32 words."""
+    import numpy as np
+    a = t.detach().cpu().contiguous().numpy()
+    return np.frombuffer(a.tobytes(), dtype=np.int32).tolist()
+
+
+def _from_words(words: List[int], dt: torch.dtype, shape) -> torch.Tensor:
+    import numpy as np
+    a = np.array(words, dtype=np.int32).tobytes()
+    npdt = {torch.float32: np.float32, torch.int64: np.int64, torch.int32: np.int32, torch.float64: np.float64}[dt]
+    return torch.from_numpy(np.frombuffer(a, dtype=npdt).copy()).reshape(shape)
+
+
 def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int = 0, capacity_bytes: int = DEFAULT_CAPACITY_BYTES,
-                           device: Optional[torch.device] = None, bf16_keys: Sequence[str] = BF16_KEYS) -> Dict[str, torch.Tensor]:
+                           device: Optional[torch.device] = None, bf16_keys: Sequence[str] = BF16_KEYS,
+                           host_keys: Sequence[str] = HOST_KEYS, src_error: int = 0) -> Dict[str, torch.Tensor]:
     """Broadcast a dict of tensors from `src` at its EXACT size: a 0.4 KB header (shapes, dtypes, byte count - only `src` knows
     the request: L depends on the caption) followed by one flat byte payload, 16-byte aligned items.  Keys in `bf16_keys` travel
     as bf16 (see BF16_KEYS: lossless for this path), integer tensors as they are, the rest as fp32.  A 30 s request is 3.3 MB
@@ -91,7 +117,9 @@ def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int =
     algorithm on the xGMI full mesh for MB-scale payloads.
 
     Non-src ranks pass the KEYS (values ignored, may be None).  Anything wrong with the bundle on `src` (too many items or
-    dimensions, larger than `capacity_bytes`) travels in the header and raises on EVERY rank instead of dead-locking the others.
+    dimensions, larger than `capacity_bytes`, or `src_error`: the caller on `src` has no request to send) travels in the header and
+    raises on EVERY rank instead of dead-locking the others.  Keys in `host_keys` whose tensors fit the header's host area (4 KB in
+    all; int / fp32 / fp64) travel inside the header and come back as CPU tensors on every rank - no extra device read.
     Returned tensors keep their transport dtype (bf16 / int / fp32) and are private copies."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return bundle
@@ -99,14 +127,15 @@ def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int =
     rank = dist.get_rank()
     dev = _collective_device(device, bundle)
     head = torch.zeros(_HEADER, dtype=torch.int32, device=dev)
-    parts: List[torch.Tensor] = []
+    parts: List[Optional[torch.Tensor]] = []
     total = 0
     if rank == src:
         h = [_MAGIC, len(keys), 0, _ERR_NONE]
-        err = _ERR_NONE
-        if len(keys) > _MAX_ITEMS:
+        host: List[int] = []
+        err = src_error
+        if err == _ERR_NONE and len(keys) > _MAX_ITEMS:
             err = _ERR_BAD_ITEM
-        else:
+        elif err == _ERR_NONE:
             for k in keys:
                 t = bundle[k]
                 if not torch.is_tensor(t) or t.dim() > _MAX_DIMS:
@@ -117,6 +146,12 @@ def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int =
                     t = t.to(torch.bfloat16)
                 elif t.dtype not in _DTYPES:
                     t = t.to(torch.float32) if t.is_floating_point() else t.to(torch.int64)
+                nwords = (t.numel() * t.element_size() + 3) // 4
+                if k in host_keys and t.dtype != torch.bfloat16 and (t.numel() * t.element_size()) % 4 == 0 and len(host) + nwords <= _HOST_WORDS:
+                    h += [_IN_HEADER + _DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (_MAX_DIMS - t.dim())
+                    host += _to_words(t)
+                    parts.append(None)
+                    continue
                 t = t.to(dev).contiguous()
                 h += [_DTYPES.index(t.dtype), t.dim()] + list(t.shape) + [0] * (_MAX_DIMS - t.dim())
                 parts.append(t)
@@ -125,10 +160,12 @@ def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int =
                 err = _ERR_TOO_BIG
         if err != _ERR_NONE:
             h = [_MAGIC, -1, 0, err]
-            parts, total = [], 0
+            parts, total, host = [], 0, []
         else:
             h[2] = total
         head[: len(h)] = torch.tensor(h, dtype=torch.int32)
+        if host:
+            head[_ITEMS_END: _ITEMS_END + len(host)] = torch.tensor(host, dtype=torch.int32)
     dist.broadcast(head, src=src)
     hl = head.tolist()   # (the one host read of a request: receivers cannot slice the payload without the shapes)
     if hl[0] != _MAGIC:
@@ -136,6 +173,8 @@ def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int =
     if hl[1] < 0:
         if hl[3] == _ERR_TOO_BIG:
             raise ValueError(f"broadcast_conditioning: the bundle does not fit the {capacity_bytes}-byte limit")
+        if hl[3] == _ERR_NO_REQUEST:
+            raise ValueError("broadcast_conditioning: the source rank holds no request")
         raise ValueError(f"broadcast_conditioning: at most {_MAX_ITEMS} tensors of at most {_MAX_DIMS} dimensions per bundle")
     if hl[1] != len(keys):
         raise RuntimeError("broadcast_conditioning: ranks passed different key lists")
@@ -146,16 +185,25 @@ def broadcast_conditioning(bundle: Dict[str, Optional[torch.Tensor]], src: int =
     if rank == src:
         off = 0
         for t in parts:
+            if t is None:
+                continue
             nb = t.numel() * t.element_size()
             buf[off: off + nb] = t.reshape(-1).view(torch.uint8)
             off += _pad(nb)
     if total:
         dist.broadcast(buf, src=src)
-    out, off = {}, 0
+    out, off, hoff = {}, 0, _ITEMS_END
     for i, k in enumerate(keys):
         base = 4 + i * (_MAX_DIMS + 2)
-        dt, nd = _DTYPES[hl[base]], hl[base + 1]
+        code, nd = hl[base], hl[base + 1]
         shape = tuple(hl[base + 2: base + 2 + nd])
+        if code >= _IN_HEADER:   # rode in the header: a CPU tensor on every rank (src included: same object kind everywhere)
+            dt = _DTYPES[code - _IN_HEADER]
+            nw = int(torch.Size(shape).numel()) * torch.empty((), dtype=dt).element_size() // 4
+            out[k] = _from_words(hl[hoff: hoff + nw], dt, shape)
+            hoff += nw
+            continue
+        dt = _DTYPES[code]
         nb = int(torch.Size(shape).numel()) * torch.empty((), dtype=dt).element_size()
         out[k] = buf[off: off + nb].view(dt).view(shape).clone() if rank != src else parts[i]
         off += _pad(nb)
@@ -212,13 +260,17 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0):
 
 
 # ------------------------------------------------------------------------------------------------ the request runner
-KNOBS = ("inference_steps", "guidance_scale", "shift", "cfg_interval_start", "cfg_interval_end", "use_adg", "infer_method_sde")
+# every per-request scalar of generate_music travels with the request: a rank called with other defaults must not generate its songs
+# with settings that differ from rank 0's (advisor r3); explicit `timesteps` ride as their own (header) item
+KNOBS = ("inference_steps", "guidance_scale", "shift", "cfg_interval_start", "cfg_interval_end", "use_adg", "infer_method_sde",
+         "use_tiled_decode", "latent_shift", "latent_rescale")
 _KNOB_DEFAULTS = {"inference_steps": 27, "guidance_scale": 7.0, "shift": 1.0, "cfg_interval_start": 0.0, "cfg_interval_end": 1.0,
-                  "use_adg": 0.0, "infer_method_sde": 0.0}
+                  "use_adg": 0.0, "infer_method_sde": 0.0, "use_tiled_decode": 1.0, "latent_shift": 0.0, "latent_rescale": 1.0}
 
 
 def pack_request(encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor, seeds: Sequence[int],
-                 null_condition_emb: Optional[torch.Tensor] = None, **knobs) -> Dict[str, torch.Tensor]:
+                 null_condition_emb: Optional[torch.Tensor] = None, timesteps: Optional[Sequence[float]] = None,
+                 **knobs) -> Dict[str, torch.Tensor]:
     """The wire form of one generate_music request of G songs (rank 0): the DISTINCT rows of ``encoder_hidden_states [G | 1, L, D]``
     with an index per song (the reference replicates one caption across the batch, handler/batch_prep.py:93-96: one row),
     ``context_latents [G | 1, T, 128]`` collapsed to one row when every song shares it, per-song seeds, the request knobs."""
@@ -248,10 +300,12 @@ def pack_request(encoder_hidden_states: torch.Tensor, context_latents: torch.Ten
          "knobs": torch.tensor([kv[k] for k in KNOBS], dtype=torch.float64)}
     if null_condition_emb is not None:
         b["null"] = null_condition_emb.reshape(-1).contiguous()
+    # explicit schedule of the sft variant (base.py:1864-1875); empty = derive it from inference_steps / shift
+    b["timesteps"] = torch.as_tensor([] if timesteps is None else [float(t) for t in timesteps], dtype=torch.float32)
     return b
 
 
-_REQUEST_KEYS = ("enc_rows", "enc_index", "ctx", "seeds", "knobs", "null")
+_REQUEST_KEYS = ("enc_rows", "enc_index", "ctx", "seeds", "knobs", "null", "timesteps")
 
 
 def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[Dict[str, Any]], Any], src: int = 0,
@@ -262,32 +316,43 @@ def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[D
     1/2/4/8 GPUs), `execute(local)` on every rank that owns a song, optional gather of what it returned.
 
     `local` = {"encoder_hidden_states" [b, L, D], "context_latents" [b, T, 128], "null_condition_emb" [D] | None, "seeds" [b],
-    "knobs" {name: float}, "range" (s0, s1), "global_batch" G, "enc_rows", "enc_index"} - tensors in their transport dtype on
-    the collective device.  With `use_lm_hints` (same value on every rank) the per-song hints [G, T, 64] on `src` are scattered and
+    "knobs" {name: float}, "timesteps" list | None, "range" (s0, s1), "global_batch" G, "enc_rows", "enc_index"} - tensors in their
+    transport dtype on the collective device.  A source rank without a request makes EVERY rank raise (in-band, like the other refusals).  With `use_lm_hints` (same value on every rank) the per-song hints [G, T, 64] on `src` are scattered and
     replace the source-latent half of each song's context (base.py:1646-1649).  Returns {"local": execute's result or None,
     "range", "global_batch", "gathered": list per rank on `src` when `gather` (execute must then return a [b, ...] tensor)}."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world > 1:
         keys = list(_REQUEST_KEYS)
-        if rank == src:
-            if request is None:
-                raise ValueError("run_request: the source rank must hold the request")
-            # (a request without a null embedding still ships the key: every rank must pass the same key list)
+        src_error = _ERR_NONE
+        if rank == src and request is not None:
+            # (a request without a null embedding / explicit timesteps still ships the keys: every rank must pass the same key list)
             req = {k: request.get(k) for k in keys}
             if req["null"] is None:
                 req["null"] = torch.zeros(0)
+            if req["timesteps"] is None:
+                req["timesteps"] = torch.zeros(0)
         else:
+            # (src without a request: raising HERE would leave the other ranks waiting in the broadcast - the refusal rides in the
+            #  header and raises on every rank, advisor r3)
             req = {k: None for k in keys}
-        b = broadcast_conditioning(req, src=src, capacity_bytes=capacity_bytes, device=device)
+            if rank == src:
+                src_error = _ERR_NO_REQUEST
+        b = broadcast_conditioning(req, src=src, capacity_bytes=capacity_bytes, device=device, src_error=src_error)
     else:
         if request is None:
             raise ValueError("run_request: no request")
         b = dict(request)
         b.setdefault("null", None)
+        b.setdefault("timesteps", None)
     G = int(b["seeds"].numel())
     s0, s1 = shard_range(G, world, rank)
-    knobs = dict(zip(KNOBS, [float(x) for x in b["knobs"].tolist()]))
+    # (seeds / enc_index / knobs / timesteps rode in the header at N > 1: CPU tensors, no device read here)
+    kvals = [float(x) for x in b["knobs"].tolist()]
+    knobs = dict(_KNOB_DEFAULTS)
+    knobs.update(dict(zip(KNOBS, kvals)))   # (a shorter knob vector = an older packer: the missing ones keep their defaults)
+    ts_t = b.get("timesteps")
+    timesteps = [float(x) for x in ts_t.tolist()] if ts_t is not None and ts_t.numel() else None
     seeds_all = [int(x) for x in b["seeds"].tolist()]
     idx_all = [int(x) for x in b["enc_index"].tolist()]
     ctx = b["ctx"]
@@ -306,6 +371,7 @@ def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[D
         null = b.get("null")
         local = {"encoder_hidden_states": b["enc_rows"][[idx_all[i] for i in range(s0, s1)]], "context_latents": ctx_l,
                  "null_condition_emb": None if null is None or null.numel() == 0 else null, "seeds": seeds_all[s0:s1], "knobs": knobs,
+                 "timesteps": timesteps,
                  "range": (s0, s1), "global_batch": G, "enc_rows": b["enc_rows"], "enc_index": idx_all[s0:s1]}
         result = execute(local)
     out = {"local": result, "range": (s0, s1), "global_batch": G}

@@ -200,6 +200,16 @@ class NativeDit:
         False / 0: off; True / 1: default (calls with >= 1536 token rows); 2: every call the kernels support."""
         native.check(self._lib.ace355_dit_set_norm_fold(self._h, int(enable)), "dit_set_norm_fold")
 
+    def set_cfg_fork(self, mode) -> None:
+        """CFG fork: the null rows' MLP on a side stream beside the conditional rows' cross-attention chain (include/ace355.h).
+        False / 0: off; True / 1: default (big bf16 sampler calls); 2: every eligible call."""
+        native.check(self._lib.ace355_dit_set_cfg_fork(self._h, int(mode)), "dit_set_cfg_fork")
+
+    def cfg_fork_count(self) -> int:
+        n = C.c_int64()
+        native.check(self._lib.ace355_dit_cfg_fork_count(self._h, C.byref(n)), "dit_cfg_fork_count")
+        return n.value
+
     # ------------------------------------------------------------------ hipGraph replay of the sampler loop
     def set_graph(self, enable: bool) -> None:
         """Capture the sampler's launch sequence once per (shapes, schedule, knobs, slots, stream) and replay it afterwards."""

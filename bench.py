@@ -157,22 +157,41 @@ def vae_flops_per_frame(vcfg):
     return f
 
 
-def pmc_traffic_bytes_per_launch(with_source=False):
+def library_source_sha() -> str:
+    """sha256 (first 16 hex digits) over the sources libace355.so is built from (csrc/*.hip, csrc/common.h, include/ace355.h, sorted
+    by name): computable on the GPU box, where there is no .git - tools/pmc_summary.py stamps every PMC summary with it, so a profile
+    can be matched to the library that is being timed."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "ace-step-1.5-for-windows_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + [os.path.join(csrc, "common.h"), os.path.join(ROOT, "include", "ace355.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic_bytes_per_launch():
     """L2-miss-side bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (profiles/*.json,
     separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM: gfx950 tallies
     128-B requests at 64 B; both counters are in KiB).  These counters sit between the XCDs' L2s and the fabric: the bytes
-    include Infinity-Cache hits, i.e. they bound HBM traffic from above.  None when no profile is present: bench.py cannot
-    collect PMCs in its own process."""
+    include Infinity-Cache hits, i.e. they bound HBM traffic from above.  bench.py cannot collect PMCs in its own process, so the
+    number is only reported as `traffic` when the profile was taken on THIS library (the summary's `lib_src_sha` equals the sha of
+    the sources in the tree); an older profile is named with its commit under `traffic_stale` and `traffic` stays null.
+    -> dict(bytes, file, commit, lib_src_sha, current)."""
     try:
         import glob
+        # newest by the round / version in the name (r04_final sorts after r04_v1 ... after r03_*)
         f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")))[-1]
         w = f.replace("FETCH_SIZE", "WRITE_SIZE")
-        fetch = json.load(open(f))["gemm"]["FETCH_SIZE"]["per_launch"]
-        write = json.load(open(w))["gemm"]["WRITE_SIZE"]["per_launch"]
-        b = (2.0 * fetch + write) * 1024.0
-        return (b, os.path.relpath(f, ROOT)) if with_source else b
+        jf, jw = json.load(open(f)), json.load(open(w))
+        b = (2.0 * jf["gemm"]["FETCH_SIZE"]["per_launch"] + jw["gemm"]["WRITE_SIZE"]["per_launch"]) * 1024.0
+        meta = jf.get("_meta", {})
+        sha = meta.get("lib_src_sha")
+        return {"bytes": b, "file": os.path.relpath(f, ROOT), "commit": meta.get("commit"), "lib_src_sha": sha,
+                "current": bool(sha) and sha == library_source_sha() and jw.get("_meta", {}).get("lib_src_sha") == sha}
     except Exception:
-        return (None, None) if with_source else None
+        return None
 
 
 def usable_cpus() -> int:
@@ -358,22 +377,22 @@ def main():
     null = torch.randn(D, generator=g).to(device)
     ctx_shared = torch.cat([0.5 * torch.randn(T, 64, generator=g), torch.ones(T, 64)], -1).to(device)
 
-    noise_cache = {}
     last_local = {}
 
     def execute(local):
-        """One rank's share of a request: cross-K/V build for the cond / null slots -> sampler -> decode -> peak normalise.  Inputs
-        resident in HBM: the per-song noise (CPU generator: the reference's stream, base.py:1733-1770) is uploaded once per seed list."""
+        """One rank's share of a request: per-song noise -> cross-K/V build for the cond / null slots -> sampler -> decode -> peak
+        normalise.  The conditioning is resident in HBM; the noise is part of the request as in generate_audio (prepare_noise,
+        base.py:1733-1770: one CPU generator per seed - the reference's stream - then one upload), so it is drawn and uploaded in EVERY
+        pass, inside the timed region (until round 3 it was cached per seed list outside it)."""
         last_local.clear()
         last_local.update(local)
-        seeds = tuple(local["seeds"])
-        if seeds not in noise_cache:
-            noise_cache[seeds] = prepare_noise((len(seeds), T, 64), list(seeds)).to(device)
+        seeds = list(local["seeds"])
+        noise = prepare_noise((len(seeds), T, 64), seeds).to(device, non_blocking=True)
         k = local["knobs"]
         ts = schedule(int(k["inference_steps"]), k["shift"])
         dit.set_condition(SLOT_COND, local["enc_rows"][0])
         dit.set_condition(SLOT_NULL, local["null_condition_emb"].reshape(1, -1), L=L)
-        lat = dit.sample(noise_cache[seeds], local["context_latents"], ts, guidance_scale=k["guidance_scale"])
+        lat = dit.sample(noise, local["context_latents"], ts, guidance_scale=k["guidance_scale"])
         if vae is None:
             return lat
         wav = vae.decode(lat.transpose(1, 2).contiguous())
@@ -465,7 +484,7 @@ def main():
             "gemm_sp_kernel (bf16 MFMA 32x32x16; 192x256x64 and 192x128x64 8-wave / 128-192x128x64 4-wave tiles, LDS-DMA staging)"
         result["roofline"] = {"bound": "mfma", "kernel": kname,
                               "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tf / peak,
-                              "traffic": pmc_traffic_bytes_per_launch(), "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
+                              "traffic": None, "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
                               "avg_launch_us": 1000.0 * p["gemm_ms"] / max(p["gemm_launches"], 1),
                               "flops_per_launch": p["gemm_flops"] / max(p["gemm_launches"], 1),
                               "attn_tflops": p["attn_flops"] / (p["attn_ms"] * 1e-3) / 1e12 if p["attn_ms"] > 0 else 0.0,
@@ -490,11 +509,23 @@ def main():
                 "default": "on: the residual GEMMs also write bf16(h*g) + row sums, the QKV / cross-q / gate|up GEMMs apply rstd + shift W^T; "
                            "the standalone rmsnorm kernels (13.0 + 13.0 + 7.3 us per layer) are gone from the pass",
                 "gemm_ms_per_pass_norms_as_kernels": q["gemm_ms"], "achieved_norms_as_kernels": q_tf, "frac_norms_as_kernels": q_tf / peak}
-        tr = result["roofline"]["traffic"]
-        # L2-miss-side GB/s of the dominant kernel = PMC bytes per launch (committed profile of this command) / live launch time
-        result["roofline"]["hbm_gbps"] = (tr / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9) if tr else None
-        result["roofline"]["traffic_source"] = (f"{pmc_traffic_bytes_per_launch(True)[1]} + WRITE_SIZE twin: rocprofv3 --pmc passes of this command, committed "
-                                                "(not collected live); fabric-side of the L2s, so Infinity-Cache hits are included: an upper bound on HBM bytes")
+        # L2-miss-side bytes / GB/s of the dominant kernel = PMC bytes per launch (committed profile of this command) / live launch time;
+        # only when that profile was taken on the library being timed (same source sha), else it is named as stale and traffic stays null
+        pm = pmc_traffic_bytes_per_launch()
+        result["roofline"]["library_src_sha"] = library_source_sha()
+        if pm is not None:
+            src = (f"{pm['file']} + WRITE_SIZE twin (commit {pm['commit']}, lib_src_sha {pm['lib_src_sha']}): rocprofv3 --pmc passes of this command, "
+                   "committed (not collected live); fabric-side of the L2s, so Infinity-Cache hits are included: an upper bound on HBM bytes")
+            if pm["current"]:
+                result["roofline"]["traffic"] = pm["bytes"]
+                result["roofline"]["hbm_gbps"] = pm["bytes"] / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9
+                result["roofline"]["traffic_source"] = src
+            else:
+                result["roofline"]["hbm_gbps"] = None
+                result["roofline"]["traffic_stale"] = {"bytes": pm["bytes"], "source": src,
+                                                       "why": "the newest PMC profile under profiles/ was not taken on the library sources in this tree"}
+        else:
+            result["roofline"]["hbm_gbps"] = None
         do_cfg = args.guidance > 1.0
         alg = B * ((2 if do_cfg else 1) * args.infer_steps * dit_flops_per_forward_per_seq(dcfg, S, L) + (0 if args.no_vae else T * vae_flops_per_frame(vcfg)))
         result["algorithmic_tflop_per_step"] = alg / 1e12
@@ -514,7 +545,7 @@ def main():
             import subprocess
             dit.set_condition(SLOT_COND, enc)
             dit.set_condition(SLOT_NULL, null.reshape(1, -1), L=L)
-            _ = dit.sample(noise_cache[tuple(last_local["seeds"])], ctx_shared[None].expand(B, -1, -1).contiguous(), schedule(args.infer_steps, 1.0),
+            _ = dit.sample(prepare_noise((B, T, 64), list(last_local["seeds"])).to(device), ctx_shared[None].expand(B, -1, -1).contiguous(), schedule(args.infer_steps, 1.0),
                            guidance_scale=args.guidance)   # queued, not awaited
             out_smi = subprocess.run(["rocm-smi", "-d", str(device.index or 0), "--showclocks", "--showpower"], capture_output=True, text=True,
                                      timeout=20).stdout

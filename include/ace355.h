@@ -157,6 +157,15 @@ int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
  * enable: 0 off, 1 default (calls with >= 1536 token rows: below that the norm launches are cheaper), 2 every call (tests). */
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 
+/* CFG fork (on by default; ACE355_CFG_FORK=0 in the environment or mode = 0 here turns it off): under classifier-free guidance the
+ * batch is cat([cond, null]) (base.py:1905-1911) and the null half's cross-attention is a constant, so inside a decoder layer
+ * (base.py:515-539) the conditional rows' cross-attention chain and the null rows' MLP are independent: ace355_dit_sample queues the
+ * latter on a side stream (fork after the self-attention o_proj, join before the next layer's QKV projection; captured like any
+ * other launch under ace355_dit_set_graph).  Bit-identical to the single-stream order.  mode: 0 off, 1 default (bf16 calls whose two
+ * halves have >= 1536 token rows each), 2 every eligible call (tests).  cfg_fork_count: layers that forked so far. */
+int ace355_dit_set_cfg_fork(ace355_dit* h, int mode);
+int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks);
+
 /* Test / debug hook: after decoder layer `layer` (0-based) of every following forward, copy the fp32 residual stream
  * hidden_states [N*S, hidden] (the layer's output, base.py:539) to dst_dev; dst_dev NULL clears the tap.  Lets the parity
  * tests compare the per-layer activations the golden fixtures hold, not only the final velocity. */

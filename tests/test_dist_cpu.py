@@ -32,6 +32,9 @@ def _worker(rank, world, port, q):
     mine = ref if rank == 0 else {k: None for k in ref}  # only rank 0 knows the request: shapes travel in the header
     out = a_dist.broadcast_conditioning(mine, src=0, capacity_bytes=1 << 16)
     ok = all(out[k].dtype == want[k].dtype and torch.equal(out[k], want[k]) for k in ref)
+    # the small per-request scalars (HOST_KEYS) rode INSIDE the header: CPU tensors on every rank, bit for bit (int64 seeds above 2^32,
+    # fp64 knobs), no payload bytes and no second device read for them (round 4)
+    ok = ok and all(out[k].device.type == "cpu" for k in ("seeds", "knobs")) and out["seeds"].tolist() == ref["seeds"].tolist()
     out2 = a_dist.broadcast_conditioning(mine, src=0, capacity_bytes=1 << 16)  # results are private copies
     ok = ok and all(torch.equal(out[k], want[k]) and torch.equal(out2[k], want[k]) for k in ref)
     for bad in ({"big": torch.zeros(1 << 15) if rank == 0 else None},                       # larger than the limit
@@ -48,7 +51,15 @@ def _worker(rank, world, port, q):
     enc5[3] += 1.0                                            # songs 0,1,2,4 share a caption, song 3 has its own
     ctx5 = torch.randn(1, 6, 128, generator=g)
     seeds5 = [10, 11, 12, 13, 14]
-    req = a_dist.pack_request(enc5, ctx5.expand(G5, -1, -1), seeds5, torch.ones(16), inference_steps=9, guidance_scale=3.5) if rank == 0 else None
+    # a source rank WITHOUT a request: the refusal rides in the header and raises on every rank (it used to raise on src before the
+    # broadcast and leave the others waiting in it: advisor r3)
+    try:
+        a_dist.run_request(None, lambda local: None, src=0, device=torch.device("cpu"))
+        ok = False
+    except ValueError as e:
+        ok = ok and "no request" in str(e)
+    req = a_dist.pack_request(enc5, ctx5.expand(G5, -1, -1), seeds5, torch.ones(16), timesteps=[1.0, 0.6, 0.25, 0.0], inference_steps=9,
+                              guidance_scale=3.5, latent_rescale=0.5, use_tiled_decode=0.0) if rank == 0 else None
     if rank == 0:
         ok = ok and tuple(req["enc_rows"].shape) == (2, 7, 16) and req["enc_index"].tolist() == [0, 0, 0, 1, 0] and req["ctx"].shape[0] == 1
     calls = []
@@ -64,6 +75,9 @@ def _worker(rank, world, port, q):
     ok = ok and torch.equal(loc["encoder_hidden_states"].float(), enc5[s5:e5].to(torch.bfloat16).float())
     ok = ok and tuple(loc["context_latents"].shape) == (e5 - s5, 6, 128) and loc["knobs"]["inference_steps"] == 9.0 and loc["knobs"]["guidance_scale"] == 3.5
     ok = ok and loc["null_condition_emb"] is not None and float(loc["null_condition_emb"].float().sum()) == 16.0
+    # every per-request setting is rank 0's: explicit timesteps and the decode-side scalars travel too (defaults for what was not given)
+    ok = ok and loc["timesteps"] == [1.0, 0.6000000238418579, 0.25, 0.0] and loc["knobs"]["latent_rescale"] == 0.5
+    ok = ok and loc["knobs"]["use_tiled_decode"] == 0.0 and loc["knobs"]["latent_shift"] == 0.0 and loc["knobs"]["shift"] == 1.0
     if rank == 0:
         allw = torch.cat(res["gathered"], 0).reshape(-1)
         expect = enc5.to(torch.bfloat16).float().sum(dim=(1, 2)) + torch.tensor(seeds5, dtype=torch.float32)

@@ -124,6 +124,72 @@ def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
     assert torch.equal(folded, again) and not torch.equal(folded, plain)
 
 
+def test_tiny_sampler_with_cfg_fork_forced(gpu_device, golden_dir):
+    """The CFG fork on the small launches (forced with set_cfg_fork(2): 4-wave tiles, ordered split-K is off for forked halves only
+    when they are big, so here both streams run the small-M kernels) against the single-stream order and the reference's golden."""
+    from ace355 import weightgen
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
+    name = "cfg7_shift1"
+    cfg, w, dit = _make(TINY, int(G["seed"]), gpu_device)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=int(G["seed"]))
+    enc = torch.from_numpy(G[f"{name}_enc"])
+    ctx = torch.from_numpy(G[f"{name}_ctx"])
+    B = ctx.shape[0]
+    lo, hi = G[f"{name}_interval"].tolist()
+    kw = dict(seed=G[f"{name}_seeds"].tolist(), infer_steps=int(G[f"{name}_steps"]), diffusion_guidance_sale=float(G[f"{name}_guidance"]),
+              cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=G[f"{name}_timesteps"].tolist() or None)
+    ref = torch.from_numpy(G[f"{name}_out"])
+    res = {}
+    for fold in (0, 2):
+        dit.set_norm_fold(fold)
+        dit.set_cfg_fork(0)
+        single = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+        dit.set_cfg_fork(2)
+        n0 = dit.cfg_fork_count()
+        forked = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+        assert dit.cfg_fork_count() > n0, "the forced fork was not taken"
+        res[fold] = (_rel(forked, ref), _rel(forked, single))
+        assert torch.equal(forked, single), res
+    print(f"tiny sampler, cfg fork forced: vs reference {res[0][0]:.3e} (norm kernels) / {res[2][0]:.3e} (folded); forked == single stream")
+    assert res[0][0] < 5e-3 and res[2][0] < 5e-3, res
+
+
+def test_folded_norms_with_unordered_split_k_switch(gpu_device):
+    """ACE355_GEMM_SKORD=0 (the fp32-atomics split-K the split-K timeout message recommends) together with the folded RMSNorm of
+    the small-M launches (advisor r3): a folded-norm producer cannot be split into unordered parts - launch_gemm keeps such a launch's
+    K range whole instead of refusing the call.  A mid-size configuration whose residual GEMMs do split K (hidden 1024: 16 K steps,
+    16 tiles), batch 1 with CFG, folded vs norms as kernels, in a fresh process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import ace355\n"
+        "from ace355 import weightgen\n"
+        "from ace355.dit import NativeDit, generate_latents\n"
+        "dev = torch.device('cuda:0')\n"
+        "cfg = ace355.DitConfig(hidden_size=1024, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4)\n"
+        "w = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=3, mode='test')\n"
+        "null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=3)\n"
+        "dit = NativeDit(cfg, dev); dit.load_state_dict(w)\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "B, T, L = 1, 200, 33\n"
+        "enc = torch.randn(B, L, cfg.hidden_size, generator=g)\n"
+        "ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1)\n"
+        "kw = dict(seed=[7], infer_steps=4, diffusion_guidance_sale=7.0)\n"
+        "dit.set_norm_fold(0); a = generate_latents(dit, null, enc, ctx, **kw)['target_latents'].cpu()\n"
+        "dit.set_norm_fold(2); b = generate_latents(dit, null, enc, ctx, **kw)['target_latents'].cpu()\n"
+        "dit.poll_errors()\n"
+        "r = float((a - b).norm() / a.norm())\n"
+        "assert torch.isfinite(b).all() and r < 5e-3, r\n"
+        "print('skord0 fold ok', r)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ACE355_GEMM_SKORD="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "skord0 fold ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_tiny_sampler_cover_switch(gpu_device, golden_dir):
     from ace355 import weightgen
     from ace355.dit import generate_latents

@@ -119,6 +119,50 @@ def test_metric_batch_sampler_norm_fold_on_off(gpu_device, golden_dir, full_dit_
     assert not torch.equal(outs[True], outs[False])  # the two paths really are different launch sequences
 
 
+def test_cfg_fork_is_bit_identical_to_the_single_stream_order(gpu_device, golden_dir, full_dit_seed4):
+    """CFG fork (include/ace355.h ace355_dit_set_cfg_fork; base.py:515-539, 1905-1911): the null rows' MLP on a side stream beside the
+    conditional rows' cross-attention chain.  The metric batch (G12: 8 songs x 30 s, CFG 7 + APG, 3 steps) with the fork on and off,
+    folded norms and norms as kernels, eager and as a replayed graph: every output must be bit-identical to the single-stream order,
+    the fork must really have been taken (24 layers x 3 steps), and the result still matches the reference golden."""
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g12_metric_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    _, ctx1 = _inputs(B, T)
+    ref = torch.from_numpy(G["out"])
+    steps = int(G["steps"])
+
+    def run():
+        return generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G["seeds"].tolist(),
+                                infer_steps=steps, diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
+    try:
+        for fold in (True, False):
+            dit.set_norm_fold(fold)
+            dit.set_cfg_fork(0)
+            n0 = dit.cfg_fork_count()
+            single = run()
+            assert dit.cfg_fork_count() == n0
+            dit.set_cfg_fork(1)
+            forked = run()
+            assert dit.cfg_fork_count() == n0 + cfg.num_hidden_layers * steps, (dit.cfg_fork_count(), n0)
+            assert torch.equal(single, forked), f"fold={fold}: fork changed the result by {_rel(forked, single):.3e}"
+            dit.set_graph(True)
+            try:
+                g1 = run()   # capture (the side stream joins the capture through the fork event)
+                g2 = run()   # replay
+                assert dit.graph_stats()["replays"] >= 1
+            finally:
+                dit.set_graph(False)
+            assert torch.equal(single, g1) and torch.equal(single, g2), f"fold={fold}: graph replay of the forked sequence differs"
+            r = _rel(forked, ref)
+            print(f"cfg fork, fold={fold}: forked == single-stream bit for bit (eager and graph); vs reference fp32 {r:.3e}")
+            assert r < 1e-2, r
+    finally:
+        dit.set_norm_fold(True)
+        dit.set_cfg_fork(1)
+
+
 def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
     """G15: the reference's generate_audio over the WHOLE 27-step schedule at full size (B = 3 x 30 s, CFG 7 + APG: N = 6 sequences,
     2250 token rows = big GEMM tiles + folded RMSNorm in the native sampler) against one ace355_dit_sample call, folded and unfolded."""

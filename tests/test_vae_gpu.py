@@ -56,6 +56,54 @@ def test_decode_vs_oracle(gpu_device, cfg_kw, B, T):
     assert snr_emu > 30.0, snr_emu
 
 
+def test_decode_at_the_metric_length_vs_oracle(gpu_device):
+    """The decode AT THE METRIC LENGTH against the oracle itself (call site generate_music_decode.py:165-177):
+    full configuration, T = 750 latent frames (30 s, 1 440 000 samples per channel), B = 1, the whole waveform against
+    oracle/oobleck.py in fp32 and with bf16 storage between layers - the gates of test_decode_vs_oracle.  Until round 3 every decode
+    longer than 48 frames was only checked against shorter NATIVE decodes: a defect common to all native decodes of a certain size
+    (a grid-dimension wrap, a 32-bit offset) would have passed.  ~25 s of oracle time on the GPU box's 16 host threads."""
+    from oracle import oobleck as o_vae
+    cfg, w, vae = _build(dict(), gpu_device)
+    T = 750
+    z = torch.randn(1, 64, T, generator=torch.Generator().manual_seed(750))
+    wav = vae.decode(z)
+    assert wav.shape == (1, cfg.audio_channels, cfg.hop * T) and torch.isfinite(wav).all()
+    o_cfg = o_vae.VaeConfig()
+    ref = o_vae.decode(o_cfg, w, z)
+    emu = o_vae.decode(o_cfg, w, z, emulate_bf16=True)
+    snr_fp32, snr_emu, drift = _snr_db(wav, ref), _snr_db(wav, emu), _snr_db(emu, ref)
+    # the worst 1 s stretch as well: a localised defect would hide in a whole-signal SNR
+    sec = 48000
+    per_sec = [_snr_db(wav[..., i:i + sec], emu[..., i:i + sec]) for i in range(0, wav.shape[-1], sec)]
+    print(f"vae decode full config T=750 B=1: SNR vs fp32 oracle {snr_fp32:.1f} dB, vs bf16-storage oracle {snr_emu:.1f} dB (oracle's own "
+          f"bf16 drift {drift:.1f} dB); worst second vs bf16-storage oracle {min(per_sec):.1f} dB")
+    assert snr_fp32 > drift - 6.0, (snr_fp32, drift)
+    assert snr_emu > 30.0 and min(per_sec) > 27.0, (snr_emu, min(per_sec))
+
+
+def test_long_decode_deep_window_vs_oracle(gpu_device):
+    """configs[2]'s length (T = 3000 latent frames, 120 s): the LAST 200 frames of the native whole-sequence decode against the ORACLE
+    run on a window deep inside the sequence (frames 2784..3000: 16 halo frames on the left - the decoder's receptive field is 8.9
+    latent frames, DESIGN.md section 4 - the true sequence end on the right).  The reference side is the oracle, not a native decode."""
+    from oracle import oobleck as o_vae
+    cfg, w, vae = _build(dict(), gpu_device)
+    T, win, halo = 3000, 200, 16
+    z = torch.randn(1, 64, T, generator=torch.Generator().manual_seed(3000))
+    wav = vae.decode(z)
+    assert wav.shape == (1, cfg.audio_channels, cfg.hop * T) and torch.isfinite(wav).all()
+    zc = z[:, :, T - win - halo:].contiguous()
+    o_cfg = o_vae.VaeConfig()
+    ref = o_vae.decode(o_cfg, w, zc)[..., cfg.hop * halo:]
+    emu = o_vae.decode(o_cfg, w, zc, emulate_bf16=True)[..., cfg.hop * halo:]
+    got = wav[..., cfg.hop * (T - win):]
+    assert got.shape == ref.shape
+    snr_fp32, snr_emu, drift = _snr_db(got, ref), _snr_db(got, emu), _snr_db(emu, ref)
+    print(f"vae decode full config T=3000, frames 2800-3000 vs the oracle on that window: SNR vs fp32 {snr_fp32:.1f} dB, vs bf16-storage "
+          f"{snr_emu:.1f} dB (oracle's own bf16 drift {drift:.1f} dB)")
+    assert snr_fp32 > drift - 6.0, (snr_fp32, drift)
+    assert snr_emu > 30.0, snr_emu
+
+
 def test_whole_sequence_equals_tiled(gpu_device):
     """the reference's overlap-discard tiling equals the un-tiled decode away from fp order."""
     from oracle import tiling as o_tiling

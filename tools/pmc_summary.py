@@ -18,5 +18,14 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
 res = {}
 for fam, cs in agg.items():
     res[fam] = {c: {"total": v, "launches": len(launches[(fam, c)]), "per_launch": v / max(1, len(launches[(fam, c)]))} for c, v in cs.items()}
+# provenance: which library the pass ran on (sha of its sources: there is no .git on the GPU box) and, when the caller knows it
+# (ACE355_COMMIT, set from `git rev-parse --short HEAD` in the gpurun command line), the commit
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import library_source_sha
+    res["_meta"] = {"lib_src_sha": library_source_sha(), "commit": os.environ.get("ACE355_COMMIT") or None}
+except Exception as e:  # (never lose a profile over its stamp)
+    res["_meta"] = {"error": str(e)[:200]}
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps({f: {c: round(d["per_launch"], 1) for c, d in cs.items()} for f, cs in res.items()}))
+print(json.dumps({f: {c: round(d["per_launch"], 1) for c, d in cs.items()} for f, cs in res.items() if f != "_meta"}))

@@ -709,9 +709,11 @@ static int gqa_nwh(const AttnArgs& a) {  // which attn_gqa_kernel instantiation 
     if (a.Hq != 2 * a.Hkv || gqa_env == 0) return 0;
     auto units = [&](int nwh) { return (long)a.N * a.Hkv * ((a.Sq + 32 * nwh - 1) / (32 * nwh)); };
     if (gqa_env == 3 || gqa_env == 4 || gqa_env == 6) return gqa_env;
-    if (units(6) >= 224) return 6;
-    if (units(4) >= 224) return 4;
-    if (units(3) >= 128) return 3;
+    static int cus = -1;   // ACE355_MAX_WGS (experiment, gemm.hip): plan for this many CUs instead of 256
+    if (cus < 0) { const char* e = getenv("ACE355_MAX_WGS"); cus = e ? atoi(e) : 256; if (cus < 8 || cus > 256) cus = 256; }
+    if (units(6) >= 224 * cus / 256) return 6;
+    if (units(4) >= 224 * cus / 256) return 4;
+    if (units(3) >= 128 * cus / 256) return 3;
     return 0;
 }
 bool attention_mx_out_ok(const AttnArgs& a) { return gqa_nwh(a) != 0 && !a.kv_len; }

@@ -536,7 +536,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
 
     // CFG fork eligibility: a sampler forward (one shared timestep row: per-row gate / norm vectors have stride 0), bf16 kernels,
     // both halves present and big enough for the big tiles
-    const int fk_min = h->fk.mode >= 2 ? 64 : h->fk.min_rows;
+    const int fk_min = h->fk.mode >= 2 ? 1 : h->fk.min_rows;
     const bool fork_ok = h->fk.mode > 0 && h->fk.side && temb_rows == 1 && n_sc > 0 && Nc > 0 && Mc >= fk_min && M - Mc >= fk_min &&
                          h->precision != ACE355_PRECISION_MXFP8;
     // SwiGLU MLP (base.py:530-533) of token rows [r0, r0 + nr) on stream st (bf16 kernels): [norm] -> gate|up + SwiGLU -> down + gated residual

@@ -1188,6 +1188,19 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// ACE355_MAX_WGS (experiment, round 4; default 256 = the CUs of the chip): the number of workgroup slots a GEMM launch plans for.  With
+// 128 every launch is shaped for HALF the chip (tile choice, persistent grid of 128 workgroups), so that two independent launch
+// sequences on two streams run side by side on 128 CUs each instead of interleaving their workgroups over all 256.
+static int gemm_cu_slots() {
+    static int v = -1;
+    if (v < 0) {
+        v = env_int("ACE355_MAX_WGS", 256);
+        if (v < 8 || v > 256) v = 256;
+        v &= ~7;
+    }
+    return v;
+}
+
 template <int MODE>
 static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc,
                         int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
@@ -1221,12 +1234,13 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
     const dim3 grid(8 * region, ep.kparts > 1 ? ep.kparts : 1);
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
-    const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= 256;
+    const int cus = gemm_cu_slots(), pers_x = cus / 8;   // persistent workgroups per XCD
+    const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= cus;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
         if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
-        else if (big && pers && !ep.no_pers && region > 32) {
-            const dim3 pgrid(8 * 32);
+        else if (big && pers && !ep.no_pers && region > pers_x) {
+            const dim3 pgrid(8 * pers_x);
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
         } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
@@ -1241,8 +1255,8 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
             if (mid_ns == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
             else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
         }
-    } else if (big && pers && !ep.no_pers && region > 32 && (MODE != 2 || pers >= 2)) {
-        const dim3 pgrid(8 * 32);
+    } else if (big && pers && !ep.no_pers && region > pers_x && (MODE != 2 || pers >= 2)) {
+        const dim3 pgrid(8 * pers_x);
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
     } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
@@ -1279,7 +1293,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     int mt = 2, bn = BN;
     int big = 0;  // 0: 4-wave 128/192x128 tiles, 1: 8-wave 192x256, 2: 8-wave 192x128
     if (variant != 1) {
-        const long slots = 512;
+        const long cus = gemm_cu_slots();
+        const long slots = 2 * cus;
         const long tn128 = (N + 127) / 128;
         const long t128 = (long)((M + 127) / 128) * tn128, t192 = (long)((M + 191) / 192) * tn128;
         const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
@@ -1289,8 +1304,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
         // (>= 180 tiles: three quarters of the CUs with one 8-wave workgroup each beat the same work as 384 four-wave workgroups on 512
         //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
-        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 && (N % 256 == 0 || N >= 1024)) || (ep.tile_hint == 1 && bigenv != 0 && N % 256 == 0)) { mt = 3; bn = 256; big = 1; }
-        else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 && t192 <= 320))) { mt = 3; bn = 128; big = 2; }
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 * cus / 256 && (N % 256 == 0 || N >= 1024)) || (ep.tile_hint == 1 && bigenv != 0 && N % 256 == 0)) { mt = 3; bn = 256; big = 1; }
+        else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 * cus / 256 && t192 <= 320 * cus / 256))) { mt = 3; bn = 128; big = 2; }
     }
     // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every
     // workgroup alone on its CU with a long serial K loop.  Slab split-K (ACE355_GEMM_SLAB=1, OFF by default): the 8-wave 192x128 tile, K

@@ -709,8 +709,9 @@ static int gqa_nwh(const AttnArgs& a) {  // which attn_gqa_kernel instantiation 
     if (a.Hq != 2 * a.Hkv || gqa_env == 0) return 0;
     auto units = [&](int nwh) { return (long)a.N * a.Hkv * ((a.Sq + 32 * nwh - 1) / (32 * nwh)); };
     if (gqa_env == 3 || gqa_env == 4 || gqa_env == 6) return gqa_env;
-    static int cus = -1;   // ACE355_MAX_WGS (experiment, gemm.hip): plan for this many CUs instead of 256
-    if (cus < 0) { const char* e = getenv("ACE355_MAX_WGS"); cus = e ? atoi(e) : 256; if (cus < 8 || cus > 256) cus = 256; }
+    static int cus_env = -1;   // AttnArgs::cu_slots, else ACE355_MAX_WGS (gemm.hip): plan for this many CUs instead of 256
+    if (cus_env < 0) { const char* e = getenv("ACE355_MAX_WGS"); cus_env = e ? atoi(e) : 256; if (cus_env < 8 || cus_env > 256) cus_env = 256; }
+    const int cus = (a.cu_slots >= 8 && a.cu_slots <= 256) ? a.cu_slots : cus_env;
     if (units(6) >= 224 * cus / 256) return 6;
     if (units(4) >= 224 * cus / 256) return 4;
     if (units(3) >= 128 * cus / 256) return 3;

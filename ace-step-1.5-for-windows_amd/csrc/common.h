@@ -156,6 +156,10 @@ struct GemmEpilogue {
     // tile even for multi-round launches (a persistent grid keeps every CU it was given until its last tile: nothing for a kernel of
     // another stream to slip into)
     int tile_hint; int no_pers;
+    // cu_slots (0 = the whole chip, 256): the CUs this launch plans for - tile choice, persistent grid size, deep-pipeline decision.  The
+    // dual-chain sampler (dit.hip) runs two independent launch sequences on two hardware queues and shapes every launch of both for 128
+    // CUs, so that the chains run side by side instead of interleaving workgroups over all 256 (round 4: 512 -> 473 ms per 8-song pass)
+    int cu_slots;
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
@@ -206,6 +210,7 @@ struct AttnArgs {
     // tiles of one (q-block, head, sequence), each leaving un-normalised O (fp32), its running max and its row sum, and a second small
     // kernel merges them (same result as one pass up to fp32 rounding; order fixed, so bit-reproducible).  kv_split is set by launch_attention.
     float* part; long part_floats; int kv_split;
+    int cu_slots;   // host-side hint, as GemmEpilogue::cu_slots: 0 = plan for the whole chip
 };
 int launch_attention(const AttnArgs& a, hipStream_t s);
 bool attention_mx_out_ok(const AttnArgs& a);  // will launch_attention take the kernel that can write MXFP8?
@@ -252,6 +257,8 @@ int launch_small_linear(const float* in, const bf16_t* W, const float* b, float*
                         int silu_in, int silu_out, int accumulate, hipStream_t s);
 int launch_small_linear_ex(const float* in, const bf16_t* W, const float* b, float* out, float* out_silu, int Mr, int N,
                            int K, int silu_out, int accumulate, hipStream_t s);
+// one wave that spins for `us` microseconds (wall clock): the stream-concurrency probe of the dual-chain sampler (dit.hip)
+int launch_spin(int us, hipStream_t s);
 int launch_pack_xin(const float* x, const float* ctx, bf16_t* xin, int N, int T, int Tpad, hipStream_t s);
 int launch_set_xin_latent(const float* xt, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s);
 int launch_set_xin_ctx(const float* ctx, bf16_t* xin, int B, int copies, int T, int Tpad, hipStream_t s);

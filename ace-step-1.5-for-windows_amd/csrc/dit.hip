@@ -129,7 +129,9 @@ struct ace355_dit {
     // cat (base.py:1905-1911).  Results are bit-identical to the single-stream order (every output element is the same accumulation
     // whatever launch it lands in; the row sums are integer atomics).
     struct CfgFork {
-        int mode = 1;                 // ACE355_CFG_FORK / ace355_dit_set_cfg_fork: 0 off, 1 default (big bf16 sampler launches), 2 every eligible call (tests)
+        int mode = 0;                 // ACE355_CFG_FORK / ace355_dit_set_cfg_fork: 0 off (default: measured SLOWER, 549 vs 507 ms per pass - a
+                                      // persistent gate|up grid on the side stream holds every CU and the cross-attention launches wait for it;
+                                      // DESIGN.md section 10), 1 big bf16 sampler launches, 2 every eligible call (tests)
         int min_rows = 1536;          // both halves must take the big tiles (no split-K counters shared between the streams)
         int down_big = 1;             // ACE355_FORK_DOWN_BIG: the two half-batch down projections on the 192x256 tile (128 workgroups each)
         int no_pers = 0;              // ACE355_FORK_NOPERS: side-stream gate|up without persistent workgroups
@@ -138,6 +140,25 @@ struct ace355_dit {
         int* sk_cnt = nullptr;        // the side stream's own split-K turn counters (two concurrent launches must not share tile counters)
         long forks = 0;               // layers that took the fork so far (tests)
     } fk;
+
+    // Dual-chain sampler (round 4).  The songs of a request are independent through the whole sampling loop (generate_audio carries no
+    // cross-item term: per-item noise, per-item CFG / APG, base.py:1783-1989), so ace355_dit_sample runs them as TWO half-batch samplers
+    // on two hardware queues, every launch of both shaped for half the chip (cu_slots = 128): each chain keeps its 128 CUs busy with its
+    // own K loops while the other's memory-bound phases (the residual GEMMs' fp32 read-modify-write bursts, attention prologues, output
+    // bursts) get the fabric to themselves.  Measured on 1 x MI355X, 8 songs x 30 s x 27 steps: 512.4 ms as one chain, 473 ms as two
+    // (tools/dual_chain_probe.py).  Chain 2 runs on a CONTEXT: a second ace355_dit that aliases this handle's
+    // weights and condition slots and owns its workspace and schedule tables.
+    struct Dual {
+        int mode = 1;                 // ACE355_DUAL / ace355_dit_set_dual: 0 one chain, 1 two chains when the request has >= 2 songs
+        int slots_min_rows = 1536;    // ACE355_DUAL_SLOTS_MIN_ROWS: chains with at least this many token rows plan their launches for half the chip
+        ace355_dit* ctx = nullptr;    // chain 2's context (created on first use)
+        hipStream_t probed_main = nullptr;   // the caller stream the side stream was last checked against
+        bool probed = false, concurrent = false;
+        long calls = 0;               // sampler calls that ran as two chains (tests)
+    } dual;
+    bool fork_blocked = false;   // the current call runs as two chains: the side stream is chain 2's, no per-layer CFG fork on it
+    bool alias = false;      // this object is a chain context: weights, slots and rope tables belong to the owning handle
+    int cu_slots = 0;        // GemmEpilogue::cu_slots / AttnArgs::cu_slots of this context's launches (0: the whole chip)
 
     int* sk_cnt = nullptr;   // split-K counters lent to launch_gemm (GemmEpilogue::sk_cnt)
     float* sk_slab = nullptr;   // slab split-K scratch lent to launch_gemm (GemmEpilogue::sk_slab, SK_SLAB_FLOATS)
@@ -267,6 +288,7 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
     const bool side = h->fk.side && s == h->fk.side;
     e2.sk_cnt = side ? h->fk.sk_cnt : h->sk_cnt;
     e2.sk_slab = side ? nullptr : h->sk_slab; e2.sk_slab_cap = SK_SLAB_FLOATS;
+    e2.cu_slots = h->cu_slots;
     return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, e2, s);
 }
 
@@ -279,20 +301,22 @@ int gemm_mx(ace355_dit* h, const bf16_t* A, int lda, const MxW& W, void* C, int 
         int rc = launch_mx_quant(A, lda, M, K, h->xq, h->xs, h->xs_pad, s);
         if (rc) return rc;
     }
+    GemmEpilogue epx = ep;
+    epx.cu_slots = h->cu_slots;
     if (preq) {
         EvScope ev(h, &h->gemm_ev, s);
         if (h->profile) {
             h->gemm_flops += 2.0 * M * N * K;
             h->gemm_launches++;
         }
-        return launch_gemm_mx(preq, pres, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, ep, s);
+        return launch_gemm_mx(preq, pres, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, epx, s);
     }
     EvScope ev(h, &h->gemm_ev, s);
     if (h->profile) {
         h->gemm_flops += 2.0 * M * N * K;
         h->gemm_launches++;
     }
-    return launch_gemm_mx(h->xq, h->xs, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, ep, s);
+    return launch_gemm_mx(h->xq, h->xs, h->xs_pad, W.q, W.sc, W.pad, C, ldc, M, N, K, epx, s);
 }
 bool mx_usable(const ace355_dit* h, const MxW& W, int M, int N, int K, int mode, int q_cols = 0, int qk_cols = 0) {
     static int mask = -1;  // ACE355_MX_MASK: subset of the projections that run in MXFP8 (error / time trade-offs)
@@ -537,7 +561,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     // CFG fork eligibility: a sampler forward (one shared timestep row: per-row gate / norm vectors have stride 0), bf16 kernels,
     // both halves present and big enough for the big tiles
     const int fk_min = h->fk.mode >= 2 ? 1 : h->fk.min_rows;
-    const bool fork_ok = h->fk.mode > 0 && h->fk.side && temb_rows == 1 && n_sc > 0 && Nc > 0 && Mc >= fk_min && M - Mc >= fk_min &&
+    const bool fork_ok = h->fk.mode > 0 && !h->fork_blocked && !h->alias && h->fk.side && temb_rows == 1 && n_sc > 0 && Nc > 0 && Mc >= fk_min && M - Mc >= fk_min &&
                          h->precision != ACE355_PRECISION_MXFP8;
     // SwiGLU MLP (base.py:530-533) of token rows [r0, r0 + nr) on stream st (bf16 kernels): [norm] -> gate|up + SwiGLU -> down + gated residual
     auto mlp_rows = [&](int li, int r0, int nr, hipStream_t st) -> int {
@@ -609,6 +633,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.window = sliding ? h->cfg.sliding_window : -1;
             a.scale = scale;
             a.part = h->attn_part; a.part_floats = h->attn_part_floats;
+            a.cu_slots = h->cu_slots;
             if (mx_usable(h, W.mx_o, M, D, QD, 2) && attention_mx_out_ok(a)) {  // the o_proj MX GEMM's operand straight from the attention epilogue
                 a.out_q = h->xq; a.out_scales = h->xs; a.out_pad = h->xs_pad;
                 ao_is_mx = true;
@@ -680,6 +705,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
             a.N = Nc; a.Sq = S; a.Skv = L; a.Hq = h->HQ; a.Hkv = h->KVH; a.window = -1; a.scale = scale;
             a.part = h->attn_part; a.part_floats = h->attn_part_floats;
+            a.cu_slots = h->cu_slots;
             if (mx_cross && mx_usable(h, W.mx_oc, Mc, D, QD, 2) && attention_mx_out_ok(a)) {
                 a.out_q = h->xq; a.out_scales = h->xs; a.out_pad = h->xs_pad;
                 cao_is_mx = true;
@@ -751,60 +777,189 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     return rc;
 }
 
-// The sampling loop of generate_audio (base.py:1913-1981) as a launch sequence on stream s: steps x {timestep embedding,
-// decoder forward, guidance + update}.  Pure enqueue (no synchronisation, no allocation): runs eagerly or under stream capture.
-int run_sampler_steps(ace355_dit* h, const ace355_sample_params* p, int B, int T, hipStream_t s, std::vector<hipEvent_t>* evs) {
+// The sampling loop of generate_audio (base.py:1913-1981) as a launch sequence: steps x {timestep embedding, decoder forward, guidance +
+// update}.  Pure enqueue (no synchronisation, no allocation): runs eagerly or under stream capture.  One SamplerChain = one context (the
+// handle, or the chain-2 context of the dual-chain sampler) advancing ITS songs on ITS stream; the chains of a call are stepped in turn
+// by the caller, so that the host feeds both hardware queues step by step instead of one chain's whole schedule first.
+struct SamplerChain {
+    ace355_dit* h = nullptr;
+    ace355_sample_params p;      // this chain's view of the request (per-item pointers advanced to its first song)
+    int B = 0, T = 0;
+    int sde_B = 0;               // songs of the WHOLE request: the per-step stride of sde_noise_dev [steps][B][T][64]
+    hipStream_t s = nullptr;
+    int cond = 0;
+    const int32_t* cond_tab = nullptr;
+    bool switched = false;
+    int apg_calls = 0;
+};
+int sampler_begin(SamplerChain& c) {
+    const bool do_cfg = c.p.guidance_scale > 1.0f;
+    c.cond_tab = c.p.cond_slots_host;  // per-item conditions (NULL: cond_slot for every item)
+    c.cond = c.p.cond_slot;
+    c.switched = false;
+    c.apg_calls = 0;
+    return normfold_prepare(c.h, &c.p, c.B * (do_cfg ? 2 : 1), c.T, c.s);
+}
+int sampler_step(SamplerChain& c, int i, hipEvent_t ev) {
+    ace355_dit* h = c.h;
+    const ace355_sample_params* p = &c.p;
+    hipStream_t s = c.s;
+    const int B = c.B, T = c.T;
     const bool do_cfg = p->guidance_scale > 1.0f;
     const int copies = do_cfg ? 2 : 1, N = B * copies;
     const int Tpad = 2 * ((T + 1) / 2);
     int rc;
     int slots[ACE355_MAX_SEQS];
-    const int32_t* cond_tab = p->cond_slots_host;  // per-item conditions (NULL: cond_slot for every item)
-    int cond = p->cond_slot;
-    bool switched = false;
-    int apg_calls = 0;
-    rc = normfold_prepare(h, p, N, T, s);
+    h->nf.step = i;
+    if (i >= p->cover_switch_step && !c.switched) {  // base.py:1916-1927
+        c.switched = true;
+        ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
+        c.cond = p->non_cover_slot;
+        c.cond_tab = p->non_cover_slots_host;
+        rc = launch_set_xin_ctx(p->ctx_non_cover_dev, h->xin, B, copies, T, Tpad, s);
+        if (rc) return rc;
+    }
+    for (int b = 0; b < B; ++b) {
+        slots[b] = c.cond_tab ? c.cond_tab[b] : c.cond;
+        if (do_cfg) slots[B + b] = p->null_slot;
+    }
+    const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
+    RoctxRange r_step("ace355.sampler_step");
+    if (!h->nf.emb_on) {   // (normfold_prepare already computed the embeddings of the whole schedule: forward_core reads row i)
+        rc = time_embed(h, &t_curr, &t_curr, 1, s);
+        if (rc) return rc;
+    }
+    rc = forward_core(h, N, T, slots, 1, s);
     if (rc) return rc;
-    for (int i = 0; i < p->num_steps; ++i) {
-        h->nf.step = i;
-        if (i >= p->cover_switch_step && !switched) {  // base.py:1916-1927
-            switched = true;
-            ACE_CHECK(p->ctx_non_cover_dev != nullptr, "dit_sample: cover switch needs ctx_non_cover_dev");
-            cond = p->non_cover_slot;
-            cond_tab = p->non_cover_slots_host;
-            rc = launch_set_xin_ctx(p->ctx_non_cover_dev, h->xin, B, copies, T, Tpad, s);
-            if (rc) return rc;
-        }
-        for (int b = 0; b < B; ++b) {
-            slots[b] = cond_tab ? cond_tab[b] : cond;
-            if (do_cfg) slots[B + b] = p->null_slot;
-        }
-        const float t_curr = p->t_sched_host[i], t_prev = p->t_sched_host[i + 1];
-        RoctxRange r_step("ace355.sampler_step");
-        if (!h->nf.emb_on) {   // (normfold_prepare already computed the embeddings of the whole schedule: forward_core reads row i)
-            rc = time_embed(h, &t_curr, &t_curr, 1, s);
-            if (rc) return rc;
-        }
-        rc = forward_core(h, N, T, slots, 1, s);
-        if (rc) return rc;
-        const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
-        const float dt = t_curr - t_prev;
-        StepUpdate up{nullptr, t_curr, 0.f};
-        if (p->infer_method == 1) {
-            up.sde_noise = p->sde_noise_dev + (size_t)i * B * T * h->OUTC;
-            // base / sft: linear level (base.py:1972); turbo: the next table value (turbo.py:1980-1984)
-            up.t_next = p->sde_next_from_sched ? t_prev : 1.0f - (float)(i + 1) / (float)p->num_steps;
-        }
-        if (do_cfg && apply && p->use_adg)
-            rc = launch_adg_step(h->vpad, (long)B * Tpad * h->OUTC, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, t_curr, dt, up, s);
-        else
-            rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
-                                  apply, do_cfg ? 1 : 0, apg_calls == 0 ? 1 : 0, up, s);
-        if (rc) return rc;
-        if (do_cfg && apply && !p->use_adg) ++apg_calls;
-        if (evs) hipEventRecord((*evs)[i + 1], s);
+    const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
+    const float dt = t_curr - t_prev;
+    StepUpdate up{nullptr, t_curr, 0.f};
+    if (p->infer_method == 1) {
+        up.sde_noise = p->sde_noise_dev + (size_t)i * c.sde_B * T * h->OUTC;
+        // base / sft: linear level (base.py:1972); turbo: the next table value (turbo.py:1980-1984)
+        up.t_next = p->sde_next_from_sched ? t_prev : 1.0f - (float)(i + 1) / (float)p->num_steps;
+    }
+    if (do_cfg && apply && p->use_adg)
+        rc = launch_adg_step(h->vpad, (long)B * Tpad * h->OUTC, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, t_curr, dt, up, s);
+    else
+        rc = launch_apg_euler(h->vpad, (long)B * Tpad * h->OUTC, h->avg, h->xt, h->xin, copies, B, T, Tpad, p->guidance_scale, dt,
+                              apply, do_cfg ? 1 : 0, c.apg_calls == 0 ? 1 : 0, up, s);
+    if (rc) return rc;
+    if (do_cfg && apply && !p->use_adg) ++c.apg_calls;
+    if (ev) hipEventRecord(ev, s);
+    return 0;
+}
+
+// One or two chains of one call, stepped in turn.  Two chains: chain 2 (the context) runs on the handle's side stream between a fork
+// and a join event on `s` - the same sequence eagerly and under stream capture (the side stream joins the capture through the event).
+int run_sampler_chains(ace355_dit* h, SamplerChain* chains, int nchains, hipStream_t s, std::vector<hipEvent_t>* evs) {
+    int rc;
+    if (nchains == 2) {
+        ACE_HIP(hipEventRecord(h->fk.ev_fork, s));
+        ACE_HIP(hipStreamWaitEvent(chains[1].s, h->fk.ev_fork, 0));
+    }
+    for (int k = nchains - 1; k >= 0; --k)
+        if ((rc = sampler_begin(chains[k]))) return rc;
+    const int steps = chains[0].p.num_steps;
+    for (int i = 0; i < steps; ++i)
+        for (int k = nchains - 1; k >= 0; --k)
+            if ((rc = sampler_step(chains[k], i, (k == 0 && evs) ? (*evs)[i + 1] : nullptr))) return rc;
+    if (nchains == 2) {
+        ACE_HIP(hipEventRecord(h->fk.ev_join, chains[1].s));
+        ACE_HIP(hipStreamWaitEvent(s, h->fk.ev_join, 0));
     }
     return 0;
+}
+
+// ---- chain-2 context of the dual-chain sampler
+int chain_ctx_sync(ace355_dit* h) {
+    if (!h->dual.ctx) {
+        ace355_dit* c = new ace355_dit();
+        c->alias = true;
+        c->fk.mode = 0;
+        c->dual.mode = 0;
+        ALLOC(c->allocs, c->flags_dev, 4);
+        ALLOC(c->allocs, c->sk_cnt, SK_CNT_INTS);
+        ACE_HIP(hipMemset(c->sk_cnt, 0, SK_CNT_INTS * sizeof(int)));
+        ALLOC(c->allocs, c->fk.sk_cnt, SK_CNT_INTS);
+        ACE_HIP(hipMemset(c->fk.sk_cnt, 0, SK_CNT_INTS * sizeof(int)));
+        c->attn_part_floats = h->attn_part_floats;
+        ALLOC(c->allocs, c->attn_part, (size_t)c->attn_part_floats);
+        h->dual.ctx = c;
+    }
+    ace355_dit* c = h->dual.ctx;
+    // everything the forward reads but does not own: dimensions, packed weights (+ their MXFP8 copies), norm tables, condition slots, rope
+    c->cfg = h->cfg;
+    c->D = h->D; c->F = h->F; c->QD = h->QD; c->KVD = h->KVD; c->NL = h->NL; c->KVH = h->KVH; c->HQ = h->HQ; c->OUTC = h->OUTC;
+    c->layers = h->layers;
+    c->w_in = h->w_in; c->w_out = h->w_out; c->w_cond = h->w_cond;
+    c->b_in = h->b_in; c->b_out = h->b_out; c->b_cond = h->b_cond; c->norm_out = h->norm_out; c->sst_out = h->sst_out;
+    c->te[0] = h->te[0]; c->te[1] = h->te[1];
+    c->mod_tab = h->mod_tab;
+    c->finalized = h->finalized;
+    for (int i = 0; i < ACE355_MAX_SLOTS; ++i) c->slots[i] = h->slots[i];
+    c->rope_cos = h->rope_cos; c->rope_sin = h->rope_sin; c->rope_S = h->rope_S;
+    if (c->precision != h->precision || c->weights_fp8wo != h->weights_fp8wo || c->nf.enabled != h->nf.enabled) c->nf.key.clear();
+    c->precision = h->precision; c->weights_fp8wo = h->weights_fp8wo; c->mx_min_rows = h->mx_min_rows;
+    c->nf.enabled = h->nf.enabled; c->nf.min_rows = h->nf.min_rows;
+    c->profile = h->profile;
+    return 0;
+}
+void chain_ctx_destroy(ace355_dit* c) {
+    if (!c) return;
+    for (void* p : c->allocs) hipFree(p);
+    for (void* p : c->ws_allocs) hipFree(p);
+    for (void* p : c->nf.allocs) hipFree(p);
+    for (auto& e : c->gemm_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : c->attn_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    delete c;
+}
+
+// Do the caller's stream and the side stream sit on different hardware queues?  The runtime hands out a few queues (GPU_MAX_HW_QUEUES,
+// 4 by default) and shares them between streams beyond that; two streams on one queue run their kernels strictly one after the
+// other (the two-stream probes of rounds 2 / 3 measured exactly that and read it as "no gain").  Two 60 us spin kernels, one per stream,
+// between two events: ~60 us side by side, ~120 us in series.  A serialised side stream is replaced by a fresh one (up to 6 tries).
+// Once per caller stream; synchronises it.  Not under capture.
+int dual_probe_streams(ace355_dit* h, hipStream_t s) {
+    if (h->dual.probed && h->dual.probed_main == s) return 0;
+    h->dual.probed = true;
+    h->dual.probed_main = s;
+    h->dual.concurrent = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ACE_HIP(hipEventCreate(&e0));
+    ACE_HIP(hipEventCreate(&e1));
+    std::vector<hipStream_t> losers;
+    int rc = 0;
+    for (int attempt = 0; attempt < 6 && !h->dual.concurrent; ++attempt) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 2 && !rc; ++rep) {   // (the first pair also pays the streams' first-use set-up)
+            hipEventRecord(e0, s);
+            hipEventRecord(h->fk.ev_fork, s);
+            hipStreamWaitEvent(h->fk.side, h->fk.ev_fork, 0);
+            rc = launch_spin(60, h->fk.side);
+            hipEventRecord(h->fk.ev_join, h->fk.side);
+            if (!rc) rc = launch_spin(60, s);
+            hipStreamWaitEvent(s, h->fk.ev_join, 0);
+            hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) rc = 2;
+            float ms = 0.f;
+            if (!rc && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) best = std::min(best, ms);
+        }
+        if (rc) break;
+        if (best < 0.095f) { h->dual.concurrent = true; break; }
+        losers.push_back(h->fk.side);   // (kept alive until a winner is found: a destroyed stream's queue slot would be handed out again)
+        h->fk.side = nullptr;
+        if (hipStreamCreateWithFlags(&h->fk.side, hipStreamNonBlocking) != hipSuccess) { h->fk.side = losers.back(); losers.pop_back(); break; }
+    }
+    for (hipStream_t l : losers) hipStreamDestroy(l);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (!h->dual.concurrent && !rc) {
+        static bool said = false;
+        if (!said) fprintf(stderr, "[ace355] no side stream on a hardware queue of its own for this caller stream: the sampler runs as one chain\n");
+        said = true;
+    }
+    return rc;
 }
 
 }  // namespace
@@ -865,6 +1020,8 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     if (int prc = gemm_verify_splitk_placement()) return prc;
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
+    if (const char* e = getenv("ACE355_DUAL")) h->dual.mode = atoi(e);
+    if (const char* e = getenv("ACE355_DUAL_SLOTS_MIN_ROWS")) h->dual.slots_min_rows = atoi(e);
     if (const char* e = getenv("ACE355_CFG_FORK")) h->fk.mode = atoi(e);
     if (const char* e = getenv("ACE355_CFG_FORK_MIN_ROWS")) h->fk.min_rows = atoi(e);
     if (const char* e = getenv("ACE355_FORK_DOWN_BIG")) h->fk.down_big = atoi(e);
@@ -888,6 +1045,7 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
 void ace355_dit_destroy(ace355_dit* h) {
     if (!h) return;
     hipDeviceSynchronize();
+    chain_ctx_destroy(h->dual.ctx);
     for (void* p : h->allocs) hipFree(p);
     for (void* p : h->ws_allocs) hipFree(p);
     for (void* p : h->mx_allocs) hipFree(p);
@@ -975,6 +1133,7 @@ int ace355_dit_finalize(ace355_dit* h) {
         ACE_HIP(hipMemcpy(h->mod_tab, tab.data(), tab.size() * sizeof(ModEntry), hipMemcpyHostToDevice));
     }
     h->nf.key.clear();   // embedding / bias tables are functions of the (possibly new) weights
+    if (h->dual.ctx) h->dual.ctx->nf.key.clear();
     h->finalized = true;
     return ACE355_OK;
 }
@@ -1058,6 +1217,8 @@ int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, 
     ACE_CHECK(N > 0 && N <= ACE355_MAX_SEQS && T > 0, "dit_forward: N in [1,64], T > 0");
     hipStream_t s = (hipStream_t)stream;
     h->vt_key_N = h->vt_key_S = -1;   // (see ace355_dit_sample)
+    h->cu_slots = 0;
+    h->fork_blocked = false;
     int rc = ensure_workspace(h, N, T, s);
     if (rc) return rc;
     const int Tpad = 2 * ((T + 1) / 2);
@@ -1084,21 +1245,72 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     ACE_CHECK(N <= ACE355_MAX_SEQS, "dit_sample: at most 64 sequences per call");
     hipStream_t s = (hipStream_t)stream;
     RoctxRange r_sample("ace355.dit_sample");
-    // the pad columns [S, Sp) of V^T are zeroed by the first forward of EVERY call (12.6 MB at the metric shape), also inside a captured
-    // graph: a replay skips forward_core, so a key that survived across calls could describe a buffer another shape had since written
-    // (stale - possibly non-finite - V values under zero attention weights; advisor r3)
-    h->vt_key_N = h->vt_key_S = -1;
-    int rc = ensure_workspace(h, N, T, s);
+    const int S = (T + 1) / 2;
+    const int Tpad = 2 * S;
+    const int OC = h->OUTC;
+
+    // ---- one chain or two (dual-chain sampler, see ace355_dit::Dual): songs [0, B0) stay on this handle and the caller's stream,
+    // songs [B0, B) go to the chain-2 context on the side stream.  Taps address the rows of the whole batch: one chain.
+    bool taps = false;
+    for (int l = 0; l < h->NL; ++l) taps = taps || h->tap_dst[l] != nullptr;
+    const bool graph = h->graph_mode && !per_step_ms_host && !h->profile && !taps;
+    if (graph && !h->graph_stream) {
+        ACE_HIP(hipStreamCreateWithFlags(&h->graph_stream, hipStreamNonBlocking));
+        ACE_HIP(hipEventCreateWithFlags(&h->graph_in, hipEventDisableTiming));
+        ACE_HIP(hipEventCreateWithFlags(&h->graph_out, hipEventDisableTiming));
+    }
+    hipStream_t run_s = graph ? h->graph_stream : s;   // the stream the loop is enqueued (or captured) on
+    int nchains = 1;
+    if (h->dual.mode && B >= 2 && !taps && h->fk.side) {
+        int rc0 = dual_probe_streams(h, run_s);
+        if (rc0) return rc0;
+        if (h->dual.concurrent) nchains = 2;
+    }
+    const int B0 = nchains == 2 ? (B + 1) / 2 : B, B1 = B - B0;
+    ace355_dit* ctxs[2] = {h, nullptr};
+    if (nchains == 2) {
+        int rc0 = chain_ctx_sync(h);
+        if (rc0) return rc0;
+        ctxs[1] = h->dual.ctx;
+    }
+    const int Bc[2] = {B0, B1}, b0[2] = {0, B0};
+    h->fork_blocked = nchains == 2;
+    int rc;
+    for (int k = 0; k < nchains; ++k) {
+        ace355_dit* c = ctxs[k];
+        // launches planned for half the chip when there are two chains of big launches (small ones never fill a half anyway)
+        c->cu_slots = (nchains == 2 && Bc[k] * copies * S >= h->dual.slots_min_rows) ? 128 : 0;
+        // the pad columns [S, Sp) of V^T are zeroed by the first forward of EVERY call (12.6 MB at the metric shape), also inside a
+        // captured graph: a replay skips forward_core, so a key that survived across calls could describe a buffer another shape had
+        // since written (stale - possibly non-finite - V values under zero attention weights; advisor r3)
+        c->vt_key_N = c->vt_key_S = -1;
+        if (k == 1 && c->rope_S < S) {   // (the handle's rope tables grow in its own ensure_workspace: pick the new ones up)
+            c->rope_cos = nullptr; c->rope_sin = nullptr; c->rope_S = 0;
+        }
+    }
+    rc = ensure_workspace(h, B0 * copies, T, s);
     if (rc) return rc;
-    rc = normfold_reserve(h, p->num_steps, N, T, s);
+    rc = normfold_reserve(h, p->num_steps, B0 * copies, T, s);
     if (rc) return rc;
-    const int Tpad = 2 * ((T + 1) / 2);
-    const size_t lat_bytes = (size_t)B * T * h->OUTC * sizeof(float);
-    ACE_HIP(hipMemcpyAsync(h->xt, xt0_dev, lat_bytes, hipMemcpyDeviceToDevice, s));
-    rc = launch_set_xin_ctx(ctx_dev, h->xin, B, copies, T, Tpad, s);
-    if (rc) return rc;
-    rc = launch_set_xin_latent(h->xt, h->xin, B, copies, T, Tpad, s);
-    if (rc) return rc;
+    if (nchains == 2) {
+        ace355_dit* c = ctxs[1];
+        c->rope_cos = h->rope_cos; c->rope_sin = h->rope_sin; c->rope_S = h->rope_S;   // (ensure_rope above covers S; the context never grows them)
+        const long e_before = c->ws_epoch;
+        rc = ensure_workspace(c, B1 * copies, T, s);
+        if (rc) return rc;
+        rc = normfold_reserve(c, p->num_steps, B1 * copies, T, s);
+        if (rc) return rc;
+        if (c->ws_epoch != e_before) h->ws_epoch++;   // a captured graph holds the context's buffers too
+    }
+    const size_t item_lat = (size_t)T * OC, item_ctx = (size_t)T * 2 * OC;
+    for (int k = 0; k < nchains; ++k) {   // inputs into the chains' own buffers (on the caller's stream, ahead of the fork)
+        ace355_dit* c = ctxs[k];
+        ACE_HIP(hipMemcpyAsync(c->xt, xt0_dev + b0[k] * item_lat, Bc[k] * item_lat * sizeof(float), hipMemcpyDeviceToDevice, s));
+        rc = launch_set_xin_ctx(ctx_dev + b0[k] * item_ctx, c->xin, Bc[k], copies, T, Tpad, s);
+        if (rc) return rc;
+        rc = launch_set_xin_latent(c->xt, c->xin, Bc[k], copies, T, Tpad, s);
+        if (rc) return rc;
+    }
 
     struct Events {  // destroyed on every exit path (a failing step used to leak them)
         std::vector<hipEvent_t> v;
@@ -1110,88 +1322,99 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         for (auto& e : evs) ACE_HIP(hipEventCreate(&e));
         hipEventRecord(evs[0], s);
     }
-    // hipGraph replay: the loop below is a fixed launch sequence for fixed (shapes, schedule, knobs, slot layout, buffers):
-    // captured once, replayed for every later call with the same key (the latent / context inputs were copied into the
-    // handle's own buffers above, the result is copied out below, so caller pointers are not part of the graph)
-    bool done = false;
+    // chain views of the request: per-item pointers advanced to the chain's first song
     ace355_sample_params pg = *p;   // graph mode: the loop reads handle-owned copies of the caller's optional tensors
-    if (h->graph_mode && !per_step_ms_host && !h->profile) {
-        bool taps = false;
-        for (int l = 0; l < h->NL; ++l) taps = taps || h->tap_dst[l] != nullptr;
-        if (!taps) {
-            auto own = [&](const float* src, size_t n, float** dst, size_t* cap) -> int {
-                if (!src) return 0;
-                if (n > *cap) {
-                    ACE_HIP(hipStreamSynchronize(s));
-                    if (*dst) hipFree(*dst);
-                    *dst = nullptr; *cap = 0;
-                    ACE_HIP(hipMalloc((void**)dst, n * sizeof(float) + 256));
-                    *cap = n;
-                    h->ws_epoch++;
-                }
-                ACE_HIP(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-                return 0;
-            };
-            if ((rc = own(p->ctx_non_cover_dev, (size_t)B * T * 2 * h->OUTC, &h->g_ctx_nc, &h->g_ctx_nc_n))) return rc;
-            if ((rc = own(p->sde_noise_dev, (size_t)p->num_steps * B * T * h->OUTC, &h->g_sde, &h->g_sde_n))) return rc;
-            if (p->ctx_non_cover_dev) pg.ctx_non_cover_dev = h->g_ctx_nc;
-            if (p->sde_noise_dev) pg.sde_noise_dev = h->g_sde;
-            p = &pg;
-            std::string key((const char*)p->t_sched_host, (size_t)(p->num_steps + 1) * sizeof(float));
-            auto add = [&](const void* q, size_t n) { key.append((const char*)q, n); };
-            const long scal[] = {B, T, p->num_steps, p->infer_method, p->use_adg, p->cond_slot, p->null_slot, p->cover_switch_step,
-                                 p->non_cover_slot, p->sde_next_from_sched, h->ws_epoch, h->cond_epoch,
-                                 p->ctx_non_cover_dev ? 1L : 0L, p->sde_noise_dev ? 1L : 0L};
-            add(scal, sizeof(scal));
-            const float fl[] = {p->guidance_scale, p->cfg_interval_start, p->cfg_interval_end};
-            add(fl, sizeof(fl));
-            if (p->cond_slots_host) add(p->cond_slots_host, sizeof(int32_t) * B);
-            key.push_back('|');
-            if (p->non_cover_slots_host) add(p->non_cover_slots_host, sizeof(int32_t) * B);
-            if (!h->graph_stream) {
-                ACE_HIP(hipStreamCreateWithFlags(&h->graph_stream, hipStreamNonBlocking));
-                ACE_HIP(hipEventCreateWithFlags(&h->graph_in, hipEventDisableTiming));
-                ACE_HIP(hipEventCreateWithFlags(&h->graph_out, hipEventDisableTiming));
-            }
-            hipStream_t gs = h->graph_stream;
-            ACE_HIP(hipEventRecord(h->graph_in, s));            // the input copies above
-            ACE_HIP(hipStreamWaitEvent(gs, h->graph_in, 0));
-            if (h->graph_exec && key == h->graph_key) {
-                ACE_HIP(hipGraphLaunch(h->graph_exec, gs));
-                h->graph_replays++;
-                done = true;
-            } else {
-                if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-                hipGraph_t g = nullptr;
-                if (hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    rc = run_sampler_steps(h, p, B, T, gs, nullptr);
-                    const hipError_t e = hipStreamEndCapture(gs, &g);
-                    if (rc) { if (g) hipGraphDestroy(g); return rc; }
-                    if (e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-                        h->graph_key = key;
-                        h->graph_captures++;
-                        hipGraphDestroy(g);
-                        ACE_HIP(hipGraphLaunch(h->graph_exec, gs));
-                        done = true;
-                    } else {
-                        if (g) hipGraphDestroy(g);
-                        h->graph_exec = nullptr;
-                        (void)hipGetLastError();  // capture / instantiate refused: run eagerly below
-                    }
+    auto own = [&](const float* src, size_t n, float** dst, size_t* cap) -> int {
+        if (!src) return 0;
+        if (n > *cap) {
+            ACE_HIP(hipStreamSynchronize(s));
+            if (*dst) hipFree(*dst);
+            *dst = nullptr; *cap = 0;
+            ACE_HIP(hipMalloc((void**)dst, n * sizeof(float) + 256));
+            *cap = n;
+            h->ws_epoch++;
+        }
+        ACE_HIP(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    };
+    if (graph) {
+        if ((rc = own(p->ctx_non_cover_dev, (size_t)B * T * 2 * OC, &h->g_ctx_nc, &h->g_ctx_nc_n))) return rc;
+        if ((rc = own(p->sde_noise_dev, (size_t)p->num_steps * B * T * OC, &h->g_sde, &h->g_sde_n))) return rc;
+        if (p->ctx_non_cover_dev) pg.ctx_non_cover_dev = h->g_ctx_nc;
+        if (p->sde_noise_dev) pg.sde_noise_dev = h->g_sde;
+    }
+    SamplerChain chains[2];
+    for (int k = 0; k < nchains; ++k) {
+        SamplerChain& c = chains[k];
+        c.h = ctxs[k];
+        c.p = pg;
+        c.B = Bc[k]; c.T = T; c.sde_B = B;
+        c.s = k == 0 ? run_s : h->fk.side;
+        if (c.p.cond_slots_host) c.p.cond_slots_host += b0[k];
+        if (c.p.non_cover_slots_host) c.p.non_cover_slots_host += b0[k];
+        if (c.p.ctx_non_cover_dev) c.p.ctx_non_cover_dev += b0[k] * item_ctx;
+        if (c.p.sde_noise_dev) c.p.sde_noise_dev += b0[k] * item_lat;
+    }
+    // hipGraph replay: the loop is a fixed launch sequence for fixed (shapes, schedule, knobs, slot layout, buffers, chain split):
+    // captured once, replayed for every later call with the same key (the latent / context inputs were copied into the
+    // chains' own buffers above, the result is copied out below, so caller pointers are not part of the graph)
+    bool done = false;
+    if (graph) {
+        std::string key((const char*)p->t_sched_host, (size_t)(p->num_steps + 1) * sizeof(float));
+        auto add = [&](const void* q, size_t n) { key.append((const char*)q, n); };
+        const long scal[] = {B, T, p->num_steps, p->infer_method, p->use_adg, p->cond_slot, p->null_slot, p->cover_switch_step,
+                             p->non_cover_slot, p->sde_next_from_sched, h->ws_epoch, h->cond_epoch,
+                             p->ctx_non_cover_dev ? 1L : 0L, p->sde_noise_dev ? 1L : 0L, nchains, (long)(uintptr_t)h->fk.side};
+        add(scal, sizeof(scal));
+        const float fl[] = {p->guidance_scale, p->cfg_interval_start, p->cfg_interval_end};
+        add(fl, sizeof(fl));
+        if (p->cond_slots_host) add(p->cond_slots_host, sizeof(int32_t) * B);
+        key.push_back('|');
+        if (p->non_cover_slots_host) add(p->non_cover_slots_host, sizeof(int32_t) * B);
+        hipStream_t gs = h->graph_stream;
+        ACE_HIP(hipEventRecord(h->graph_in, s));            // the input copies above
+        ACE_HIP(hipStreamWaitEvent(gs, h->graph_in, 0));
+        if (h->graph_exec && key == h->graph_key) {
+            ACE_HIP(hipGraphLaunch(h->graph_exec, gs));
+            h->graph_replays++;
+            done = true;
+        } else {
+            if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(gs, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                rc = run_sampler_chains(h, chains, nchains, gs, nullptr);
+                const hipError_t e = hipStreamEndCapture(gs, &g);
+                if (rc) { if (g) hipGraphDestroy(g); return rc; }
+                if (e == hipSuccess && g && hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    h->graph_key = key;
+                    h->graph_captures++;
+                    hipGraphDestroy(g);
+                    ACE_HIP(hipGraphLaunch(h->graph_exec, gs));
+                    done = true;
                 } else {
-                    (void)hipGetLastError();
+                    if (g) hipGraphDestroy(g);
+                    h->graph_exec = nullptr;
+                    (void)hipGetLastError();  // capture / instantiate refused: run eagerly below
                 }
+            } else {
+                (void)hipGetLastError();
             }
         }
-    }
-    if (done) {  // the output copy below (and whatever the caller enqueues next) waits for the replay
-        ACE_HIP(hipEventRecord(h->graph_out, h->graph_stream));
+        // the output copy below (and whatever the caller enqueues next) waits for the replay / for an eager fallback on gs
+        if (!done) {
+            rc = run_sampler_chains(h, chains, nchains, gs, nullptr);
+            if (rc) return rc;
+        }
+        ACE_HIP(hipEventRecord(h->graph_out, gs));
         ACE_HIP(hipStreamWaitEvent(s, h->graph_out, 0));
     } else {
-        rc = run_sampler_steps(h, p, B, T, s, per_step_ms_host ? &evs : nullptr);
+        rc = run_sampler_chains(h, chains, nchains, s, per_step_ms_host ? &evs : nullptr);
         if (rc) return rc;
     }
-    ACE_HIP(hipMemcpyAsync(latents_out_dev, h->xt, lat_bytes, hipMemcpyDeviceToDevice, s));
+    if (nchains == 2) h->dual.calls++;
+    h->cu_slots = 0;   // (a host-side launch hint: later single-chain work on this handle plans for the whole chip again)
+    for (int k = 0; k < nchains; ++k)
+        ACE_HIP(hipMemcpyAsync(latents_out_dev + b0[k] * item_lat, ctxs[k]->xt, Bc[k] * item_lat * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (per_step_ms_host) {
         ACE_HIP(hipStreamSynchronize(s));
         for (int i = 0; i < p->num_steps; ++i) hipEventElapsedTime(&per_step_ms_host[i], evs[i], evs[i + 1]);
@@ -1236,6 +1459,7 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
             ACE_HIP(hipDeviceSynchronize());
             h->weights_fp8wo = true;
             h->nf.key.clear();        // embedding / bias tables are functions of the weights
+            if (h->dual.ctx) h->dual.ctx->nf.key.clear();
             for (CondSlot& c : h->slots) c.valid = false;   // cross K/V were projected with the unrounded weights
         }
         h->precision = ACE355_PRECISION_BF16;   // (compute path: the bf16 kernels)
@@ -1273,7 +1497,9 @@ int ace355_dit_set_precision(ace355_dit* h, int precision) {
 int ace355_dit_poll_errors(ace355_dit* h, void* stream) {
     ACE_CHECK(h, "poll_errors: null handle");
     if (int rc = gemm_splitk_poll(h->sk_cnt, (hipStream_t)stream)) return rc;
-    return gemm_splitk_poll(h->fk.sk_cnt, (hipStream_t)stream);   // (the side stream's launches were joined into `stream` before it could be idle)
+    if (int rc = gemm_splitk_poll(h->fk.sk_cnt, (hipStream_t)stream)) return rc;   // (the side stream's launches were joined into `stream` before it could be idle)
+    if (h->dual.ctx) return gemm_splitk_poll(h->dual.ctx->sk_cnt, (hipStream_t)stream);
+    return ACE355_OK;
 }
 
 int ace355_dit_trim_slots(ace355_dit* h, int first_unused) {
@@ -1297,6 +1523,19 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable) {
     ACE_CHECK(h, "set_norm_fold: null handle");
     h->nf.enabled = enable;   // 0 off, 1 default (big-M calls), 2 every call the kernels support (tests)
     h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_set_dual(ace355_dit* h, int mode) {
+    ACE_CHECK(h && (mode == 0 || mode == 1), "set_dual: mode must be 0 or 1");
+    h->dual.mode = mode;
+    h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_dual_count(ace355_dit* h, int64_t* calls) {
+    ACE_CHECK(h && calls, "dual_count: null argument");
+    *calls = h->dual.calls;
     return ACE355_OK;
 }
 
@@ -1341,13 +1580,16 @@ int ace355_dit_set_tap(ace355_dit* h, int layer, float* dst_dev) {
 int ace355_dit_set_profile(ace355_dit* h, int enable) {
     ACE_CHECK(h, "set_profile: null handle");
     hipDeviceSynchronize();
-    for (auto& e : h->gemm_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (auto& e : h->attn_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    h->gemm_ev.clear();
-    h->attn_ev.clear();
-    h->gemm_flops = h->attn_flops = 0;
-    h->gemm_launches = 0;
-    h->profile = enable != 0;
+    for (ace355_dit* c : {h, h->dual.ctx}) {
+        if (!c) continue;
+        for (auto& e : c->gemm_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+        for (auto& e : c->attn_ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+        c->gemm_ev.clear();
+        c->attn_ev.clear();
+        c->gemm_flops = c->attn_flops = 0;
+        c->gemm_launches = 0;
+        c->profile = enable != 0;
+    }
     return ACE355_OK;
 }
 
@@ -1355,15 +1597,26 @@ int ace355_dit_get_profile(ace355_dit* h, double* gemm_ms, double* gemm_flops, d
                            int64_t* gemm_launches) {
     ACE_CHECK(h, "get_profile: null handle");
     ACE_HIP(hipDeviceSynchronize());
-    double g = 0, a = 0;
+    // Two chains: every launch of both is timed on its own stream, and the two run side by side on 128 CUs each - the sum of the
+    // durations over both chains is twice the time the chip spent.  The times reported are that sum divided by the number of chains
+    // that ran, i.e. chip time: flops / ms then prices a launch against the WHOLE chip's peak, as for one chain.
+    double g = 0, a = 0, gf = 0, af = 0;
+    long gl = 0;
+    int chains = 0;
     float ms;
-    for (auto& e : h->gemm_ev) { if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) g += ms; }
-    for (auto& e : h->attn_ev) { if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) a += ms; }
-    if (gemm_ms) *gemm_ms = g;
-    if (gemm_flops) *gemm_flops = h->gemm_flops;
-    if (attn_ms) *attn_ms = a;
-    if (attn_flops) *attn_flops = h->attn_flops;
-    if (gemm_launches) *gemm_launches = h->gemm_launches;
+    for (ace355_dit* c : {h, h->dual.ctx}) {
+        if (!c || (c != h && c->gemm_ev.empty())) continue;
+        ++chains;
+        for (auto& e : c->gemm_ev) { if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) g += ms; }
+        for (auto& e : c->attn_ev) { if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) a += ms; }
+        gf += c->gemm_flops; af += c->attn_flops; gl += c->gemm_launches;
+    }
+    if (chains < 1) chains = 1;
+    if (gemm_ms) *gemm_ms = g / chains;
+    if (gemm_flops) *gemm_flops = gf;
+    if (attn_ms) *attn_ms = a / chains;
+    if (attn_flops) *attn_flops = af;
+    if (gemm_launches) *gemm_launches = gl;
     return ACE355_OK;
 }
 

@@ -947,6 +947,18 @@ int launch_small_linear(const float* in, const bf16_t* W, const float* b, float*
     return launch_small_linear_ex(in, W, b, out, nullptr, Mr, N, K, silu_out, accumulate, s);
 }
 
+// One wave spinning on the 100 MHz wall clock: two of these on two streams take ~`us` when the streams sit on different hardware
+// queues and ~2 x `us` when the runtime mapped both onto one (dit.hip: dual-chain stream probe).
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+int launch_spin(int us, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (unsigned long long)us * 100ull);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_pack_xin(const float* x, const float* ctx, bf16_t* xin, int N, int T, int Tpad, hipStream_t s) {
     const long total = (long)N * Tpad * 48;
     hipLaunchKernelGGL(pack_xin_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, x, ctx, xin, T, Tpad, total);

@@ -1188,16 +1188,17 @@ static int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
-// ACE355_MAX_WGS (experiment, round 4; default 256 = the CUs of the chip): the number of workgroup slots a GEMM launch plans for.  With
-// 128 every launch is shaped for HALF the chip (tile choice, persistent grid of 128 workgroups), so that two independent launch
-// sequences on two streams run side by side on 128 CUs each instead of interleaving their workgroups over all 256.
-static int gemm_cu_slots() {
+// The CUs a GEMM launch plans for: GemmEpilogue::cu_slots, else ACE355_MAX_WGS (default 256 = the chip).  With 128 a launch is shaped for
+// HALF the chip (tile choice, persistent grid of 128 workgroups), so that two independent launch sequences on two hardware queues run
+// side by side on 128 CUs each instead of interleaving their workgroups over all 256 (the dual-chain sampler, dit.hip).
+static int gemm_cu_slots(int hint = 0) {
     static int v = -1;
     if (v < 0) {
         v = env_int("ACE355_MAX_WGS", 256);
         if (v < 8 || v > 256) v = 256;
         v &= ~7;
     }
+    if (hint >= 8 && hint <= 256) return hint & ~7;   // GemmEpilogue::cu_slots
     return v;
 }
 
@@ -1234,7 +1235,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
     const dim3 grid(8 * region, ep.kparts > 1 ? ep.kparts : 1);
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
-    const int cus = gemm_cu_slots(), pers_x = cus / 8;   // persistent workgroups per XCD
+    const int cus = gemm_cu_slots(ep.cu_slots), pers_x = cus / 8;   // persistent workgroups per XCD
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= cus;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
@@ -1293,7 +1294,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     int mt = 2, bn = BN;
     int big = 0;  // 0: 4-wave 128/192x128 tiles, 1: 8-wave 192x256, 2: 8-wave 192x128
     if (variant != 1) {
-        const long cus = gemm_cu_slots();
+        const long cus = gemm_cu_slots(ep.cu_slots);
         const long slots = 2 * cus;
         const long tn128 = (N + 127) / 128;
         const long t128 = (long)((M + 127) / 128) * tn128, t192 = (long)((M + 191) / 192) * tn128;
@@ -1458,8 +1459,9 @@ static void launch_mx_mode(hipStream_t s, const bf16_t* A, int lda, const bf16_t
     const int xcd_n = 8 / xcd_m;
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
     // (the persistent residual variant does not fit 256 VGPRs with the scale registers: 60 spilled; its launches are one round anyway)
-    if (pers && region > 32 && MODE != 2)
-        hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1, 2, 1>), dim3(8 * 32), dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, Kh, ep, tiles_n, nwg,
+    const int pers_x = gemm_cu_slots(ep.cu_slots) / 8;
+    if (pers && region > pers_x && MODE != 2)
+        hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1, 2, 1>), dim3(8 * pers_x), dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, Kh, ep, tiles_n, nwg,
                            group_m, xcd_m);
     else
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 0, 2, 1>), dim3(8 * region), dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, Kh, ep, tiles_n,

@@ -200,9 +200,20 @@ class NativeDit:
         False / 0: off; True / 1: default (calls with >= 1536 token rows); 2: every call the kernels support."""
         native.check(self._lib.ace355_dit_set_norm_fold(self._h, int(enable)), "dit_set_norm_fold")
 
+    def set_dual(self, enable) -> None:
+        """Dual-chain sampler (default on): requests of >= 2 songs run as two half-batch samplers on two hardware queues, every launch
+        planned for half the chip (include/ace355.h ace355_dit_set_dual).  False: one chain, launches planned for the whole chip."""
+        native.check(self._lib.ace355_dit_set_dual(self._h, 1 if enable else 0), "dit_set_dual")
+
+    def dual_count(self) -> int:
+        n = C.c_int64()
+        native.check(self._lib.ace355_dit_dual_count(self._h, C.byref(n)), "dit_dual_count")
+        return n.value
+
     def set_cfg_fork(self, mode) -> None:
         """CFG fork: the null rows' MLP on a side stream beside the conditional rows' cross-attention chain (include/ace355.h).
-        False / 0: off; True / 1: default (big bf16 sampler calls); 2: every eligible call."""
+        False / 0: off (the default: measured slower); True / 1: big bf16 sampler calls; 2: every eligible call.  Only single-chain calls fork
+        (set_dual(False), or one song)."""
         native.check(self._lib.ace355_dit_set_cfg_fork(self._h, int(mode)), "dit_set_cfg_fork")
 
     def cfg_fork_count(self) -> int:

@@ -457,7 +457,8 @@ def main():
                                f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward on rank 0), L={L}, "
                                f"{G} songs per request over {world} GPU(s)" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
                    "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "batch_rank0": B, "global_batch": G,
-                   "parallelism": f"dp{world}", "tiny": bool(args.tiny)},
+                   "parallelism": f"dp{world}", "tiny": bool(args.tiny),
+                   "sampler_chains_per_gpu": 2 if (B >= 2 and os.environ.get("ACE355_DUAL", "1") != "0") else 1},
     }
     if other is not None:
         result[other["scaling"]] = other
@@ -473,10 +474,15 @@ def main():
         dit.set_profile(True)
         if vae is not None:
             vae.set_profile(True)
+        dual0 = dit.dual_count() if hasattr(dit, "dual_count") else 0
         one_pass(collective=False)
         torch.cuda.synchronize()
         p = dit.get_profile()
         dit.set_profile(False)
+        # Two chains (the default for >= 2 songs): the DiT launches of the pass ran on two hardware queues, each planned for 128 of the
+        # 256 CUs.  ace355_dit_get_profile reports CHIP time (the sum of the launch durations over both chains / 2); the average
+        # launch duration a kernel trace shows is the per-launch figure: chip time x chains / launches.
+        chains = 2 if hasattr(dit, "dual_count") and dit.dual_count() > dual0 else 1
         gemm_tf = p["gemm_flops"] / (p["gemm_ms"] * 1e-3) / 1e12 if p["gemm_ms"] > 0 else 0.0
         peak = PEAK_MXFP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
         kname = ("gemm_sp_kernel<.., FP8> (MX-scaled fp8 MFMA 32x32x64 for QKV / o_proj / gate|up / down, 192x256x128 tiles; the cross-attention "
@@ -485,8 +491,13 @@ def main():
         result["roofline"] = {"bound": "mfma", "kernel": kname,
                               "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tf / peak,
                               "traffic": None, "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],
-                              "avg_launch_us": 1000.0 * p["gemm_ms"] / max(p["gemm_launches"], 1),
+                              "avg_launch_us": 1000.0 * p["gemm_ms"] * chains / max(p["gemm_launches"], 1),
                               "flops_per_launch": p["gemm_flops"] / max(p["gemm_launches"], 1),
+                              "concurrent_chains": chains, "cus_per_launch": 256 // chains,
+                              "accounting": ("achieved = flops_per_launch / avg_launch_us x concurrent_chains: with two chains every launch is planned "
+                                             "for 128 CUs and two launches run side by side, so a launch's rate is priced against half the chip's peak "
+                                             "(equivalently: all GEMM flops of the pass / (sum of launch durations / 2))") if chains == 2 else
+                                            "achieved = flops_per_launch / avg_launch_us (one chain: every launch has the whole chip)",
                               "attn_tflops": p["attn_flops"] / (p["attn_ms"] * 1e-3) / 1e12 if p["attn_ms"] > 0 else 0.0,
                               "attn_ms_per_pass": p["attn_ms"]}
         if vae is not None:
@@ -518,7 +529,7 @@ def main():
                    "committed (not collected live); fabric-side of the L2s, so Infinity-Cache hits are included: an upper bound on HBM bytes")
             if pm["current"]:
                 result["roofline"]["traffic"] = pm["bytes"]
-                result["roofline"]["hbm_gbps"] = pm["bytes"] / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9
+                result["roofline"]["hbm_gbps"] = pm["bytes"] * chains / (result["roofline"]["avg_launch_us"] * 1e-6) / 1e9
                 result["roofline"]["traffic_source"] = src
             else:
                 result["roofline"]["hbm_gbps"] = None

@@ -157,12 +157,23 @@ int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
  * enable: 0 off, 1 default (calls with >= 1536 token rows: below that the norm launches are cheaper), 2 every call (tests). */
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 
-/* CFG fork (on by default; ACE355_CFG_FORK=0 in the environment or mode = 0 here turns it off): under classifier-free guidance the
+/* Dual-chain sampler (on by default; ACE355_DUAL=0 in the environment or mode = 0 here turns it off).  The songs of a request are
+ * independent through the whole sampling loop of generate_audio (per-item noise, per-item CFG / APG; base.py:1783-1989), so a call
+ * with B >= 2 songs runs as TWO half-batch samplers - songs [0, ceil(B/2)) on the caller's stream, the rest on a side stream that
+ * sits on a hardware queue of its own (checked once per caller stream) - with every launch of both planned for half of the chip's
+ * CUs.  One chain's memory-bound phases then fall into the other's MFMA phases: 512 -> 473 ms per 8 x 30 s x 27-step request on one
+ * MI355X.  Each song's result is what a call with that song's half-batch alone returns.  Captured like any other launch under
+ * ace355_dit_set_graph.  dual_count: calls that ran as two chains so far. */
+int ace355_dit_set_dual(ace355_dit* h, int mode);
+int ace355_dit_dual_count(ace355_dit* h, int64_t* calls);
+
+/* CFG fork (OFF by default - measured slower; ACE355_CFG_FORK=1 in the environment or mode = 1 here turns it on for
+ * single-chain calls): under classifier-free guidance the
  * batch is cat([cond, null]) (base.py:1905-1911) and the null half's cross-attention is a constant, so inside a decoder layer
  * (base.py:515-539) the conditional rows' cross-attention chain and the null rows' MLP are independent: ace355_dit_sample queues the
  * latter on a side stream (fork after the self-attention o_proj, join before the next layer's QKV projection; captured like any
- * other launch under ace355_dit_set_graph).  Bit-identical to the single-stream order.  mode: 0 off, 1 default (bf16 calls whose two
- * halves have >= 1536 token rows each), 2 every eligible call (tests).  cfg_fork_count: layers that forked so far. */
+ * other launch under ace355_dit_set_graph).  Bit-identical to the single-stream order.  mode: 0 off (default), 1 bf16 calls whose two
+ * halves have >= 1536 token rows each, 2 every eligible call (tests).  cfg_fork_count: layers that forked so far. */
 int ace355_dit_set_cfg_fork(ace355_dit* h, int mode);
 int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks);
 

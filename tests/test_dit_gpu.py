@@ -141,6 +141,7 @@ def test_tiny_sampler_with_cfg_fork_forced(gpu_device, golden_dir):
               cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=G[f"{name}_timesteps"].tolist() or None)
     ref = torch.from_numpy(G[f"{name}_out"])
     res = {}
+    dit.set_dual(False)   # (the per-layer fork lives in single-chain calls)
     for fold in (0, 2):
         dit.set_norm_fold(fold)
         dit.set_cfg_fork(0)

@@ -142,15 +142,20 @@ struct ace355_dit {
     } fk;
 
     // Dual-chain sampler (round 4).  The songs of a request are independent through the whole sampling loop (generate_audio carries no
-    // cross-item term: per-item noise, per-item CFG / APG, base.py:1783-1989), so ace355_dit_sample runs them as TWO half-batch samplers
-    // on two hardware queues, every launch of both shaped for half the chip (cu_slots = 128): each chain keeps its 128 CUs busy with its
-    // own K loops while the other's memory-bound phases (the residual GEMMs' fp32 read-modify-write bursts, attention prologues, output
-    // bursts) get the fabric to themselves.  Measured on 1 x MI355X, 8 songs x 30 s x 27 steps: 512.4 ms as one chain, 473 ms as two
-    // (tools/dual_chain_probe.py).  Chain 2 runs on a CONTEXT: a second ace355_dit that aliases this handle's
-    // weights and condition slots and owns its workspace and schedule tables.
+    // cross-item term: per-item noise, per-item CFG / APG, base.py:1783-1989), so ace355_dit_sample can run them as TWO half-batch
+    // samplers on two hardware queues.  Small requests (2-4 songs of 30 s: launches of a few dozen to ~200 workgroups, latency bound)
+    // gain from it - one chain's kernels fill the CUs the other leaves idle; at the metric batch the GEMMs of both chains sit at the
+    // power cap and the pair is no faster than one chain (numbers at `max_rows` below and in DESIGN.md section 10).  Chain 2 runs on a
+    // CONTEXT: a second ace355_dit that aliases this handle's weights and condition slots and owns its workspace and schedule tables.
     struct Dual {
-        int mode = 1;                 // ACE355_DUAL / ace355_dit_set_dual: 0 one chain, 1 two chains when the request has >= 2 songs
-        int slots_min_rows = 1536;    // ACE355_DUAL_SLOTS_MIN_ROWS: chains with at least this many token rows plan their launches for half the chip
+        int mode = 1;                 // ACE355_DUAL / ace355_dit_set_dual: 0 one chain; 1 (default) two chains for requests of >= 2 songs whose
+                                      // chains stay in the small-launch regime (<= max_rows token rows each); 2 two chains whenever >= 2 songs
+        int max_rows = 1536;          // ACE355_DUAL_MAX_ROWS.  Measured (same-box ABAB, 30 s songs, DiT + decode): 2 songs 207.1 -> 199.1 ms,
+                                      // 4 songs 300.3 -> 296.7 ms, 8 songs 507.7 -> 513-528 ms: where the launches fill the chip the GEMMs sit
+                                      // at the power cap and two chains only share it
+        int slots_min_rows = 1 << 30; // ACE355_DUAL_SLOTS_MIN_ROWS: chains with at least this many token rows plan their launches for half the
+                                      // chip (cu_slots 128).  Off by default: 473 ms against 479 without it for two 4-song chains (DiT only),
+                                      // but slower for small chains (2 songs: 226 vs 199 ms)
         ace355_dit* ctx = nullptr;    // chain 2's context (created on first use)
         hipStream_t probed_main = nullptr;   // the caller stream the side stream was last checked against
         bool probed = false, concurrent = false;
@@ -1022,6 +1027,7 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
     if (const char* e = getenv("ACE355_DUAL")) h->dual.mode = atoi(e);
     if (const char* e = getenv("ACE355_DUAL_SLOTS_MIN_ROWS")) h->dual.slots_min_rows = atoi(e);
+    if (const char* e = getenv("ACE355_DUAL_MAX_ROWS")) h->dual.max_rows = atoi(e);
     if (const char* e = getenv("ACE355_CFG_FORK")) h->fk.mode = atoi(e);
     if (const char* e = getenv("ACE355_CFG_FORK_MIN_ROWS")) h->fk.min_rows = atoi(e);
     if (const char* e = getenv("ACE355_FORK_DOWN_BIG")) h->fk.down_big = atoi(e);
@@ -1261,7 +1267,8 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     }
     hipStream_t run_s = graph ? h->graph_stream : s;   // the stream the loop is enqueued (or captured) on
     int nchains = 1;
-    if (h->dual.mode && B >= 2 && !taps && h->fk.side) {
+    const int chain_rows = ((B + 1) / 2) * copies * S;   // token rows of the larger chain
+    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || chain_rows <= h->dual.max_rows)) {
         int rc0 = dual_probe_streams(h, run_s);
         if (rc0) return rc0;
         if (h->dual.concurrent) nchains = 2;
@@ -1527,7 +1534,7 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable) {
 }
 
 int ace355_dit_set_dual(ace355_dit* h, int mode) {
-    ACE_CHECK(h && (mode == 0 || mode == 1), "set_dual: mode must be 0 or 1");
+    ACE_CHECK(h && mode >= 0 && mode <= 2, "set_dual: mode must be 0, 1 or 2");
     h->dual.mode = mode;
     h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
     return ACE355_OK;

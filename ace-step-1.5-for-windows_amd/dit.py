@@ -200,10 +200,11 @@ class NativeDit:
         False / 0: off; True / 1: default (calls with >= 1536 token rows); 2: every call the kernels support."""
         native.check(self._lib.ace355_dit_set_norm_fold(self._h, int(enable)), "dit_set_norm_fold")
 
-    def set_dual(self, enable) -> None:
-        """Dual-chain sampler (default on): requests of >= 2 songs run as two half-batch samplers on two hardware queues, every launch
-        planned for half the chip (include/ace355.h ace355_dit_set_dual).  False: one chain, launches planned for the whole chip."""
-        native.check(self._lib.ace355_dit_set_dual(self._h, 1 if enable else 0), "dit_set_dual")
+    def set_dual(self, mode) -> None:
+        """Dual-chain sampler (include/ace355.h ace355_dit_set_dual): requests of >= 2 songs as two half-batch samplers on two hardware
+        queues.  False / 0: one chain; True / 1 (default): two chains for small requests (<= 1536 token rows per chain); 2: whenever the
+        request has >= 2 songs."""
+        native.check(self._lib.ace355_dit_set_dual(self._h, int(mode)), "dit_set_dual")
 
     def dual_count(self) -> int:
         n = C.c_int64()

@@ -458,7 +458,7 @@ def main():
                                f"{G} songs per request over {world} GPU(s)" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
                    "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "batch_rank0": B, "global_batch": G,
                    "parallelism": f"dp{world}", "tiny": bool(args.tiny),
-                   "sampler_chains_per_gpu": 2 if (B >= 2 and os.environ.get("ACE355_DUAL", "1") != "0") else 1},
+                   "sampler_chains_per_gpu": (dit.dual_count() > 0) + 1 if hasattr(dit, "dual_count") else 1},
     }
     if other is not None:
         result[other["scaling"]] = other

@@ -157,13 +157,15 @@ int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
  * enable: 0 off, 1 default (calls with >= 1536 token rows: below that the norm launches are cheaper), 2 every call (tests). */
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 
-/* Dual-chain sampler (on by default; ACE355_DUAL=0 in the environment or mode = 0 here turns it off).  The songs of a request are
- * independent through the whole sampling loop of generate_audio (per-item noise, per-item CFG / APG; base.py:1783-1989), so a call
- * with B >= 2 songs runs as TWO half-batch samplers - songs [0, ceil(B/2)) on the caller's stream, the rest on a side stream that
- * sits on a hardware queue of its own (checked once per caller stream) - with every launch of both planned for half of the chip's
- * CUs.  One chain's memory-bound phases then fall into the other's MFMA phases: 512 -> 473 ms per 8 x 30 s x 27-step request on one
- * MI355X.  Each song's result is what a call with that song's half-batch alone returns.  Captured like any other launch under
- * ace355_dit_set_graph.  dual_count: calls that ran as two chains so far. */
+/* Dual-chain sampler.  The songs of a request are independent through the whole sampling loop of generate_audio (per-item noise,
+ * per-item CFG / APG; base.py:1783-1989), so a call with B >= 2 songs can run as TWO half-batch samplers - songs [0, ceil(B/2)) on the
+ * caller's stream, the rest on a side stream that sits on a hardware queue of its own (checked once per caller stream: the runtime
+ * shares a few queues between all streams, and two streams on one queue run strictly in turn).  mode 0: one chain; 1 (default,
+ * ACE355_DUAL): two chains when both stay in the small-launch regime (<= 1536 token rows each, ACE355_DUAL_MAX_ROWS: 2-4 songs of
+ * 30 s) - there one chain's launches fill the CUs the other leaves idle (2 x 30 s: 207 -> 199 ms per request incl. decode); 2: two
+ * chains whenever B >= 2 (at the metric batch of 8 the pair is no faster than one chain: both sit at the power cap).  Each song's
+ * result is what a one-chain call with that song's half-batch returns.  Captured like any other launch under ace355_dit_set_graph.
+ * dual_count: calls that ran as two chains so far. */
 int ace355_dit_set_dual(ace355_dit* h, int mode);
 int ace355_dit_dual_count(ace355_dit* h, int64_t* calls);
 

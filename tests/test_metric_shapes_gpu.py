@@ -121,10 +121,11 @@ def test_metric_batch_sampler_norm_fold_on_off(gpu_device, golden_dir, full_dit_
 
 def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
     """Dual-chain sampler (include/ace355.h ace355_dit_set_dual; the songs of generate_audio are independent, base.py:1783-1989): the
-    metric batch (G12: 8 songs x 30 s, CFG 7 + APG, 3 steps) as two half-batch samplers on two hardware queues with every launch
-    planned for half the chip.  Contract: (1) the call really ran as two chains; (2) each song's result is BIT-identical to what a
-    one-chain call with that song's half-batch alone returns (songs 0-3 / 4-7), eagerly and as a replayed graph; (3) the result
-    matches the reference golden like the one-chain path does; (4) an odd batch (5 songs: 3 + 2) and a batch of 2 (1 + 1) obey (2)."""
+    metric batch (G12: 8 songs x 30 s, CFG 7 + APG, 3 steps) FORCED to run as two half-batch samplers on two hardware queues (mode 2;
+    the default policy splits requests of 2-4 songs only).  Contract: (1) the call really ran as two chains; (2) each song's result
+    is BIT-identical to what a one-chain call with that song's half-batch alone returns (songs 0-3 / 4-7), eagerly and as a
+    replayed graph; (3) the result matches the reference golden like the one-chain path does; (4) an odd batch (5 songs: 3 + 2) and
+    a batch of 2 (1 + 1; split by the DEFAULT policy) obey (2)."""
     from ace355.dit import generate_latents
     G = np.load(f"{golden_dir}/g12_metric_sampler.npz")
     dit, cfg, null, wsum = full_dit_seed4
@@ -139,10 +140,15 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
         return generate_latents(dit, null, enc.expand(b, -1, -1), ctx1.expand(b, -1, -1).contiguous(), seed=[seeds[i] for i in items],
                                 infer_steps=steps, diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
     try:
-        dit.set_dual(True)
+        dit.set_dual(1)
         n0 = dit.dual_count()
+        d2 = run(range(2))
+        assert dit.dual_count() == n0 + 1, "a 2-song request did not run as two chains (no side stream on a hardware queue of its own?)"
+        run(range(8))
+        assert dit.dual_count() == n0 + 1, "the default policy must keep the metric batch on one chain"
+        dit.set_dual(2)
         dual = run(range(8))
-        assert dit.dual_count() == n0 + 1, "the request did not run as two chains (no side stream on a hardware queue of its own?)"
+        assert dit.dual_count() == n0 + 2
         again = run(range(8))
         assert torch.equal(dual, again)
         dit.set_graph(True)
@@ -152,8 +158,8 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
         finally:
             dit.set_graph(False)
         assert torch.equal(dual, g1) and torch.equal(dual, g2), "graph replay of the two-chain sequence differs"
-        d5, d2 = run(range(5)), run(range(2))
-        dit.set_dual(False)
+        d5 = run(range(5))
+        dit.set_dual(0)
         n1 = dit.dual_count()
         single = run(range(8))
         halves = torch.cat([run(range(0, 4)), run(range(4, 8))], 0)
@@ -161,7 +167,7 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
         s5 = torch.cat([run(range(0, 3)), run(range(3, 5))], 0)
         s2 = torch.cat([run([0]), run([1])], 0)
     finally:
-        dit.set_dual(True)
+        dit.set_dual(1)
     r_d, r_s, r_ds = _rel(dual, ref), _rel(single, ref), _rel(dual, single)
     print(f"dual-chain sampler (B=8, 3 steps): two chains vs reference fp32 {r_d:.3e}, one chain vs reference {r_s:.3e}, two chains vs one {r_ds:.3e}; "
           f"two chains == one-chain calls on the half-batches: {torch.equal(dual, halves)} (B=8), {torch.equal(d5, s5)} (B=5), {torch.equal(d2, s2)} (B=2)")
@@ -212,7 +218,7 @@ def test_cfg_fork_is_bit_identical_to_the_single_stream_order(gpu_device, golden
     finally:
         dit.set_norm_fold(True)
         dit.set_cfg_fork(0)
-        dit.set_dual(True)
+        dit.set_dual(1)
 
 
 def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):

@@ -160,7 +160,6 @@ struct GemmEpilogue {
     // dual-chain sampler (dit.hip) runs two independent launch sequences on two hardware queues and shapes every launch of both for 128
     // CUs, so that the chains run side by side instead of interleaving workgroups over all 256 (round 4: 512 -> 473 ms per 8-song pass)
     int cu_slots;
-    int kg;   // set by launch_gemm: 2 = the intra-workgroup split-K form of the 128x128 tile (gemm_sp_kernel KG)
 };
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);

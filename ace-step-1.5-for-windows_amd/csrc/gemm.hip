@@ -58,7 +58,7 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true, bool ALLOW_PRE = true>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
+template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
 __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
                                                    int wave = 0, int wnw = 1) {
@@ -326,9 +326,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         // waits for those stores to be acknowledged and then for its own round trip: two serial memory latencies per epilogue, and
         // under the ordered split-K the next part waits for all of it (M = 750: 22 k cycles for the pair of parts; ACE355_GEMM_CLK).
         // The 192x256 tile keeps one half in flight (48 more registers there cost more than the round trip, see below).
-        // (ALLOW_PRE false: the two-wave-group form of this tile runs two waves per SIMD - a 256-register budget the 64 prefetch registers
-        //  do not fit: 152 B of scratch)
-        constexpr bool PRE = (MODE == 2 && MT == 2 && NTW == 2 && ALLOW_PRE);
+        constexpr bool PRE = (MODE == 2 && MT == 2 && NTW == 2);
         constexpr int NPJ = PRE ? NTW : 1;
         float4 hvp[NPJ][NT], g1p[NPJ], a2p[NPJ], b2p[NPJ], cvp[NPJ], ngAp[NPJ], ngBp[NPJ];
         if constexpr (PRE) {
@@ -566,7 +564,7 @@ __device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], voi
 }
 
 // smem: the workgroup's LDS (dead after the K loop; every wave stages MT*32 rows x 128 B in its own slice of it).
-template <int MODE, int MT, int NTW = 2, bool FOLD = true, bool ALLOW_PRE = true>
+template <int MODE, int MT, int NTW = 2, bool FOLD = true>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem, void* __restrict__ Cv, int ldc, int M, int N,
                                               const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int wave, int lane,
                                               int bm = MT * 64, int bn = 128) {
@@ -577,8 +575,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem
         char* stg = smem + wave * (MT * 32 * 128);
         float* xw = reinterpret_cast<float*>(smem + (bn / (NTW * 32)) * (bm / (MT * 32)) * (MT * 32 * 128));  // behind the last staging slice
         const int wnw = bn / (NTW * 32);
-        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD, ALLOW_PRE>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
-        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD, ALLOW_PRE>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
+        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
     } else {
         gemm_epilogue_scalar<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
     }
@@ -738,18 +736,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 // those two 16-byte slots; tools/probe/mx_probe.py established the layout).  Scales ride as one extra 1 KB DMA piece per operand per
 // K step (waves 0 / 1) behind the tiles: word [row] = the four E8M0 bytes of this K step; the upper lane half shifts its word by 8
 // so that op_sel 0 / 2 picks block (0 | 1) / (2 | 3).
-// KG = 2 (round 4; small-M launches, one workgroup per CU or fewer): INTRA-WORKGROUP split-K.  The workgroup carries two wave groups of
-// 2 * WNW waves; group g runs the whole pipeline above on its own LDS stages over K steps [g * nk, (g + 1) * nk) of the workgroup's K
-// range, so every SIMD has two waves with independent DMA rings and MFMA chains (a lone 128x128 workgroup's K loop is latency bound: 750
-// cycles per K step against 512 of MFMA issue, more with cold operands).  After the loop group 1 parks its accumulators in its own
-// (now dead) stage area, group 0 adds them - an LDS exchange of 64 KB instead of the L2 round trip of the slab / ordered split-K - and
-// runs the epilogue alone; group 1's waves have ended by then (s_barrier counts only surviving waves).  Both groups execute the same
-// number of barriers: launch_gemm only picks this form when the K steps divide evenly.
-template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0, int NS = 2, int FP8 = 0, int KG = 1>
-__global__ __launch_bounds__(WNW * 128 * KG, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A0, int lda, const bf16_t* __restrict__ W0,
+// Round 4, built / measured / removed (git history: "Intra-workgroup split-K"): KG = 2, two wave groups per workgroup, each running this
+// pipeline on its own two LDS stages over half of the workgroup's K range, accumulators exchanged through LDS at the end (64 KB, no L2
+// round trip) - meant for the small-M launches, where a 128x128 workgroup is alone on its CU with one wave per SIMD.  Correct (100 GPU
+// tests), no scratch once the residual epilogue's prefetch registers were dropped for it, and much slower: 181.8 vs 147.4 ms per batch-1
+// request (configs[0]: 64.1 vs 48.3 ms).  The K loop of those launches is bound by what ONE CU can pull through the L2 -> LDS DMA path
+// (32 KB per K step at ~70 GB/s = 0.46 us, the in-pass figure of DESIGN.md section 10), not by MFMA issue: a second wave group adds no
+// ingest bandwidth, and the two-stage rings it leaves room for (2 x 2 x 32 KB) hide less latency than this kernel's four stages.
+template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0, int NS = 2, int FP8 = 0>
+__global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A0, int lda, const bf16_t* __restrict__ W0,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
                                                           GemmEpilogue ep, int tiles_n, int nwg, int group_m, int xcd_m) {
-    static_assert(KG == 1 || (KG == 2 && !PERS && !FP8), "intra-workgroup split-K: two wave groups, one tile per workgroup, bf16");
     constexpr int BMv = MT * 64;
     constexpr int A_BYTES = BMv * 128;
     constexpr int BNv = WNW * NTW * 32;
@@ -763,9 +760,7 @@ __global__ __launch_bounds__(WNW * 128 * KG, 2) void gemm_sp_kernel(const bf16_t
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
     constexpr int EPI_BYTES = NW * MT * 32 * 128 + NW * MT * 32 * 4;  // epilogue staging: MT*32 rows x 128 B per wave (+ mode 4's row sums)
-    constexpr int PARK_BYTES = KG > 1 ? NW * 64 * MT * NTW * 64 : 0;  // group 1's accumulators: 16 floats x MT x NTW per thread
-    static_assert(KG == 1 || (EPI_BYTES <= NS * STAGE && PARK_BYTES <= NS * STAGE), "the park area is group 1's stage area, beyond group 0's staging image");
-    __shared__ __attribute__((aligned(16))) char smem_all[KG * NS * STAGE > EPI_BYTES ? KG * NS * STAGE : EPI_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES];
 
     // Workgroup -> tile map.  Block b runs on XCD b % 8 (observed, speed only).  The 8 XCDs (private L2s) form an
     // xcd_m x xcd_n grid of rectangular tile regions, chosen per GEMM to minimise the bytes each L2 must pull from
@@ -792,10 +787,7 @@ __global__ __launch_bounds__(WNW * 128 * KG, 2) void gemm_sp_kernel(const bf16_t
     }
     const int m0 = tm * BMv, n0 = tn * BNv;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = KG > 1 ? wave_all / NW : 0;            // K group of this wave
-    const int wave = KG > 1 ? wave_all - kg * NW : wave_all;   // wave inside its group: everything below is per group
-    char* const smem = smem_all + kg * (NS * STAGE);      // this group's stages (group 0's double as the epilogue staging image)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
 
     const int lrow = lane >> 3, pslot = lane & 7;
@@ -817,11 +809,10 @@ __global__ __launch_bounds__(WNW * 128 * KG, 2) void gemm_sp_kernel(const bf16_t
 
     // split-K (ep.kparts > 1): blockIdx.y owns K steps [kt0, kt0 + nk)
     const int nk_all = K / BK;
-    const int kparts_all = ep.kparts * KG;   // K parts over (blockIdx.y, wave group)
-    const int kchunk = (nk_all + kparts_all - 1) / kparts_all;
-    const int kt0 = (kparts_all > 1) ? ((int)blockIdx.y * KG + kg) * kchunk : 0;
-    const int nk = (kparts_all > 1) ? min(kchunk, nk_all - kt0) : nk_all;
-    if (nk <= 0) return;   // (KG > 1: launch_gemm guarantees equal, non-empty K ranges for both groups)
+    const int kchunk = (nk_all + ep.kparts - 1) / ep.kparts;
+    const int kt0 = (ep.kparts > 1) ? (int)blockIdx.y * kchunk : 0;
+    const int nk = (ep.kparts > 1) ? min(kchunk, nk_all - kt0) : nk_all;
+    if (nk <= 0) return;
     const bf16_t* A = A0 + kt0 * BK;
     const bf16_t* W = W0 + kt0 * BK;
     const int frow = lane & 31, fhalf = lane >> 5;
@@ -1052,36 +1043,6 @@ __global__ __launch_bounds__(WNW * 128 * KG, 2) void gemm_sp_kernel(const bf16_t
         }
         unsigned long long e0 = 0;
         if (probe) e0 = clock64();
-        if constexpr (KG > 1) {
-            // intra-workgroup split-K: group 1 parks, group 0 adds (per-thread layout [vector][thread]: conflict-free 16-byte accesses)
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();   // every wave of both groups is done with its fragment reads
-            float4* park = reinterpret_cast<float4*>(smem_all + NS * STAGE) + (tid & (NW * 64 - 1));
-            if (kg == 1) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            float4 v;
-                            v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
-                            park[((i * NTW + j) * 4 + q) * (NW * 64)] = v;
-                        }
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();
-            if (kg == 1) return;
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 w = park[((i * NTW + j) * 4 + q) * (NW * 64)];
-                        acc[i][j][4 * q + 0] += w.x; acc[i][j][4 * q + 1] += w.y; acc[i][j][4 * q + 2] += w.z; acc[i][j][4 * q + 3] += w.w;
-                    }
-        }
         if constexpr (!PERS && !FP8) {
             if (ep.sk_slab) {   // slab split-K (workgroup-uniform): see GemmEpilogue::sk_slab
                 constexpr int NTH = NW * 64, VEC = MT * NTW * 4;   // float4 vectors per lane
@@ -1147,7 +1108,7 @@ __global__ __launch_bounds__(WNW * 128 * KG, 2) void gemm_sp_kernel(const bf16_t
                 asm volatile("" ::: "memory");
             }
         }
-        gemm_epilogue<MODE, MT, NTW, !FP8, KG == 1>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+        gemm_epilogue<MODE, MT, NTW, !FP8>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's H rows are in L2
@@ -1283,8 +1244,6 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
     const int cus = gemm_cu_slots(ep.cu_slots), pers_x = cus / 8;   // persistent workgroups per XCD
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= cus;
-    // intra-workgroup split-K (KG = 2) for the 128x128 four-wave tile when every workgroup is alone on its CU: launch_gemm decided (ep.kg)
-    const bool kg2 = ep.kg == 2 && deep && mt != 3 && big == 0;
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
         if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
@@ -1293,7 +1252,6 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
         } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
-        else if (kg2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 2, 0, 2>), 512);
         else if (deep && mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 2, 0, 3>), 256);
         else if (deep) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 4>), 256);
         else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
@@ -1310,7 +1268,6 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
     } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
-    else if (kg2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 2, 0, 2>), 512);           // two wave groups x 2 x 32 KB stages
     else if (deep && mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 2, 0, 3>), 256);   // 3 x 40 KB stages
     else if (deep) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 4>), 256);              // 4 x 32 KB stages
     else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
@@ -1399,17 +1356,9 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     // accumulation already).  With turn counters from the caller (ep.sk_cnt) the parts add in part order with plain read-modify-writes
     // - bit-reproducible, and two serialised 4 us updates cost less than 16 k fp32 atomics per part (12 us); without counters the
     // parts use fp32 atomics and the last bits depend on the arrival order.  ACE355_GEMM_KSPLIT=1 disables the split.
-    // Intra-workgroup split-K (gemm_sp_kernel KG = 2): the 128x128 tile of a launch whose workgroups are each alone on a CU, K steps
-    // dividing evenly over the parts.  ACE355_GEMM_KG: 0 off, 1 on beside the ordered blockIdx.y split of the residual GEMMs,
-    // 2 (default) on and INSTEAD of that split (one read-modify-write of H per tile, no turn counters).
-    static int kg_env = -1;
-    if (kg_env < 0) kg_env = env_int("ACE355_GEMM_KG", 2);
-    ep.kg = 1;
-    const bool kg_tile = variant != 1 && big == 0 && mt == 2 && kg_env > 0 && !ep.sk_slab && (long)nwg <= gemm_cu_slots(ep.cu_slots);
-    if (kg_tile && kg_env >= 2 && (K / BK) % 2 == 0 && (K / BK) >= 4) ep.kg = 2;
     ep.ksplit = 1;
     ep.sk_ord = 0;
-    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && !ep.sk_slab && ep.kg == 1) {
+    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && !ep.sk_slab) {
         static int ks_env = -1;
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
         const int nk = K / BK;
@@ -1427,10 +1376,6 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         ep.ksplit = ks;
         ep.kparts = ks;
         ep.sk_ord = (ord && ks > 1) ? 1 : 0;
-    }
-    if (kg_tile && kg_env == 1) {   // beside whatever blockIdx.y split was chosen: the K steps must divide over all parts, the launch stay one-per-CU
-        const int parts = (ep.kparts > 1 ? ep.kparts : 1) * 2;
-        if ((K / BK) % parts == 0 && (K / BK) / parts >= 2 && (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= gemm_cu_slots(ep.cu_slots)) ep.kg = 2;
     }
     if ((ep.nf_xg || ep.nc_rowsq) && ep.ksplit > 1 && !ep.sk_ord) {
         // a folded-norm producer needs the FINISHED h in one part's hands: with the ordered turns that is the last part, with fp32 atomics
@@ -1552,7 +1497,6 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
     ep.kparts = 1;
     ep.sk_slab = nullptr;
     ep.sk_ord = 0;
-    ep.kg = 1;
     ep.vt_out = nullptr;
     if (ep.vt_done) *ep.vt_done = 0;
     ep.mx_sa = sa; ep.mx_sw = sw; ep.mx_sa_ld = sa_ld; ep.mx_sw_ld = sw_ld;

@@ -149,10 +149,12 @@ struct ace355_dit {
     // CONTEXT: a second ace355_dit that aliases this handle's weights and condition slots and owns its workspace and schedule tables.
     struct Dual {
         int mode = 1;                 // ACE355_DUAL / ace355_dit_set_dual: 0 one chain; 1 (default) two chains for requests of >= 2 songs whose
-                                      // chains stay in the small-launch regime (<= max_rows token rows each); 2 two chains whenever >= 2 songs
-        int max_rows = 1536;          // ACE355_DUAL_MAX_ROWS.  Measured (same-box ABAB, 30 s songs, DiT + decode): 2 songs 207.1 -> 199.1 ms,
-                                      // 4 songs 300.3 -> 296.7 ms, 8 songs 507.7 -> 513-528 ms: where the launches fill the chip the GEMMs sit
-                                      // at the power cap and two chains only share it
+                                      // one-chain launches would under-fill the chip (<= max_rows token rows in all); 2 two chains whenever >= 2 songs
+        int max_rows = 2400;          // ACE355_DUAL_MAX_ROWS (token rows of the whole request, CFG copies included).  Measured (same-box ABAB x 2-3,
+                                      // 30 s songs, DiT + decode, ms per request, one chain -> two): 2 songs (1500 rows) 201.2 -> 197.5 (and 207.1 ->
+                                      // 199.1, 209.8 -> 201.0 on other boxes), 3 songs (2250 rows: 12 row tiles, an awkward fill) 275.9 -> 253.3,
+                                      // 4 songs (3000 rows) 300.1 -> 315.4, 8 songs 507.7 -> 513-528: where one chain's launches fill the chip
+                                      // the GEMMs sit at the power cap and two chains only share it
         int slots_min_rows = 1 << 30; // ACE355_DUAL_SLOTS_MIN_ROWS: chains with at least this many token rows plan their launches for half the
                                       // chip (cu_slots 128).  Off by default: 473 ms against 479 without it for two 4-song chains (DiT only),
                                       // but slower for small chains (2 songs: 226 vs 199 ms)
@@ -1267,8 +1269,7 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     }
     hipStream_t run_s = graph ? h->graph_stream : s;   // the stream the loop is enqueued (or captured) on
     int nchains = 1;
-    const int chain_rows = ((B + 1) / 2) * copies * S;   // token rows of the larger chain
-    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || chain_rows <= h->dual.max_rows)) {
+    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || N * S <= h->dual.max_rows)) {
         int rc0 = dual_probe_streams(h, run_s);
         if (rc0) return rc0;
         if (h->dual.concurrent) nchains = 2;
@@ -1282,6 +1283,11 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     }
     const int Bc[2] = {B0, B1}, b0[2] = {0, B0};
     h->fork_blocked = nchains == 2;
+    if (nchains == 1 && h->fk.mode > 0 && h->fk.side && do_cfg) {   // the per-layer CFG fork needs the same guarantee: a side stream on its own queue
+        int rc0 = dual_probe_streams(h, run_s);
+        if (rc0) return rc0;
+        h->fork_blocked = !h->dual.concurrent;
+    }
     int rc;
     for (int k = 0; k < nchains; ++k) {
         ace355_dit* c = ctxs[k];

@@ -202,8 +202,8 @@ class NativeDit:
 
     def set_dual(self, mode) -> None:
         """Dual-chain sampler (include/ace355.h ace355_dit_set_dual): requests of >= 2 songs as two half-batch samplers on two hardware
-        queues.  False / 0: one chain; True / 1 (default): two chains for small requests (<= 1536 token rows per chain); 2: whenever the
-        request has >= 2 songs."""
+        queues.  False / 0: one chain; True / 1 (default): two chains for small requests (<= 2400 token rows in all: 2-3 songs of 30 s); 2: whenever
+        the request has >= 2 songs."""
         native.check(self._lib.ace355_dit_set_dual(self._h, int(mode)), "dit_set_dual")
 
     def dual_count(self) -> int:

@@ -161,9 +161,10 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
  * per-item CFG / APG; base.py:1783-1989), so a call with B >= 2 songs can run as TWO half-batch samplers - songs [0, ceil(B/2)) on the
  * caller's stream, the rest on a side stream that sits on a hardware queue of its own (checked once per caller stream: the runtime
  * shares a few queues between all streams, and two streams on one queue run strictly in turn).  mode 0: one chain; 1 (default,
- * ACE355_DUAL): two chains when both stay in the small-launch regime (<= 1536 token rows each, ACE355_DUAL_MAX_ROWS: 2-4 songs of
- * 30 s) - there one chain's launches fill the CUs the other leaves idle (2 x 30 s: 207 -> 199 ms per request incl. decode); 2: two
- * chains whenever B >= 2 (at the metric batch of 8 the pair is no faster than one chain: both sit at the power cap).  Each song's
+ * ACE355_DUAL): two chains when one chain's launches would under-fill the chip (<= 2400 token rows in the whole request,
+ * ACE355_DUAL_MAX_ROWS: 2-3 songs of 30 s under CFG) - there one chain's launches fill the CUs the other leaves idle (2 x 30 s:
+ * 201 -> 197 ms per request incl. decode, 3 x 30 s: 276 -> 253 ms); 2: two chains whenever B >= 2 (4 songs: 300 -> 315 ms, the
+ * metric batch of 8: 508 -> 513-528 ms: both chains sit at the power cap).  Each song's
  * result is what a one-chain call with that song's half-batch returns.  Captured like any other launch under ace355_dit_set_graph.
  * dual_count: calls that ran as two chains so far. */
 int ace355_dit_set_dual(ace355_dit* h, int mode);

@@ -159,8 +159,8 @@ struct ace355_dit {
                                       // chip (cu_slots 128).  Off by default: 473 ms against 479 without it for two 4-song chains (DiT only),
                                       // but slower for small chains (2 songs: 226 vs 199 ms)
         ace355_dit* ctx = nullptr;    // chain 2's context (created on first use)
-        hipStream_t probed_main = nullptr;   // the caller stream the side stream was last checked against
-        bool probed = false, concurrent = false;
+        std::vector<std::pair<hipStream_t, bool>> probed;   // caller streams the side stream was checked against -> on a queue of its own?
+        bool concurrent = false;      // the answer for the current call's stream
         long calls = 0;               // sampler calls that ran as two chains (tests)
     } dual;
     bool fork_blocked = false;   // the current call runs as two chains: the side stream is chain 2's, no per-layer CFG fork on it
@@ -928,9 +928,8 @@ void chain_ctx_destroy(ace355_dit* c) {
 // between two events: ~60 us side by side, ~120 us in series.  A serialised side stream is replaced by a fresh one (up to 6 tries).
 // Once per caller stream; synchronises it.  Not under capture.
 int dual_probe_streams(ace355_dit* h, hipStream_t s) {
-    if (h->dual.probed && h->dual.probed_main == s) return 0;
-    h->dual.probed = true;
-    h->dual.probed_main = s;
+    for (const auto& pr : h->dual.probed)
+        if (pr.first == s) { h->dual.concurrent = pr.second; return 0; }
     h->dual.concurrent = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ACE_HIP(hipEventCreate(&e0));
@@ -956,11 +955,16 @@ int dual_probe_streams(ace355_dit* h, hipStream_t s) {
         if (best < 0.095f) { h->dual.concurrent = true; break; }
         losers.push_back(h->fk.side);   // (kept alive until a winner is found: a destroyed stream's queue slot would be handed out again)
         h->fk.side = nullptr;
+        h->dual.probed.clear();         // (answers about the old side stream)
         if (hipStreamCreateWithFlags(&h->fk.side, hipStreamNonBlocking) != hipSuccess) { h->fk.side = losers.back(); losers.pop_back(); break; }
     }
     for (hipStream_t l : losers) hipStreamDestroy(l);
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    if (!rc) {
+        if (h->dual.probed.size() >= 16) h->dual.probed.erase(h->dual.probed.begin());
+        h->dual.probed.push_back({s, h->dual.concurrent});
+    }
     if (!h->dual.concurrent && !rc) {
         static bool said = false;
         if (!said) fprintf(stderr, "[ace355] no side stream on a hardware queue of its own for this caller stream: the sampler runs as one chain\n");

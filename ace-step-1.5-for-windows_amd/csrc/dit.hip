@@ -521,13 +521,8 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     int rc;
     GemmEpilogue ep{};
 
-    int L = -1;
-    for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < N; ++i)
         ACE_CHECK(slots[i] >= 0 && slots[i] < ACE355_MAX_SLOTS && h->slots[slots[i]].valid, "forward: condition slot not set");
-        if (L < 0) L = h->slots[slots[i]].L;
-        ACE_CHECK(h->slots[slots[i]].L == L, "forward: all condition slots of one call must share L");
-    }
-    const int Lpad = ((L + 63) / 64) * 64;
     // trailing sequences that attend a broadcast slot (the CFG null branch) skip cross-attention entirely: their
     // residual term is the slot's per-layer constant, folded into the self-attention epilogue below.
     int n_sc = 0;
@@ -535,6 +530,15 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     for (int i = N - n_sc; i < N; ++i)
         if (slots[i] != slots[N - 1]) { n_sc = 0; break; }  // one constant per call
     const int Nc = N - n_sc, Mc = Nc * S;
+    // the sequences that DO run cross-attention share one key count; the broadcast slot of the shortcut has no say (L identical keys give
+    // the same constant for every L: the null slot built for the cover conditions' length serves the non-cover phase of another length,
+    // as null_condition_emb.expand_as(...) does for either, base.py:1907 / :1919)
+    int L = -1;
+    for (int i = 0; i < (Nc > 0 ? Nc : N); ++i) {
+        if (L < 0) L = h->slots[slots[i]].L;
+        ACE_CHECK(h->slots[slots[i]].L == L, "forward: the condition slots that run cross-attention in one call must share L");
+    }
+    const int Lpad = ((L + 63) / 64) * 64;
     const float* cconst = n_sc ? h->slots[slots[N - 1]].cross_const : nullptr;
 
     if (h->vt_key_N != N || h->vt_key_S != S) {   // V^T layout [N][KVH][128][Sp] changed: pad positions [S, Sp) must read as zero

@@ -311,8 +311,8 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
     if cover_steps < steps:
         if enc_nc is None or context_latents_non_cover is None:
             raise ValueError("audio_cover_strength < 1 needs the non-cover conditions")
-        if enc_nc.shape[1] != enc.shape[1]:
-            raise NotImplementedError("ace355: cover / non-cover conditions must share the encoder length")
+        # (cover and non-cover conditions may have different encoder lengths, as in the reference, base.py:1916-1927: each phase's
+        #  forwards see one length, and the CFG null slot is the same constant whatever length it was expanded to)
         rows_n, idx_n = distinct(enc_nc)
     n_slots = n_c + 1 + len(rows_n)   # (the null slot keeps its place in the layout with CFG off)
     if n_slots > native.MAX_SLOTS:    # checked BEFORE any cross-K/V build, for every path

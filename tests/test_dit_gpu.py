@@ -393,6 +393,33 @@ def test_full_size_properties_batch_invariance_and_determinism(gpu_device):
     assert _rel(a[0:1], a[1:2]) > 0.5
 
 
+def test_cover_switch_with_conditions_of_different_lengths_vs_oracle(gpu_device):
+    """Cover switch (base.py:1916-1927) where the cover and the non-cover conditions have DIFFERENT encoder lengths (the reference
+    expands null_condition_emb to either, :1907 / :1919): until round 4 the native host refused this request and the seam fell back
+    to PyTorch.  The CFG null slot is a constant whatever length it was built for, so each phase only needs its
+    own conditional slots to agree.  Tiny configuration against the oracle's sampler (pinned by G3 `cover`), CFG 4, per-item rows."""
+    from ace355 import weightgen
+    from ace355.dit import generate_latents
+    from oracle import dit as o_dit
+    from oracle import sampler as o_sampler
+    cfg, w, dit = _make(TINY, 5, gpu_device)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=5)
+    g = torch.Generator().manual_seed(77)
+    B, T, L1, L2 = 2, 40, 19, 33
+    enc = torch.randn(B, L1, cfg.hidden_size, generator=g)
+    enc_nc = torch.randn(B, L2, cfg.hidden_size, generator=g)
+    ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1)
+    ctx_nc = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.zeros(B, T, 64)], -1)
+    src = 0.5 * torch.randn(B, T, 64, generator=g)
+    kw = dict(seed=[11, 12], infer_steps=8, diffusion_guidance_sale=4.0, shift=2.0, audio_cover_strength=0.5, cover_noise_strength=0.3,
+              src_latents=src, encoder_hidden_states_non_cover=enc_nc, context_latents_non_cover=ctx_nc)
+    out = generate_latents(dit, null, enc, ctx, **kw)["target_latents"].cpu()
+    ref = o_sampler.generate_audio(o_dit.DitConfig(**TINY), w, null, enc, ctx, **kw)
+    r = _rel(out, ref)
+    print(f"cover switch, encoder lengths {L1} -> {L2}: rel L2 vs the oracle = {r:.3e}")
+    assert torch.isfinite(out).all() and r < 4e-3, r
+
+
 @pytest.mark.parametrize("name", ["shift3", "explicit", "cover", "sde_shift3"])
 def test_turbo_sampler_vs_reference_golden(gpu_device, golden_dir, name):
     """Turbo model family: 8-step tables, no CFG (models/turbo/modeling_acestep_v15_turbo.py:1780-1995) vs vectors captured from

@@ -66,6 +66,26 @@ __global__ void snake_prep_kernel(const float* __restrict__ alpha, const float* 
     ea[i] = expf(alpha[i]);
     ib[i] = 1.0f / (expf(beta[i]) + 1e-9f);
 }
+// Box probe: every wave issues `iters` x 4 independent v_mfma_f32_32x32x16_bf16 on random bf16 operands, no memory traffic - the
+// matrix-pipe ceiling of THIS board under its power cap (tools/probe/mfma_clock_probe.hip is the stand-alone form).
+__global__ __launch_bounds__(512) void mfma_probe_kernel(float* sink, int iters) {
+    unsigned s0 = 1u + 1103515245u * (unsigned)(blockIdx.x * blockDim.x + threadIdx.x + 1);
+    union { unsigned u[4]; bf16x8 v; } a, b;
+    for (int i = 0; i < 4; ++i) {   // sign + 7 mantissa bits random, exponent around 1.0
+        a.u[i] = ((s0 * (2654435761u + i)) & 0x807f807fu) | 0x3f003f00u;
+        b.u[i] = ((s0 * (40503u + 7 * i) + i) & 0x807f807fu) | 0x3f003f00u;
+    }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c3, 0, 0, 0);
+    }
+    float acc = 0.f;
+    for (int r = 0; r < 16; ++r) acc += c0[r] + c1[r] + c2[r] + c3[r];
+    if (acc == 12345.678f) sink[0] = acc;
+}
 }  // namespace
 
 }  // namespace ace355
@@ -76,6 +96,33 @@ extern "C" {
 
 const char* ace355_last_error(void) { return g_err.c_str(); }
 int ace355_version(void) { return 100; }
+
+int ace355_box_probe_mfma(int iters, double* tflops_out) {
+    ACE_CHECK(tflops_out && iters > 0 && iters <= (1 << 22), "box_probe_mfma: bad argument");
+    float* sink = nullptr;
+    ACE_HIP(hipMalloc((void**)&sink, 64));
+    hipDeviceProp_t prop;
+    int dev = 0;
+    ACE_HIP(hipGetDevice(&dev));
+    ACE_HIP(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ACE_HIP(hipEventCreate(&e0));
+    ACE_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, nullptr, sink, 2000);   // warm-up (clocks ramp)
+    hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(512), 0, nullptr, sink, iters);
+    hipEventRecord(e1, nullptr);
+    const hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(sink);
+    if (e != hipSuccess) return hip_fail(e, "box_probe_mfma", __FILE__, __LINE__);
+    *tflops_out = ms > 0.f ? (double)cus * 8.0 * 4.0 * iters * 32768.0 / (ms * 1e-3) / 1e12 : 0.0;
+    return ACE355_OK;
+}
 
 int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream) {
     ACE_CHECK(wav_dev && B > 0 && B <= 256 && per_item > 0, "peak_normalize: bad argument");

@@ -82,6 +82,7 @@ SIGNATURES = {
     "ace355_dit_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_norm_fold": (C.c_int, [C.c_void_p, C.c_int]),
+    "ace355_box_probe_mfma": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "ace355_dit_set_dual": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_dual_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ace355_dit_set_cfg_fork": (C.c_int, [C.c_void_p, C.c_int]),

@@ -568,6 +568,21 @@ def main():
         except Exception as e:  # no rocm-smi, no permission, ...: the line is complete without it
             result["gpu_state_under_load"] = {"error": str(e)[:120]}
 
+    if rank == 0 and not args.no_roofline:
+        # what THIS board's matrix pipe does on a pure MFMA loop with random bf16 operands (no memory traffic), right after the passes:
+        # the same binary measures 493-549 ms per pass over the boxes of the pool (DVFS under one power cap), and a line is only
+        # comparable with another box's beside this number (nominal dense peak 2500; round 2's reference box: 1964)
+        try:
+            import ctypes as C
+            from ace355 import native
+            tf = C.c_double()
+            torch.cuda.synchronize()
+            native.check(native.lib().ace355_box_probe_mfma(150000, C.byref(tf)), "box_probe_mfma")
+            result["box_probe"] = {"mfma_random_bf16_tflops": tf.value, "what": "pure v_mfma_f32_32x32x16_bf16 loop, random operands, 8 waves per CU, "
+                                   "no memory traffic (ace355_box_probe_mfma)", "gemm_achieved_over_probe": result["roofline"]["achieved"] / tf.value if tf.value else None}
+        except Exception as e:
+            result["box_probe"] = {"error": str(e)[:160]}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # reported at N=1 only
         result["cpu_baseline"] = cpu_baseline(args, dcfg, vcfg, sd, vsd, enc.cpu(), null.cpu(), ctx_shared.cpu()[None], T, L)
 

@@ -44,6 +44,10 @@ extern "C" {
 
 const char* ace355_last_error(void);
 int ace355_version(void);
+/* Measurement aid (bench.py `box_probe`; no reference counterpart): dense bf16 MFMA rate of THIS board on a pure
+ * v_mfma_f32_32x32x16_bf16 loop with random operands, 8 waves per CU, no memory traffic (TFLOP/s; the boxes of the pool differ by a
+ * few percent under the same power cap, and a bench line is only comparable across boxes beside this number).  Synchronises the device. */
+int ace355_box_probe_mfma(int iters, double* tflops_out);
 
 /* ------------------------------------------------------------------------------------------
  * DiT decoder (AceStepDiTModel, base.py:1240-1507) + sampler (generate_audio, base.py:1783-1989)

@@ -140,6 +140,7 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
         return generate_latents(dit, null, enc.expand(b, -1, -1), ctx1.expand(b, -1, -1).contiguous(), seed=[seeds[i] for i in items],
                                 infer_steps=steps, diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
     try:
+        dit.set_cfg_fork(0)   # (the one-chain comparison calls must not fork per layer: chains never do)
         dit.set_dual(1)
         n0 = dit.dual_count()
         d2 = run(range(2))

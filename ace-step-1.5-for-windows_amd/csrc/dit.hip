@@ -935,6 +935,11 @@ int dual_probe_streams(ace355_dit* h, hipStream_t s) {
     for (const auto& pr : h->dual.probed)
         if (pr.first == s) { h->dual.concurrent = pr.second; return 0; }
     h->dual.concurrent = false;
+    {   // a caller that is capturing `s` into a graph of its own cannot be synchronised: unknown stream = one chain for this call
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (cap != hipStreamCaptureStatusNone) return 0;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ACE_HIP(hipEventCreate(&e0));
     ACE_HIP(hipEventCreate(&e1));
@@ -1364,6 +1369,7 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         if (p->ctx_non_cover_dev) pg.ctx_non_cover_dev = h->g_ctx_nc;
         if (p->sde_noise_dev) pg.sde_noise_dev = h->g_sde;
     }
+    // (per_step_ms_host, when asked for, times chain 1's steps on the caller's stream: the chains advance side by side, step for step)
     SamplerChain chains[2];
     for (int k = 0; k < nchains; ++k) {
         SamplerChain& c = chains[k];

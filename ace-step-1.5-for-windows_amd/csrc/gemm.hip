@@ -326,6 +326,10 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         // waits for those stores to be acknowledged and then for its own round trip: two serial memory latencies per epilogue, and
         // under the ordered split-K the next part waits for all of it (M = 750: 22 k cycles for the pair of parts; ACE355_GEMM_CLK).
         // The 192x256 tile keeps one half in flight (48 more registers there cost more than the round trip, see below).
+        // (Round 4, measured and removed: the big tiles requesting half 1's old H rows as soon as half 0's accumulators are staged, i.e.
+        //  ahead of half 0's stores.  100 B of scratch - the per-column vectors spill - and the in-pass probe of this epilogue at M = 6000
+        //  went from 42.3 k to 51.7 k cycles, the pass from 515.8 to 523.5 ms (ABAB).  The burst is bandwidth bound as it is: 122 MB per
+        //  launch in 23.7 us = 5.1 TB/s, beside 5.4 TB/s for the pure-store burst of the patchify GEMM; profiles/r04_gemm_clk_inpass.txt.)
         constexpr bool PRE = (MODE == 2 && MT == 2 && NTW == 2);
         constexpr int NPJ = PRE ? NTW : 1;
         float4 hvp[NPJ][NT], g1p[NPJ], a2p[NPJ], b2p[NPJ], cvp[NPJ], ngAp[NPJ], ngBp[NPJ];

@@ -1282,7 +1282,9 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     }
     hipStream_t run_s = graph ? h->graph_stream : s;   // the stream the loop is enqueued (or captured) on
     int nchains = 1;
-    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || N * S <= h->dual.max_rows)) {
+    // (under graph replay the two chains become two branches of one graph, which the runtime places on streams of its own choosing:
+    //  measured 281 ms against 214 ms for the one-chain graph at 2 songs - the default policy keeps a captured call on one chain)
+    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || (N * S <= h->dual.max_rows && !graph))) {
         int rc0 = dual_probe_streams(h, run_s);
         if (rc0) return rc0;
         if (h->dual.concurrent) nchains = 2;

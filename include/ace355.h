@@ -148,7 +148,9 @@ int ace355_dit_set_precision(ace355_dit* h, int precision);
 
 /* hipGraph replay of the sampling loop: with enable != 0, ace355_dit_sample captures its launch
  * sequence (steps x ~360 kernels) into a graph on first use and replays it for every later call with the same shapes, schedule,
- * knobs, slot layout and stream; any change re-captures.  Results are identical to the eager path (same kernels, same order).
+ * knobs, slot layout and stream; any change re-captures.  Results are identical to the eager path of the same chain configuration (same
+ * kernels, same order; by default a captured call runs as ONE sampler chain - two chains become two graph branches that the runtime
+ * places on streams of its own choosing, measured slower - while an eager request of 2-3 songs runs as two: ace355_dit_set_dual).
  * Off by default; ACE355_SAMPLE_GRAPH=1 in the environment turns it on at handle creation.  graph_stats: captures / replays so far. */
 int ace355_dit_set_graph(ace355_dit* h, int enable);
 int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);

@@ -586,13 +586,16 @@ def test_torch_library_ops_match_direct_calls(gpu_device):
     ops.release_handle(kv)
 
 
-def test_hipgraph_replay_of_the_sampler_equals_eager(gpu_device):
+@pytest.mark.parametrize("dual", [0, 2])
+def test_hipgraph_replay_of_the_sampler_equals_eager(gpu_device, dual):
     """ace355_dit_set_graph: the sampler's launch sequence captured once and replayed - same kernels in the same order, so the
-    latents are bit-identical to the eager path; a changed knob or shape re-captures; conditions may be re-uploaded between
-    replays (slot memory is reused in place)."""
+    latents are bit-identical to the eager path OF THE SAME CHAIN CONFIGURATION (one chain, or two chains forced: by default a
+    captured call stays on one chain while an eager small request takes two, round 4); a changed knob or shape re-captures;
+    conditions may be re-uploaded between replays (slot memory is reused in place)."""
     from ace355 import weightgen
     from ace355.dit import prepare_noise, schedule
     cfg, w, dit = _make(TINY, 9, gpu_device)
+    dit.set_dual(dual)
     g = torch.Generator().manual_seed(3)
     B, T, L = 3, 54, 21
     enc = torch.randn(L, cfg.hidden_size, generator=g)

@@ -25,10 +25,12 @@ __device__ __forceinline__ void operands(bf16x8* a, bf16x8* b, int n) {
 // MODE 1: 16x16x32, 8 independent accumulator tiles (the same 32 K flop per 32 cycles per pair of instructions), one operand pair
 // MODE 2 / 3: the same with 4 distinct operand pairs cycling (closer to a GEMM's register traffic)
 template <int MODE>
-__global__ __launch_bounds__(512) void probe(float* sink, int iters) {
+__global__ __launch_bounds__(512) void probe(float* sink, int iters, unsigned long long* clk) {
     bf16x8 a[4], b[4];
     operands(a, b, 4);
     float acc = 0.f;
+    __syncthreads();
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
     if constexpr (MODE == 0 || MODE == 2) {
         f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
         for (int it = 0; it < iters; ++it) {
@@ -48,20 +50,26 @@ __global__ __launch_bounds__(512) void probe(float* sink, int iters) {
         }
         for (int k = 0; k < 8; ++k) for (int r = 0; r < 4; ++r) acc += c[k][r];
     }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
     if (acc == 12345.678f) sink[0] = acc;
+    if (blockIdx.x == 7 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
 template <int MODE>
 static void run(const char* name, float* sink, int cus, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(512), 0, 0, sink, 2000);
+    unsigned long long* clk; hipMalloc(&clk, 16);
+    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(512), 0, 0, sink, 2000, clk);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(512), 0, 0, sink, iters);
+    hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(512), 0, 0, sink, iters, clk);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = (double)cus * 8.0 * iters * 4.0 * 32768.0;   // per iteration: 4 x 32 K flop (MODE 0 / 2) = 8 x 16 K flop (MODE 1 / 3)
-    printf("%-58s %8.3f ms  %7.0f TFLOP/s\n", name, ms, flop / (ms * 1e-3) / 1e12);
+    unsigned long long hc[2]; hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost); hipFree(clk);
+    // shader cycles per 32 K flop per wave (one 32x32x16, or two 16x16x32): 64 = the pipe's rate with two waves per SIMD sharing it
+    printf("%-58s %8.3f ms  %7.0f TFLOP/s  %.3f GHz  %.1f cycles per 32 Kflop per wave\n", name, ms, flop / (ms * 1e-3) / 1e12,
+           (double)hc[0] / ((double)hc[1] * 10.0), (double)hc[0] / (4.0 * iters));
 }
 
 int main(int argc, char** argv) {

@@ -46,6 +46,37 @@ __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + (
 //   read back row-major (8 lanes x 16 B = one 128-byte row, XOR-swizzled 16-B slots), then global 16-B loads / stores.
 // The fp32 residual update (mode 2) issues all its loads for a half before the FMAs and stores.
 // Tiles that are partial in N (or a misaligned C) take the scalar path below.
+// Accumulator tile of one 32x32 output block per wave, in one of two register layouts (round 4):
+//   L16 = false: one v_mfma_f32_32x32x16_bf16 accumulator (16 registers): lane l holds row l & 31, quad q = columns 8q + 4 (l >> 5) .. + 3
+//   L16 = true : four v_mfma_f32_16x16x32_bf16 accumulators (4 registers each), quad q = (row half q >> 1, column half q & 1): lane l
+//                holds row 16 (q >> 1) + (l & 15), columns 16 (q & 1) + 4 (l >> 4) .. + 3
+// (operands swapped in both: D = Wfrag x Afrag^T, so a lane owns ONE output row per quad and four consecutive columns).  The bf16
+// kernels use L16: under the power cap the 16x16x32 form sustains 2135-2276 TFLOP/s against 1792-2049 for 32x32x16 on a pure MFMA
+// loop (tools/probe/mfma_shape_probe.hip: half the accumulator register traffic per FLOP), same pipe time per FLOP.
+typedef __attribute__((ext_vector_type(4))) float f32x4v;
+template <bool L16> struct AccTile { f32x16 v; };
+template <> struct AccTile<true> { f32x4v q[4]; };
+template <bool L16> __device__ __forceinline__ float aq(const AccTile<L16>& t, int q, int e) {
+    if constexpr (L16) return t.q[q][e]; else return t.v[4 * q + e];
+}
+template <bool L16> __device__ __forceinline__ void aq_add(AccTile<L16>& t, int q, int e, float x) {
+    if constexpr (L16) t.q[q][e] += x; else t.v[4 * q + e] += x;
+}
+template <bool L16> __device__ __forceinline__ void acc_zero(AccTile<L16>& t) {
+    if constexpr (L16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.q[q][e] = 0.f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t.v[r] = 0.f;
+    }
+}
+template <bool L16> __device__ __forceinline__ int q_row(int q, int lane) { return L16 ? (q >> 1) * 16 + (lane & 15) : (lane & 31); }   // row of quad q inside the block
+template <bool L16> __device__ __forceinline__ int q_col(int q, int lane) { return L16 ? (q & 1) * 16 + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5); }   // its first column
+template <bool L16> __device__ __forceinline__ int q_rr(int q) { return L16 ? (q >> 1) : 0; }   // which of the lane's rows of the block (L16: two)
+
 template <int RB>
 __device__ __forceinline__ int stage_off(int row, int slot) {
     return RB == 128 ? row * 128 + ((slot ^ (row & 7)) << 4) : row * 64 + ((slot ^ ((row >> 1) & 3)) << 4);
@@ -58,11 +89,12 @@ __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
-template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
-__device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
+template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true, bool L16 = false>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
+__device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
                                                    int wave = 0, int wnw = 1) {
-    const int frow = lane & 31, fhalf = lane >> 5;
+    constexpr int RPB = L16 ? 2 : 1;   // rows of a 32x32 block one lane holds (AccTile)
+    const int lrow = L16 ? (lane & 15) : (lane & 31);   // the lane's row inside its 16- / 32-row group
     const bool eprobe = ep.clk_probe && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0;   // ACE355_GEMM_CLK: phases of this epilogue
     const unsigned long long ep0 = eprobe ? clock64() : 0ull;
     if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {
@@ -72,19 +104,23 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         // arithmetic is unconditional (rstd 1, bias 0 with the hooks off: x * 1 + 0 is x) and the accumulators are never written: an
         // in-place update made hipcc move all 96 of them to VGPRs and spill (persistent QKV kernel: 192 B of scratch, epilogue 9.5 k ->
         // 32 k cycles per tile, +19 us per launch even with the hooks OFF).
-        float rs_in[MT];
+        float rs_in[MT][RPB];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) rs_in[i] = 1.f;
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rr = 0; rr < RPB; ++rr) rs_in[i][rr] = 1.f;
         if (FOLD && ep.nc_rowsq) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int m = mw0 + i * 32 + frow;
-                rs_in[i] = rsqrtf((float)(long long)ep.nc_rowsq[ROWS_FULL ? m : min(m, M - 1)] * (1.f / 16777216.f) * ep.nc_inv_d + ep.nc_eps);
-            }
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int rr = 0; rr < RPB; ++rr) {
+                    const int m = mw0 + i * 32 + rr * 16 + lrow;
+                    rs_in[i][rr] = rsqrtf((float)(long long)ep.nc_rowsq[ROWS_FULL ? m : min(m, M - 1)] * (1.f / 16777216.f) * ep.nc_inv_d + ep.nc_eps);
+                }
         }
-        auto fold_bias = [&](int j, int g) -> float4 {   // nc_bias of this lane's 4 columns of group (j, g); zeros with the hooks off
+        auto fold_bias = [&](int j, int g) -> float4 {   // nc_bias of this lane's 4 columns of quad g of block column j; zeros with the hooks off
             float4 bq = {0.f, 0.f, 0.f, 0.f};
-            if (FOLD && ep.nc_bias) bq = ldf4(ep.nc_bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+            if (FOLD && ep.nc_bias) bq = ldf4(ep.nc_bias + nw0 + j * 32 + q_col<L16>(g, lane));
             return bq;
         };
         // mode 4, q / k tiles (workgroup-uniform): per-row sum of squares over the head's 128 columns = this wave's 64 (two
@@ -94,65 +130,78 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
             if (ep.vt_out && nw0 >= ep.hn_qk_cols) {   // v tile -> V^T (workgroup-uniform: q | k | v boundaries fall on tile edges)
                 const int rps = ep.rows_per_seq;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int m = mw0 + i * 32 + frow;
-                    const int sq = m / rps, sp = m - sq * rps;
-                    bf16_t* base = ep.vt_out + (long)sq * ep.vt_heads * 128 * ep.vt_ld + sp;
-                    const bool ok = ROWS_FULL || m < M;
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < NTW; ++j)
+                    for (int rr = 0; rr < RPB; ++rr) {
+                        const int m = mw0 + i * 32 + rr * 16 + lrow;
+                        const int sq = m / rps, sp = m - sq * rps;
+                        bf16_t* base = ep.vt_out + (long)sq * ep.vt_heads * 128 * ep.vt_ld + sp;
+                        const bool ok = ROWS_FULL || m < M;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float4 bq = fold_bias(j, g);
-                            const int c = nw0 - ep.hn_qk_cols + j * 32 + 8 * g + 4 * fhalf;   // head * 128 + d of this lane's 4 columns
-                            bf16_t* col = base + (long)c * ep.vt_ld;
-                            if (ok) {
-                                col[0] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 0], rs_in[i], bq.x));
-                                col[ep.vt_ld] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 1], rs_in[i], bq.y));
-                                col[2 * (long)ep.vt_ld] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 2], rs_in[i], bq.z));
-                                col[3 * (long)ep.vt_ld] = f2bf(__builtin_fmaf(acc[i][j][4 * g + 3], rs_in[i], bq.w));
+                        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                if (q_rr<L16>(g) != rr) continue;   // (the quads of this row)
+                                const float4 bq = fold_bias(j, g);
+                                const int c = nw0 - ep.hn_qk_cols + j * 32 + q_col<L16>(g, lane);   // head * 128 + d of this lane's 4 columns
+                                bf16_t* col = base + (long)c * ep.vt_ld;
+                                if (ok) {
+                                    col[0] = f2bf(__builtin_fmaf(aq<L16>(acc[i][j], g, 0), rs_in[i][rr], bq.x));
+                                    col[ep.vt_ld] = f2bf(__builtin_fmaf(aq<L16>(acc[i][j], g, 1), rs_in[i][rr], bq.y));
+                                    col[2 * (long)ep.vt_ld] = f2bf(__builtin_fmaf(aq<L16>(acc[i][j], g, 2), rs_in[i][rr], bq.z));
+                                    col[3 * (long)ep.vt_ld] = f2bf(__builtin_fmaf(aq<L16>(acc[i][j], g, 3), rs_in[i][rr], bq.w));
+                                }
                             }
-                        }
-                }
+                    }
                 return;
             }
         }
-        float rstd[MT];
+        float rstd[MT][RPB];
         const bool hn = (MODE == 4) && (nw0 < ep.hn_qk_cols);
         const float* hw = nullptr;
         if constexpr (MODE == 4) {
             constexpr int HW = 4 / NTW;  // waves per 128-column head: a pair (64 columns each) or all four N-waves of a 128-wide tile
             if (hn) {
                 hw = (nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk;
-                float ss[MT];
+                float ss[MT][RPB];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) ss[i] = 0.f;
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < RPB; ++rr) ss[i][rr] = 0.f;
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 bq = fold_bias(j, g);
+                        constexpr int dummy = 0; (void)dummy;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) {
-                            const float t0 = __builtin_fmaf(acc[i][j][4 * g + 0], rs_in[i], bq.x), t1 = __builtin_fmaf(acc[i][j][4 * g + 1], rs_in[i], bq.y);
-                            const float t2 = __builtin_fmaf(acc[i][j][4 * g + 2], rs_in[i], bq.z), t3 = __builtin_fmaf(acc[i][j][4 * g + 3], rs_in[i], bq.w);
-                            ss[i] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+                            const float rs = rs_in[i][q_rr<L16>(g)];
+                            const float t0 = __builtin_fmaf(aq<L16>(acc[i][j], g, 0), rs, bq.x), t1 = __builtin_fmaf(aq<L16>(acc[i][j], g, 1), rs, bq.y);
+                            const float t2 = __builtin_fmaf(aq<L16>(acc[i][j], g, 2), rs, bq.z), t3 = __builtin_fmaf(aq<L16>(acc[i][j], g, 3), rs, bq.w);
+                            ss[i][q_rr<L16>(g)] += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
                         }
                     }
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    ss[i] += __shfl_xor(ss[i], 32, 64);
-                    if (lane < 32) xw[wave * (MT * 32) + i * 32 + frow] = ss[i];
-                }
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int rr = 0; rr < RPB; ++rr) {
+                        // the lanes that hold the other columns of this row: l ^ 32 (32x32 layout), l ^ 16 and l ^ 32 (16x16 layout)
+                        if constexpr (L16) ss[i][rr] += __shfl_xor(ss[i][rr], 16, 64);
+                        ss[i][rr] += __shfl_xor(ss[i][rr], 32, 64);
+                        if (lane < (L16 ? 16 : 32)) xw[wave * (MT * 32) + i * 32 + rr * 16 + lrow] = ss[i][rr];
+                    }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    float tot = 0.f;
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int k = 0; k < HW; ++k) tot += xw[((wave & ~(HW - 1)) + k) * (MT * 32) + i * 32 + frow];
-                    rstd[i] = rsqrtf(tot * (1.f / 128.f) + ep.hn_eps);
-                }
+                    for (int rr = 0; rr < RPB; ++rr) {
+                        float tot = 0.f;
+#pragma unroll
+                        for (int k = 0; k < HW; ++k) tot += xw[((wave & ~(HW - 1)) + k) * (MT * 32) + i * 32 + rr * 16 + lrow];
+                        rstd[i][rr] = rsqrtf(tot * (1.f / 128.f) + ep.hn_eps);
+                    }
                 if (eprobe) g_clk_probe[9] = clock64() - ep0;    // row scales + head sums of squares exchanged
             }
         }
@@ -166,7 +215,6 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
         typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
         f32x2 hwl[NTW * 4], hwh[NTW * 4];
         const bool rope = (MODE == 4) && ep.hn_cos != nullptr;  // no table: plain column order, norm only (cross-attention q)
-        const int cb = (MODE == 4) ? ((nw0 & 127) + 4 * fhalf) : 0;
         if constexpr (MODE == 4) {
             if (hn) {
                 // (the layout test stays outside the unrolled loops: a branch per element fences every load behind the
@@ -174,14 +222,14 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 if (rope) {
 #pragma unroll
                     for (int q8 = 0; q8 < NTW * 4; ++q8) {
-                        const int c = cb + (q8 >> 2) * 32 + (q8 & 3) * 8;
+                        const int c = (nw0 & 127) + (q8 >> 2) * 32 + q_col<L16>(q8 & 3, lane);
                         hwl[q8] = *reinterpret_cast<const f32x2*>(hw + (c >> 1));
                         hwh[q8] = *reinterpret_cast<const f32x2*>(hw + 64 + (c >> 1));
                     }
                 } else {
 #pragma unroll
                     for (int q8 = 0; q8 < NTW * 4; ++q8) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + cb + (q8 >> 2) * 32 + (q8 & 3) * 8);
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + (nw0 & 127) + (q8 >> 2) * 32 + q_col<L16>(q8 & 3, lane));
                         hwl[q8] = f32x2{w4[0], w4[2]};
                         hwh[q8] = f32x2{w4[1], w4[3]};
                     }
@@ -200,32 +248,36 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
                 float4 bu = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (MODE == 3) bu = fold_bias(J1, g);
                 float4 bb = {0.f, 0.f, 0.f, 0.f};
+                const int qc = q_col<L16>(g, lane);   // first of this quad's 4 columns inside the 32-column block
                 if constexpr (MODE != 4 && MODE != 3) {  // (the head epilogue takes no bias: launch_gemm checks)
-                    if (ep.bias) bb = ldf4(ep.bias + nw0 + j * 32 + 8 * g + 4 * fhalf);
+                    if (ep.bias) bb = ldf4(ep.bias + nw0 + j * 32 + qc);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
+                    const int rr = q_rr<L16>(g);
+                    const float rs = rs_in[i][rr];
                     float v0, v1, v2, v3;
                     if constexpr (MODE == 3) {  // W rows are interleaved [32 gate | 32 up] per 64: acc[i][0] = gate, acc[i][1] = up
-                        v0 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 0], rs_in[i], bq.x)) * __builtin_fmaf(acc[i][J1][4 * g + 0], rs_in[i], bu.x);
-                        v1 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 1], rs_in[i], bq.y)) * __builtin_fmaf(acc[i][J1][4 * g + 1], rs_in[i], bu.y);
-                        v2 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 2], rs_in[i], bq.z)) * __builtin_fmaf(acc[i][J1][4 * g + 2], rs_in[i], bu.z);
-                        v3 = silu_f(__builtin_fmaf(acc[i][0][4 * g + 3], rs_in[i], bq.w)) * __builtin_fmaf(acc[i][J1][4 * g + 3], rs_in[i], bu.w);
+                        v0 = silu_f(__builtin_fmaf(aq<L16>(acc[i][0], g, 0), rs, bq.x)) * __builtin_fmaf(aq<L16>(acc[i][J1], g, 0), rs, bu.x);
+                        v1 = silu_f(__builtin_fmaf(aq<L16>(acc[i][0], g, 1), rs, bq.y)) * __builtin_fmaf(aq<L16>(acc[i][J1], g, 1), rs, bu.y);
+                        v2 = silu_f(__builtin_fmaf(aq<L16>(acc[i][0], g, 2), rs, bq.z)) * __builtin_fmaf(aq<L16>(acc[i][J1], g, 2), rs, bu.z);
+                        v3 = silu_f(__builtin_fmaf(aq<L16>(acc[i][0], g, 3), rs, bq.w)) * __builtin_fmaf(aq<L16>(acc[i][J1], g, 3), rs, bu.w);
                     } else {
-                        v0 = __builtin_fmaf(acc[i][j][4 * g + 0], rs_in[i], bq.x) + bb.x; v1 = __builtin_fmaf(acc[i][j][4 * g + 1], rs_in[i], bq.y) + bb.y;
-                        v2 = __builtin_fmaf(acc[i][j][4 * g + 2], rs_in[i], bq.z) + bb.z; v3 = __builtin_fmaf(acc[i][j][4 * g + 3], rs_in[i], bq.w) + bb.w;
+                        v0 = __builtin_fmaf(aq<L16>(acc[i][j], g, 0), rs, bq.x) + bb.x; v1 = __builtin_fmaf(aq<L16>(acc[i][j], g, 1), rs, bq.y) + bb.y;
+                        v2 = __builtin_fmaf(aq<L16>(acc[i][j], g, 2), rs, bq.z) + bb.z; v3 = __builtin_fmaf(aq<L16>(acc[i][j], g, 3), rs, bq.w) + bb.w;
                         if constexpr (MODE == 4) {
                             if (hn) {
                                 const int q8 = j * 4 + g;  // head-norm here (per-column weights broadcast over the rows) ...
-                                v0 = hwl[q8].x * (v0 * rstd[i]), v1 = hwh[q8].x * (v1 * rstd[i]);
-                                v2 = hwl[q8].y * (v2 * rstd[i]), v3 = hwh[q8].y * (v3 * rstd[i]);
+                                v0 = hwl[q8].x * (v0 * rstd[i][rr]), v1 = hwh[q8].x * (v1 * rstd[i][rr]);
+                                v2 = hwl[q8].y * (v2 * rstd[i][rr]), v3 = hwh[q8].y * (v3 * rstd[i][rr]);
                             }
                         }
                     }
                     uint2 pk;
                     pk.x = pack_bf2(v0, v1);
                     pk.y = pack_bf2(v2, v3);
-                    *reinterpret_cast<uint2*>(stg + stage_off<RB>(i * 32 + frow, j * 4 + g) + 8 * fhalf) = pk;
+                    // staged image: 8-column (16-byte) slots; this quad = 4 columns = one half of slot (j * 32 + qc) / 8
+                    *reinterpret_cast<uint2*>(stg + stage_off<RB>(i * 32 + q_row<L16>(g, lane), j * 4 + (qc >> 3)) + (qc & 4) * 2) = pk;
                 }
             }
         if (eprobe) g_clk_probe[10] = clock64() - ep0;   // ... + staged
@@ -367,8 +419,9 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float4 a;
-                    a.x = acc[i][j][4 * g + 0]; a.y = acc[i][j][4 * g + 1]; a.z = acc[i][j][4 * g + 2]; a.w = acc[i][j][4 * g + 3];
-                    *reinterpret_cast<float4*>(stg + stage_off<128>(i * 32 + frow, 2 * g + fhalf)) = a;
+                    a.x = aq<L16>(acc[i][j], g, 0); a.y = aq<L16>(acc[i][j], g, 1); a.z = aq<L16>(acc[i][j], g, 2); a.w = aq<L16>(acc[i][j], g, 3);
+                    // fp32 staged image: 4-column (16-byte) slots
+                    *reinterpret_cast<float4*>(stg + stage_off<128>(i * 32 + q_row<L16>(g, lane), q_col<L16>(g, lane) >> 2)) = a;
                 }
             const int n = nw0 + j * 32 + slot * 4;
             float* hp = reinterpret_cast<float*>(Cv) + n;
@@ -532,44 +585,45 @@ __device__ __forceinline__ void gemm_epilogue_wide(f32x16 (&acc)[MT][NTW], char*
 }
 
 // Per-element path for tiles that are partial in N or whose C / vectors are not 16-byte aligned (unit-test shapes, tiny configs).
-template <int MODE, int MT, int NTW>
-__device__ __forceinline__ void gemm_epilogue_scalar(f32x16 (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
+template <int MODE, int MT, int NTW, bool L16 = false>
+__device__ __forceinline__ void gemm_epilogue_scalar(AccTile<L16> (&acc)[MT][NTW], void* __restrict__ Cv, int ldc, int M, int N,
                                                      const GemmEpilogue& ep, int mw0, int nw0, int lane) {
-    const int frow = lane & 31, fhalf = lane >> 5;
     constexpr int J1 = NTW - 1;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = mw0 + i * 32 + frow;
-        if (m >= M) continue;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < (MODE == 3 ? 1 : NTW); ++j)
+        for (int g = 0; g < 4; ++g) {
+            const int m = mw0 + i * 32 + q_row<L16>(g, lane);
+            if (m >= M) continue;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int nl = j * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
-                if (MODE == 3) {
-                    if (nw0 + 32 + nl < N) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + (nw0 >> 1) + nl] = f2bf(silu_f(acc[i][0][r]) * acc[i][J1][r]);
-                    continue;
+            for (int j = 0; j < (MODE == 3 ? 1 : NTW); ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int nl = j * 32 + q_col<L16>(g, lane) + e;
+                    if (MODE == 3) {
+                        if (nw0 + 32 + nl < N) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + (nw0 >> 1) + nl] = f2bf(silu_f(aq<L16>(acc[i][0], g, e)) * aq<L16>(acc[i][J1], g, e));
+                        continue;
+                    }
+                    const int n = nw0 + nl;
+                    if (n >= N) continue;
+                    const float v = aq<L16>(acc[i][j], g, e);
+                    if (MODE == 0 || MODE == 4) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + (ep.bias ? ep.bias[n] : 0.f));  // (4: launch_gemm never sends the head epilogue here)
+                    else if (MODE == 1) reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + (ep.bias ? ep.bias[n] : 0.f);
+                    else {
+                        float gate = 1.f;
+                        if (ep.g1) gate = ep.g1[n] + ep.g2[(long)(m / ep.rows_per_seq) * ep.g2_stride + n];
+                        float add = gate * v;
+                        if (ep.cvec && m >= ep.cvec_row0 && (ep.ksplit <= 1 || blockIdx.y == 0)) add += ep.cvec[n];
+                        if (ep.ksplit > 1 && !ep.sk_ord) unsafeAtomicAdd(reinterpret_cast<float*>(Cv) + (long)m * ldc + n, add);
+                        else reinterpret_cast<float*>(Cv)[(long)m * ldc + n] += add;
+                    }
                 }
-                const int n = nw0 + nl;
-                if (n >= N) continue;
-                const float v = acc[i][j][r];
-                if (MODE == 0 || MODE == 4) reinterpret_cast<bf16_t*>(Cv)[(long)m * ldc + n] = f2bf(v + (ep.bias ? ep.bias[n] : 0.f));  // (4: launch_gemm never sends the head epilogue here)
-                else if (MODE == 1) reinterpret_cast<float*>(Cv)[(long)m * ldc + n] = v + (ep.bias ? ep.bias[n] : 0.f);
-                else {
-                    float gate = 1.f;
-                    if (ep.g1) gate = ep.g1[n] + ep.g2[(long)(m / ep.rows_per_seq) * ep.g2_stride + n];
-                    float add = gate * v;
-                    if (ep.cvec && m >= ep.cvec_row0 && (ep.ksplit <= 1 || blockIdx.y == 0)) add += ep.cvec[n];
-                    if (ep.ksplit > 1 && !ep.sk_ord) unsafeAtomicAdd(reinterpret_cast<float*>(Cv) + (long)m * ldc + n, add);
-                    else reinterpret_cast<float*>(Cv)[(long)m * ldc + n] += add;
-                }
-            }
-    }
+        }
 }
 
 // smem: the workgroup's LDS (dead after the K loop; every wave stages MT*32 rows x 128 B in its own slice of it).
-template <int MODE, int MT, int NTW = 2, bool FOLD = true>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem, void* __restrict__ Cv, int ldc, int M, int N,
+template <int MODE, int MT, int NTW = 2, bool FOLD = true, bool L16 = false>
+__device__ __forceinline__ void gemm_epilogue(AccTile<L16> (&acc)[MT][NTW], char* smem, void* __restrict__ Cv, int ldc, int M, int N,
                                               const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int wave, int lane,
                                               int bm = MT * 64, int bn = 128) {
     const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NTW * 32);
@@ -579,10 +633,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][NTW], char* smem
         char* stg = smem + wave * (MT * 32 * 128);
         float* xw = reinterpret_cast<float*>(smem + (bn / (NTW * 32)) * (bm / (MT * 32)) * (MT * 32 * 128));  // behind the last staging slice
         const int wnw = bn / (NTW * 32);
-        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
-        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD, L16>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
+        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD, L16>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
     } else {
-        gemm_epilogue_scalar<MODE, MT, NTW>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
+        gemm_epilogue_scalar<MODE, MT, NTW, L16>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
     }
 }
 
@@ -634,13 +688,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
     *reinterpret_cast<uint4*>((base) + 16384 + st_off0 + 8192) = rw2;       \
     *reinterpret_cast<uint4*>((base) + 16384 + st_off0 + 12288) = rw3;
 
-    f32x16 acc[2][2];
+    AccTile<false> acc[2][2];   // (the bring-up kernel keeps the 32x32x16 MFMA)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 2; ++j) acc_zero<false>(acc[i][j]);
 
     uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
     LOAD_TILE(0)
@@ -665,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);
+                for (int j = 0; j < 2; ++j) acc[i][j].v = mfma32(fw[j], fa[i], acc[i][j].v);
         }
         if (more) {
             char* Ad = smem + ((kt + 1) & 1) * 32768;
@@ -674,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const bf16_t* __restrict__
         __syncthreads();
     }
 
-    gemm_epilogue<MODE, 2>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane);
+    gemm_epilogue<MODE, 2, 2, true, false>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane);
 }
 
 
@@ -803,13 +855,12 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     for (int j = 0; j < WJ; ++j) w_voff[j] = ((unsigned)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * (unsigned)ldw + sslot * 8) * 2u;
     const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
 
-    f32x16 acc[MT][NTW];
+    constexpr bool L16 = !FP8;   // bf16: v_mfma_f32_16x16x32_bf16 accumulators (AccTile<true>); MX fp8: the scaled 32x32x64 form
+    AccTile<L16> acc[MT][NTW];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < NTW; ++j) acc_zero<L16>(acc[i][j]);
 
     // split-K (ep.kparts > 1): blockIdx.y owns K steps [kt0, kt0 + nk)
     const int nk_all = K / BK;
@@ -819,7 +870,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     if (nk <= 0) return;
     const bf16_t* A = A0 + kt0 * BK;
     const bf16_t* W = W0 + kt0 * BK;
-    const int frow = lane & 31, fhalf = lane >> 5;
+    const int frow = L16 ? (lane & 15) : (lane & 31), fhalf = L16 ? (lane >> 4) : (lane >> 5);   // fragment row inside its 16- / 32-row group, K group of the lane
     // MX scales: wave 0 stages the A rows' words of K step kt (rows m0 .. m0+255 of scale row kt, 16 bytes per lane), wave 1 the W rows'
     const unsigned sc_voff = (unsigned)lane * 16u;
     const unsigned sc_lds = (unsigned)(uintptr_t)smem + A_BYTES + W_BYTES + (wave == 1 ? 1024u : 0u);
@@ -858,14 +909,21 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     for (int j = 0; j < NTW; ++j) w_off[j] = A_BYTES + (wn * (NTW * 32) + j * 32 + frow) * 128;
     const int swz = ((wm * (MT * 32) + frow) >> 1) & 7;   // (row>>1)&7 is the same for every 32-row tile of this lane
     const int swzw = ((wn * (NTW * 32) + frow) >> 1) & 7;
+    // Fragment (h, tile) of a half K step (kk0 = 0: k 0..31 of the step, kk0 = 2: k 32..63):
+    //   32x32x16 form: h = the 16-wide k sub-step, 32-row fragments, slot = (kk0 + h) * 2 + (lane >> 5)
+    //   16x16x32 form: h = the 16-ROW half of the 32-row block, the fragment spans the half step's 32 k: slot = (kk0 / 2) * 4 + (lane >> 4)
+    // (the same LDS image and the same XOR swizzle serve both: (row >> 1) & 7 does not change across 16-row halves, and the 16 lanes a
+    //  ds_read_b128 services together still fall on 16 different 16-byte bank groups)
+    auto frag_slot = [&](int kk0, int h) -> int { return L16 ? (kk0 >> 1) * 4 + fhalf : (kk0 + h) * 2 + fhalf; };
+    constexpr int HROW = L16 ? 16 * 128 : 0;   // byte offset of fragment half h inside its block (16x16x32 form)
     auto load_frags = [&](const char* st, int kk0, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int slot = (kk0 + h) * 2 + fhalf;
+            const int slot = frag_slot(kk0, h);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[h][i] = as_bf16x8(*reinterpret_cast<const uint4*>(st + a_off[i] + ((slot ^ swz) << 4)));
+            for (int i = 0; i < MT; ++i) fa[h][i] = as_bf16x8(*reinterpret_cast<const uint4*>(st + a_off[i] + h * HROW + ((slot ^ swz) << 4)));
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + ((slot ^ swzw) << 4)));
+            for (int j = 0; j < NTW; ++j) fw[h][j] = as_bf16x8(*reinterpret_cast<const uint4*>(st + w_off[j] + h * HROW + ((slot ^ swzw) << 4)));
         }
     };
 
@@ -895,12 +953,24 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // back to back right after the barrier stall the in-order wave before its first MFMA.  Here every MFMA is followed
     // by at most one DMA piece or two fragment reads, pinned with sched_barrier.
     {
-        constexpr int NM = 2 * MT * NTW;  // MFMAs per half K-step
+        constexpr int NM = (L16 ? 4 : 2) * MT * NTW;  // MFMAs per half K-step (16x16x32: four 16-cycle ones per 32x32 block; else two 32-cycle ones)
         constexpr int NF = 2 * (MT + NTW);  // fragment reads per half K-step
+        constexpr int FPM = (NF + NM - 1) / NM < 1 ? 1 : (NF + NM - 1) / NM;   // fragment reads hung behind one MFMA of the first half
         auto frag_ptr = [&](const char* st, int kk0, int f) -> const uint4* {
             const int h = f / (MT + NTW), e = f % (MT + NTW);
-            const int slot = (kk0 + h) * 2 + fhalf;
-            return reinterpret_cast<const uint4*>(e < MT ? st + a_off[e] + ((slot ^ swz) << 4) : st + w_off[e - MT] + ((slot ^ swzw) << 4));
+            const int slot = frag_slot(kk0, h);
+            return reinterpret_cast<const uint4*>(e < MT ? st + a_off[e] + h * HROW + ((slot ^ swz) << 4) : st + w_off[e - MT] + h * HROW + ((slot ^ swzw) << 4));
+        };
+        // MFMA m of a half K step on fragment set (fa, fw): 32x32x16 form: (h, i, j) - k sub-step h of block (i, j);
+        // 16x16x32 form: (i, hr, j, hc) - quad (hr, hc) of block (i, j), row half from fa[hr][i], column half from fw[hc][j]
+        auto mfma_m = [&](int m, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
+            if constexpr (L16) {
+                const int i = m / (4 * NTW), hr = (m / (2 * NTW)) & 1, j = (m >> 1) % NTW, hc = m & 1;
+                acc[i][j].q[hr * 2 + hc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[hc][j], fa[hr][i], acc[i][j].q[hr * 2 + hc], 0, 0, 0);
+            } else {
+                const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
+                acc[i][j].v = mfma32(fw[h][j], fa[h][i], acc[i][j].v);
+            }
         };
         auto frag_store = [&](bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW], int f, uint4 v) {
             const int h = f / (MT + NTW), e = f % (MT + NTW);
@@ -915,10 +985,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
-                acc[i][j] = mfma32(pw[h][j], pa[h][i], acc[i][j]);
+                mfma_m(m, pa, pw);
 #pragma unroll
-                for (int f = 2 * m; f < 2 * m + 2; ++f)
+                for (int f = FPM * m; f < FPM * m + FPM; ++f)
                     if (f < NF) frag_store(qa, qw, f, *frag_ptr(st, 2, f));
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -934,8 +1003,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             const bf16_t* w_k2 = W + (kt + NS) * BK;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
-                acc[i][j] = mfma32(qw[h][j], qa[h][i], acc[i][j]);
+                mfma_m(m, qa, qw);
                 constexpr int DP = (AJ + WJ + NM - 1) / NM < 1 ? 1 : (AJ + WJ + NM - 1) / NM;   // DMA pieces per MFMA slot (1 for every product tile)
                 constexpr int DSL = (AJ + WJ + DP - 1) / DP;                                      // MFMA slots that carry DMA
                 if (dma) {
@@ -966,7 +1034,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
                 const int i = m / NTW, j = m % NTW;
-                acc[i][j] = mfma_mx<0>(pw[0][j], pw[1][j], pa[0][i], pa[1][i], acc[i][j], scw[j], sca[i]);
+                if constexpr (!L16) acc[i][j].v = mfma_mx<0>(pw[0][j], pw[1][j], pa[0][i], pa[1][i], acc[i][j].v, scw[j], sca[i]);
 #pragma unroll
                 for (int f = 2 * m; f < 2 * m + 2; ++f)
                     if (f < NF) frag_store(qa, qw, f, *frag_ptr(st, 2, f));
@@ -993,7 +1061,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
                 const int i = m / NTW, j = m % NTW;
-                acc[i][j] = mfma_mx<2>(qw[0][j], qw[1][j], qa[0][i], qa[1][i], acc[i][j], scw[j], sca[i]);
+                if constexpr (!L16) acc[i][j].v = mfma_mx<2>(qw[0][j], qw[1][j], qa[0][i], qa[1][i], acc[i][j].v, scw[j], sca[i]);
                 if (dma) {
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -1061,7 +1129,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float4 v;
-                                v.x = acc[i][j][4 * q + 0]; v.y = acc[i][j][4 * q + 1]; v.z = acc[i][j][4 * q + 2]; v.w = acc[i][j][4 * q + 3];
+                                v.x = aq<L16>(acc[i][j], q, 0); v.y = aq<L16>(acc[i][j], q, 1); v.z = aq<L16>(acc[i][j], q, 2); v.w = aq<L16>(acc[i][j], q, 3);
                                 dst[((i * NTW + j) * 4 + q) * NTH] = v;
                             }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's accumulators are in L2
@@ -1089,7 +1157,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float4 w = v[(i * NTW + j) * 4 + q];
-                                acc[i][j][4 * q + 0] += w.x; acc[i][j][4 * q + 1] += w.y; acc[i][j][4 * q + 2] += w.z; acc[i][j][4 * q + 3] += w.w;
+                                aq_add<L16>(acc[i][j], q, 0, w.x); aq_add<L16>(acc[i][j], q, 1, w.y); aq_add<L16>(acc[i][j], q, 2, w.z); aq_add<L16>(acc[i][j], q, 3, w.w);
                             }
                 }
                 if (tid == 0) atomicExch(ep.sk_cnt + tile, 0);   // (only this workgroup looks at the counter from here on)
@@ -1112,7 +1180,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 asm volatile("" ::: "memory");
             }
         }
-        gemm_epilogue<MODE, MT, NTW, !FP8>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+        gemm_epilogue<MODE, MT, NTW, !FP8, L16>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's H rows are in L2

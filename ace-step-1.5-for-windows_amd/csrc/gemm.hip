@@ -15,7 +15,7 @@
 // Round 2 on top of that: an MX-scaled fp8 variant of the same kernel (FP8 template parameter, v_mfma_scale_f32_32x32x64_f8f6f4), the
 // folded-RMSNorm hooks of the epilogues (GemmEpilogue nf_* / nc_*: DESIGN.md section 5), split-K of the small-M residual launches in
 // part order (turn counters, bit-reproducible) behind a one-time check of the workgroup -> XCD placement it relies on.
-// Common: MFMA 32x32x16 bf16, K-contiguous operands, LDS image XOR-swizzled at 16-B granularity (slot ^= (row>>1)&7:
+// Common: MFMA 16x16x32 bf16 (AccTile below; the bring-up kernel and the MX kernels keep 32x32 forms), K-contiguous operands, LDS image XOR-swizzled at 16-B granularity (slot ^= (row>>1)&7:
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 

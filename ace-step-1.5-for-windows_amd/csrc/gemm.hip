@@ -19,6 +19,13 @@
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 
+#ifndef ACE355_DMA_PAT
+#define ACE355_DMA_PAT 0   // placement of the DMA pieces in the second half of a K step (dma_piece_of_slot)
+#endif
+#ifndef ACE355_ABL_NODMA
+#define ACE355_ABL_NODMA 0   // 1 (diagnostic build, WRONG results): the bf16 K loop issues no DMA pieces - what the pieces cost a K step
+#endif
+
 #include <stdio.h>
 #include <type_traits>
 #include <stdlib.h>
@@ -76,6 +83,30 @@ template <bool L16> __device__ __forceinline__ void acc_zero(AccTile<L16>& t) {
 template <bool L16> __device__ __forceinline__ int q_row(int q, int lane) { return L16 ? (q >> 1) * 16 + (lane & 15) : (lane & 31); }   // row of quad q inside the block
 template <bool L16> __device__ __forceinline__ int q_col(int q, int lane) { return L16 ? (q & 1) * 16 + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5); }   // its first column
 template <bool L16> __device__ __forceinline__ int q_rr(int q) { return L16 ? (q >> 1) : 0; }   // which of the lane's rows of the block (L16: two)
+
+// Second half of a bf16 K step: which DMA piece (or -1) rides behind MFMA slot m.  NM slots, ND pieces, G = wave group (wave >> 2 of an
+// 8-wave workgroup: waves w and w + 4 share a SIMD).
+//   PAT 0: pieces in slots 0 .. ND-1 (both groups)              PAT 1: every (NM / ND)-th slot
+//   PAT 2: as 1, group 1 one slot later                         PAT 3: group 0 as PAT 0, group 1 after its fragment reads
+//   PAT 4: group 0 as PAT 0, group 1 every (NM / ND)-th slot from slot 1
+template <int PAT, int G, int NM, int ND, int NF>
+__device__ __forceinline__ constexpr int dma_piece_of_slot(int m) {
+    if (PAT == 1 || PAT == 2 || (PAT == 4 && G == 1)) {
+        const int S = NM / ND < 1 ? 1 : NM / ND, off = ((PAT == 2 || PAT == 4) && G) ? 1 : 0;
+        return (m >= off && (m - off) % S == 0 && (m - off) / S < ND) ? (m - off) / S : -1;
+    }
+    if (PAT == 3 && G == 1) {
+        const int base = NF < NM - ND ? NF : NM - ND;
+        return (m >= base && m - base < ND) ? m - base : -1;
+    }
+    return m < ND ? m : -1;
+}
+template <int PAT, int G, int NM, int ND, int NF>
+__device__ __forceinline__ constexpr int dma_free_rank(int m) {   // how many piece-free slots precede slot m
+    int r = 0;
+    for (int x = 0; x < m; ++x) r += dma_piece_of_slot<PAT, G, NM, ND, NF>(x) < 0 ? 1 : 0;
+    return r;
+}
 
 template <int RB>
 __device__ __forceinline__ int stage_off(int row, int slot) {
@@ -849,10 +880,13 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     const int lrow = lane >> 3, pslot = lane & 7;
     const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
     unsigned a_voff[AJ], w_voff[WJ];  // per-lane byte offsets from A / W (launch_gemm checks both matrices are < 4 GB)
+    // ACE355_GEMM_CLK bits 1 / 2 (diagnostic, WRONG results): every workgroup streams the A / W panel of tile 0 - the operands come out of
+    // the L2 whatever the tile, which separates what the fabric costs a K step from what the CU-side path (DMA, LDS, MFMA) costs it
+    const int lm0 = (ep.clk_probe & 2) ? 0 : m0, ln0 = (ep.clk_probe & 4) ? 0 : n0;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) a_voff[j] = ((unsigned)min(m0 + 8 * (wave + NW * j) + lrow, M - 1) * (unsigned)lda + sslot * 8) * 2u;
+    for (int j = 0; j < AJ; ++j) a_voff[j] = ((unsigned)min(lm0 + 8 * (wave + NW * j) + lrow, M - 1) * (unsigned)lda + sslot * 8) * 2u;
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) w_voff[j] = ((unsigned)min(n0 + 8 * (wave + NW * j) + lrow, N - 1) * (unsigned)ldw + sslot * 8) * 2u;
+    for (int j = 0; j < WJ; ++j) w_voff[j] = ((unsigned)min(ln0 + 8 * (wave + NW * j) + lrow, N - 1) * (unsigned)ldw + sslot * 8) * 2u;
     const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
 
     constexpr bool L16 = !FP8;   // bf16: v_mfma_f32_16x16x32_bf16 accumulators (AccTile<true>); MX fp8: the scaled 32x32x64 form
@@ -979,8 +1013,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         unsigned long long c0 = 0, w0 = 0;
         const bool probe = ep.clk_probe && blockIdx.x == 0 && tid == 0;
         if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-        auto kstep = [&](int kt, auto more_c, auto dma_c) {
+        auto kstep = [&](int kt, auto more_c, auto dma_c, auto grp_c) {
             constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
+            constexpr int G = decltype(grp_c)::value;
             const char* st = smem + (kt % NS) * STAGE;
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
 #pragma unroll
@@ -1006,7 +1041,21 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 mfma_m(m, qa, qw);
                 constexpr int DP = (AJ + WJ + NM - 1) / NM < 1 ? 1 : (AJ + WJ + NM - 1) / NM;   // DMA pieces per MFMA slot (1 for every product tile)
                 constexpr int DSL = (AJ + WJ + DP - 1) / DP;                                      // MFMA slots that carry DMA
-                if (dma) {
+                constexpr int PAT = (AJ + WJ <= NM && NF <= NM - (AJ + WJ)) ? ACE355_DMA_PAT : 0;   // (placements need one piece / one read per slot)
+                if constexpr (PAT != 0) {
+                    const int pc = dma_piece_of_slot<PAT, G, NM, AJ + WJ, NF>(m);
+                    if (dma && pc >= 0) {
+                        if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
+                        else glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
+                    }
+                    if (more && pc < 0) {
+                        const int f = dma_free_rank<PAT, G, NM, AJ + WJ, NF>(m);
+                        if (f < NF) frag_store(pa, pw, f, *frag_ptr(stn, 0, f));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+                if (dma && !ACE355_ABL_NODMA) {
 #pragma unroll
                     for (int q = 0; q < DP; ++q) {
                         const int pc = m * DP + q;
@@ -1103,9 +1152,17 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 for (; kt + 1 < nk; ++kt) kstep_mx(kt, T{}, F{});
                 kstep_mx(kt, F{}, F{});
             } else {
-            for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{});     // steady state: branch-free
-            for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{});       // the last NS-1 K steps but one: nothing left to prefetch
-            kstep(kt, F{}, F{});                                 // last K step
+            using G0 = std::integral_constant<int, 0>;
+            using G1 = std::integral_constant<int, 1>;
+            if (ACE355_DMA_PAT >= 2 && NW == 8 && wave >= 4) {   // (wave-uniform) the second wave of every SIMD: its own piece placement
+                for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{}, G1{});
+                for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{}, G1{});
+                kstep(kt, F{}, F{}, G1{});
+            } else {
+            for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{}, G0{});     // steady state: branch-free
+            for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{}, G0{});       // the last NS-1 K steps but one: nothing left to prefetch
+            kstep(kt, F{}, F{}, G0{});                                 // last K step
+            }
             }
         }
         if (probe && (int)blockIdx.y == ep.kparts - 1) {

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
-ACE355_SAMPLE_GRAPH=0 ACE355_GEMM_CLK=1 python bench.py --steps 1 --warmup 1 --no-vae --no-roofline --no-cpu-baseline "$@" > /dev/null 2> /tmp/clk_raw.txt
+ACE355_SAMPLE_GRAPH=0 ACE355_GEMM_CLK=${ACE355_CLK_VAL:-1} python bench.py --steps 1 --warmup 1 --no-vae --no-roofline --no-cpu-baseline "$@" > /dev/null 2> /tmp/clk_raw.txt
 python - > $OUT/${TAG}_gemm_clk_inpass.txt <<'PY'
 import re, collections
 rows = collections.defaultdict(list)

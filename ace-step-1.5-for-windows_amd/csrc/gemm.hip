@@ -19,9 +19,6 @@
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 
-#ifndef ACE355_DMA_PAT
-#define ACE355_DMA_PAT 0   // placement of the DMA pieces in the second half of a K step (dma_piece_of_slot)
-#endif
 #ifndef ACE355_ABL_NODMA
 #define ACE355_ABL_NODMA 0   // 1 (diagnostic build, WRONG results): the bf16 K loop issues no DMA pieces - what the pieces cost a K step
 #endif
@@ -84,27 +81,21 @@ template <bool L16> __device__ __forceinline__ int q_row(int q, int lane) { retu
 template <bool L16> __device__ __forceinline__ int q_col(int q, int lane) { return L16 ? (q & 1) * 16 + 4 * (lane >> 4) : 8 * q + 4 * (lane >> 5); }   // its first column
 template <bool L16> __device__ __forceinline__ int q_rr(int q) { return L16 ? (q >> 1) : 0; }   // which of the lane's rows of the block (L16: two)
 
-// Second half of a bf16 K step: which DMA piece (or -1) rides behind MFMA slot m.  NM slots, ND pieces, G = wave group (wave >> 2 of an
-// 8-wave workgroup: waves w and w + 4 share a SIMD).
-//   PAT 0: pieces in slots 0 .. ND-1 (both groups)              PAT 1: every (NM / ND)-th slot
-//   PAT 2: as 1, group 1 one slot later                         PAT 3: group 0 as PAT 0, group 1 after its fragment reads
-//   PAT 4: group 0 as PAT 0, group 1 every (NM / ND)-th slot from slot 1
-template <int PAT, int G, int NM, int ND, int NF>
+// Second half of a bf16 K step: which DMA piece (or -1) rides behind MFMA slot m, and how many piece-free slots precede slot m (those
+// carry the next step's fragment reads).  The ND pieces sit on every (NM / ND)-th slot instead of back to back behind the barrier: a
+// piece blocks the issuing wave for 60-180 cycles while the address unit of the CU works through all eight waves' pieces (no-DMA
+// ablation: 1985 -> 1678 cycles per K step), and spread out the two waves of a SIMD are less often blocked together: 1984 -> 1821
+// cycles per K step on the gate|up launch, 1942 -> 1771 on QKV (profiles/r04_dma_placement_sweep.txt: "pat1"); wave-group-specific
+// placements (the second wave of each SIMD one slot later / after its reads) were no better and spilled in the persistent kernels.
+template <int NM, int ND>
 __device__ __forceinline__ constexpr int dma_piece_of_slot(int m) {
-    if (PAT == 1 || PAT == 2 || (PAT == 4 && G == 1)) {
-        const int S = NM / ND < 1 ? 1 : NM / ND, off = ((PAT == 2 || PAT == 4) && G) ? 1 : 0;
-        return (m >= off && (m - off) % S == 0 && (m - off) / S < ND) ? (m - off) / S : -1;
-    }
-    if (PAT == 3 && G == 1) {
-        const int base = NF < NM - ND ? NF : NM - ND;
-        return (m >= base && m - base < ND) ? m - base : -1;
-    }
-    return m < ND ? m : -1;
+    const int S = NM / ND < 1 ? 1 : NM / ND;
+    return (m % S == 0 && m / S < ND) ? m / S : -1;
 }
-template <int PAT, int G, int NM, int ND, int NF>
-__device__ __forceinline__ constexpr int dma_free_rank(int m) {   // how many piece-free slots precede slot m
+template <int NM, int ND>
+__device__ __forceinline__ constexpr int dma_free_rank(int m) {
     int r = 0;
-    for (int x = 0; x < m; ++x) r += dma_piece_of_slot<PAT, G, NM, ND, NF>(x) < 0 ? 1 : 0;
+    for (int x = 0; x < m; ++x) r += dma_piece_of_slot<NM, ND>(x) < 0 ? 1 : 0;
     return r;
 }
 
@@ -1013,9 +1004,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         unsigned long long c0 = 0, w0 = 0;
         const bool probe = ep.clk_probe && blockIdx.x == 0 && tid == 0;
         if (probe) { c0 = clock64(); w0 = wall_clock64(); }
-        auto kstep = [&](int kt, auto more_c, auto dma_c, auto grp_c) {
+        auto kstep = [&](int kt, auto more_c, auto dma_c) {
             constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
-            constexpr int G = decltype(grp_c)::value;
             const char* st = smem + (kt % NS) * STAGE;
             // first half: MFMA(P) with the Q fragment reads spread behind the first MFMAs
 #pragma unroll
@@ -1041,15 +1031,15 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 mfma_m(m, qa, qw);
                 constexpr int DP = (AJ + WJ + NM - 1) / NM < 1 ? 1 : (AJ + WJ + NM - 1) / NM;   // DMA pieces per MFMA slot (1 for every product tile)
                 constexpr int DSL = (AJ + WJ + DP - 1) / DP;                                      // MFMA slots that carry DMA
-                constexpr int PAT = (AJ + WJ <= NM && NF <= NM - (AJ + WJ)) ? ACE355_DMA_PAT : 0;   // (placements need one piece / one read per slot)
-                if constexpr (PAT != 0) {
-                    const int pc = dma_piece_of_slot<PAT, G, NM, AJ + WJ, NF>(m);
-                    if (dma && pc >= 0) {
+                constexpr bool SPREAD = (AJ + WJ <= NM) && (NF <= NM - (AJ + WJ));   // one piece or one read per slot (every product tile)
+                if constexpr (SPREAD) {
+                    const int pc = dma_piece_of_slot<NM, AJ + WJ>(m);
+                    if (dma && !ACE355_ABL_NODMA && pc >= 0) {
                         if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
                         else glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
                     }
                     if (more && pc < 0) {
-                        const int f = dma_free_rank<PAT, G, NM, AJ + WJ, NF>(m);
+                        const int f = dma_free_rank<NM, AJ + WJ>(m);
                         if (f < NF) frag_store(pa, pw, f, *frag_ptr(stn, 0, f));
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1152,17 +1142,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 for (; kt + 1 < nk; ++kt) kstep_mx(kt, T{}, F{});
                 kstep_mx(kt, F{}, F{});
             } else {
-            using G0 = std::integral_constant<int, 0>;
-            using G1 = std::integral_constant<int, 1>;
-            if (ACE355_DMA_PAT >= 2 && NW == 8 && wave >= 4) {   // (wave-uniform) the second wave of every SIMD: its own piece placement
-                for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{}, G1{});
-                for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{}, G1{});
-                kstep(kt, F{}, F{}, G1{});
-            } else {
-            for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{}, G0{});     // steady state: branch-free
-            for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{}, G0{});       // the last NS-1 K steps but one: nothing left to prefetch
-            kstep(kt, F{}, F{}, G0{});                                 // last K step
-            }
+            for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{});     // steady state: branch-free
+            for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{});       // the last NS-1 K steps but one: nothing left to prefetch
+            kstep(kt, F{}, F{});                                 // last K step
             }
         }
         if (probe && (int)blockIdx.y == ep.kparts - 1) {

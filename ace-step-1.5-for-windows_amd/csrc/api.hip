@@ -97,6 +97,8 @@ extern "C" {
 const char* ace355_last_error(void) { return g_err.c_str(); }
 int ace355_version(void) { return 100; }
 
+int ace355_gemm_set_k_rotation(int mode) { return gemm_set_k_rotation(mode); }
+
 int ace355_box_probe_mfma(int iters, double* tflops_out) {
     ACE_CHECK(tflops_out && iters > 0 && iters <= (1 << 22), "box_probe_mfma: bad argument");
     float* sink = nullptr;

@@ -156,11 +156,13 @@ struct GemmEpilogue {
     // tile even for multi-round launches (a persistent grid keeps every CU it was given until its last tile: nothing for a kernel of
     // another stream to slip into)
     int tile_hint; int no_pers;
+    int krot;   // kernel-visible: 1 = non-persistent bf16 launches walk K rotated by (workgroup's XCD) * nk / 8 (gemm.hip: K rotation)
     // cu_slots (0 = the whole chip, 256): the CUs this launch plans for - tile choice, persistent grid size, deep-pipeline decision.  The
     // dual-chain sampler (dit.hip) runs two independent launch sequences on two hardware queues and shapes every launch of both for 128
     // CUs, so that the chains run side by side instead of interleaving workgroups over all 256 (round 4: 512 -> 473 ms per 8-song pass)
     int cu_slots;
 };
+int gemm_set_k_rotation(int mode);   // ace355_gemm_set_k_rotation; returns the previous mode
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
 // MXFP8 operands: Aq / Wq fp8 e4m3 [M, K] / [N, K] (row stride = K bytes), scales as GemmEpilogue::mx_sa / mx_sw describe; same

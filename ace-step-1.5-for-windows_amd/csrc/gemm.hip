@@ -19,6 +19,10 @@
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 
+#ifndef ACE355_ABL_HOTK
+#define ACE355_ABL_HOTK 0    // 1 (diagnostic build, WRONG results): every K step of the bf16 loop re-reads K slices 2 / 3 of its panels - the pieces are
+                             // issued as always but never miss the L2: separates the pieces' ISSUE cost from exposed fetch latency
+#endif
 #ifndef ACE355_ABL_NODMA
 #define ACE355_ABL_NODMA 0   // 1 (diagnostic build, WRONG results): the bf16 K loop issues no DMA pieces - what the pieces cost a K step
 #endif
@@ -895,6 +899,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     if (nk <= 0) return;
     const bf16_t* A = A0 + kt0 * BK;
     const bf16_t* W = W0 + kt0 * BK;
+    // K rotation (ep.krot; one-round launches): the workgroups of XCD x start at K step x * nk / 8 and wrap, so the eight L2s do not miss the
+    // same K slice at the same moment: a slice's first reader pays the HBM latency, the other seven find it in the memory-side cache
+    // (launches that leave a quarter of the CUs without a tile have no common miss to spread: batch 1 measured + 0.3 % with the rotation on)
+    const int krot = (!PERS && !FP8 && ep.krot && ep.kparts == 1 && nwg >= 192) ? (int)(blockIdx.x & 7) * (nk >> 3) : 0;
+    auto kmap = [&](int kt) -> int { const int k = kt + krot; return k >= nk ? k - nk : k; };
     const int frow = L16 ? (lane & 15) : (lane & 31), fhalf = L16 ? (lane >> 4) : (lane >> 5);   // fragment row inside its 16- / 32-row group, K group of the lane
     // MX scales: wave 0 stages the A rows' words of K step kt (rows m0 .. m0+255 of scale row kt, 16 bytes per lane), wave 1 the W rows'
     const unsigned sc_voff = (unsigned)lane * 16u;
@@ -910,9 +919,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     auto issue = [&](int kt) {
         const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
 #pragma unroll
-        for (int j = 0; j < AJ; ++j) glds16_sv(a_voff[j], A + kt * BK, sb + j * (NW * 1024));
+        for (int j = 0; j < AJ; ++j) glds16_sv(a_voff[j], A + kmap(kt) * BK, sb + j * (NW * 1024));
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) glds16_sv(w_voff[j], W + kt * BK, sb + A_BYTES + j * (NW * 1024));
+        for (int j = 0; j < WJ; ++j) glds16_sv(w_voff[j], W + kmap(kt) * BK, sb + A_BYTES + j * (NW * 1024));
         issue_scales(kt);
     };
     // this lane's scale words of a stage (row of each of its A / W tiles), pre-shifted for the upper lane half
@@ -1024,8 +1033,9 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             }
             const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
             const char* stn = smem + ((kt + 1) % NS) * STAGE;
-            const bf16_t* a_k2 = A + (kt + NS) * BK;  // uniform: tile kt+NS goes into the stage this step just finished reading
-            const bf16_t* w_k2 = W + (kt + NS) * BK;
+            const int kt2 = kmap((ACE355_ABL_HOTK ? (kt & 1) : kt) + NS);   // (HOTK: two K slices serve every step)
+            const bf16_t* a_k2 = A + kt2 * BK;  // uniform: tile kt+NS goes into the stage this step just finished reading
+            const bf16_t* w_k2 = W + kt2 * BK;
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 mfma_m(m, qa, qw);
@@ -1386,6 +1396,17 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
 #undef ACE_LAUNCH_SP
 }
 
+static int g_k_rotation = -1;   // ace355_gemm_set_k_rotation / ACE355_GEMM_KROT (default 1)
+static int k_rotation_mode() {
+    if (g_k_rotation < 0) g_k_rotation = env_int("ACE355_GEMM_KROT", 1);
+    return g_k_rotation;
+}
+int gemm_set_k_rotation(int mode) {
+    const int prev = k_rotation_mode();
+    g_k_rotation = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    return prev;
+}
+
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep_in, hipStream_t s) {
     GemmEpilogue ep = ep_in;
@@ -1398,6 +1419,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         static int clk = -1;
         if (clk < 0) clk = env_int("ACE355_GEMM_CLK", 0);
         ep.clk_probe = clk;
+        const int krot = k_rotation_mode();   // 1: launches with N <= 2048, 2: every launch (the kernel applies it to one-round bf16 launches)
+        ep.krot = (krot == 2 || (krot == 1 && N <= 2048)) && (K / 64) % 8 == 0;
     }
     ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");

@@ -83,6 +83,7 @@ SIGNATURES = {
     "ace355_dit_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_set_norm_fold": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_box_probe_mfma": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "ace355_gemm_set_k_rotation": (C.c_int, [C.c_int]),
     "ace355_dit_set_dual": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_dual_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ace355_dit_set_cfg_fork": (C.c_int, [C.c_void_p, C.c_int]),
@@ -189,6 +190,12 @@ def last_error() -> str:
 def check(rc: int, what: str = "") -> None:
     if rc != OK:
         raise RuntimeError(f"ace355 native call failed ({what}, code {rc}): {last_error()}")
+
+
+def gemm_set_k_rotation(mode: int) -> int:
+    """`ace355_gemm_set_k_rotation` (include/ace355.h): 0 off, 1 launches with N <= 2048 (default), 2 every one-round launch; returns the
+    previous mode.  Process-wide."""
+    return int(lib().ace355_gemm_set_k_rotation(int(mode)))
 
 
 def current_stream_ptr() -> int:

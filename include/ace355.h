@@ -48,6 +48,15 @@ int ace355_version(void);
  * v_mfma_f32_32x32x16_bf16 loop with random operands, 8 waves per CU, no memory traffic (TFLOP/s; the boxes of the pool differ by a
  * few percent under the same power cap, and a bench line is only comparable across boxes beside this number).  Synchronises the device. */
 int ace355_box_probe_mfma(int iters, double* tflops_out);
+/* Tuning knob of the bf16 GEMM (no reference counterpart; process-wide, returns the previous mode).  K rotation: in a launch that gives
+ * every CU exactly one output tile (the o_proj / down projections at the metric batch), all eight L2s would miss the same K slice of the
+ * operands at the same moment; with the rotation on, the workgroups of XCD x start at K step x * nk / 8 and wrap, so a slice's first reader
+ * pays the HBM latency and the others find it in the memory-side cache (K step 1.12 -> 1.06 us, - 1 % per 8-song pass).  The fp32 accumulation
+ * ORDER of an output element then depends on the XCD region its tile falls in, i.e. on the launch shape: the same request still gives the
+ * same bits, but a song's bits depend on the batch it is part of (3e-3 rel L2 apart, both at the same distance from the reference).
+ * mode 0: off (one K order whatever the shape; what the bit-identity tests of the CFG fork pin), 1 (default; env ACE355_GEMM_KROT):
+ * launches with N <= 2048, 2: every one-round launch.  Not a per-handle setting: call it before the first request. */
+int ace355_gemm_set_k_rotation(int mode);
 
 /* ------------------------------------------------------------------------------------------
  * DiT decoder (AceStepDiTModel, base.py:1240-1507) + sampler (generate_audio, base.py:1783-1989)

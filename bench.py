@@ -487,7 +487,7 @@ def main():
         peak = PEAK_MXFP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
         kname = ("gemm_sp_kernel<.., FP8> (MX-scaled fp8 MFMA 32x32x64 for QKV / o_proj / gate|up / down, 192x256x128 tiles; the cross-attention "
                  "projections and small launches stay on the bf16 kernel: `achieved` averages over all GEMM launches)") if args.fp8 else \
-            "gemm_sp_kernel (bf16 MFMA 32x32x16; 192x256x64 and 192x128x64 8-wave / 128-192x128x64 4-wave tiles, LDS-DMA staging)"
+            "gemm_sp_kernel (bf16 MFMA 16x16x32; 192x256x64 and 192x128x64 8-wave / 128-192x128x64 4-wave tiles, LDS-DMA staging)"
         result["roofline"] = {"bound": "mfma", "kernel": kname,
                               "achieved": gemm_tf, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tf / peak,
                               "traffic": None, "gemm_ms_per_pass": p["gemm_ms"], "gemm_launches_per_pass": p["gemm_launches"],

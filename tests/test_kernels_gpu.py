@@ -56,6 +56,36 @@ def test_gemm_store(lib, gpu_device, M, N, K):
     assert torch.equal(outb, ref2.to(torch.bfloat16)) or float((outb.float() - ref2).abs().max() / ref2.abs().max()) < 8e-3
 
 
+def test_gemm_k_rotation_modes(lib, gpu_device):
+    """include/ace355.h ace355_gemm_set_k_rotation: the one-round launches walk K rotated by (XCD of the tile) * nk / 8.  Every mode must
+    give the same product up to the fp32 summation order (every K slice visited exactly once from every starting point), the rotated
+    order must really differ from the plain one on a chip-filling launch, and each mode is bit-reproducible."""
+    from ace355 import native
+    M, N, K = 6000, 2048, 2048   # 256 tiles of 192x256: one round, every XCD its own rotation
+    g = torch.Generator().manual_seed(77)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    W = _bf(torch.randn(N, K, generator=g) * 0.05 + torch.arange(N)[:, None] * 1e-3).to(gpu_device)
+    ref = A.float() @ W.float().t()
+    outs = {}
+    prev = native.gemm_set_k_rotation(0)
+    try:
+        for mode in (0, 1, 2):
+            native.gemm_set_k_rotation(mode)
+            o1 = torch.empty(M, N, device=gpu_device, dtype=torch.float32)
+            o2 = torch.empty_like(o1)
+            _chk(lib.ace355_gemm_bf16(_p(A), _p(W), _p(o1), M, N, K, 0, None, None))
+            _chk(lib.ace355_gemm_bf16(_p(A), _p(W), _p(o2), M, N, K, 0, None, None))
+            assert torch.equal(o1, o2), f"mode {mode} is not reproducible"
+            assert _rel(o1, ref) < 2e-5, (mode, _rel(o1, ref))
+            outs[mode] = o1
+        assert native.gemm_set_k_rotation(prev) == 2
+    finally:
+        native.gemm_set_k_rotation(prev)
+    d01 = _rel(outs[1], outs[0])
+    print(f"K rotation: mode 1 vs mode 0 rel L2 {d01:.2e} (summation order only), mode 2 vs mode 1 {_rel(outs[2], outs[1]):.2e}")
+    assert 0.0 < d01 < 1e-6, d01          # a different fp32 order (not bit-identical), the same sum
+
+
 @pytest.mark.parametrize("M,N,K,rows", [(375 * 4, 2048, 2048, 375), (60, 256, 256, 20), (130, 256, 768, 65)])
 def test_gemm_residual_gate(lib, gpu_device, M, N, K, rows):
     g = torch.Generator().manual_seed(7)

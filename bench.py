@@ -19,6 +19,7 @@ in HBM, plus `roofline` (dominant kernel = the bf16 MFMA GEMM, HIP-event timed) 
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -360,6 +361,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # Host threads within the container's CPU quota (per rank): torch defaults to half the logical CPUs of the HOST (128 here) while the
+    # cgroup grants 16; the OpenMP teams torch.randn / torch.cat spin up for the per-request noise then burn the quota and the kernel
+    # throttles the process for up to a 100 ms period with the GPU idle (tools/probe/noise_hiccup_probe.py: randn p99 76.7 ms against a
+    # 1.4 ms median; one pass in ~8 took 570-620 ms instead of 475, profiles/r04_bench_invocation_spread_before_gc.txt).
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // max(1, min(world, torch.cuda.device_count())))))
+
     import ace355  # noqa: F401
     from ace355 import dist as a_dist
     from ace355.dit import SLOT_COND, SLOT_NULL, prepare_noise, schedule
@@ -386,17 +393,37 @@ def main():
         pass, inside the timed region (until round 3 it was cached per seed list outside it)."""
         last_local.clear()
         last_local.update(local)
+        tr = [] if trace_passes is not None else None   # ACE355_BENCH_TRACE=1 (diagnostic): host clock + a HIP event after every section
+
+        def mark(name):
+            if tr is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                tr.append((name, time.perf_counter(), ev))
+        mark("start")
         seeds = list(local["seeds"])
         noise = prepare_noise((len(seeds), T, 64), seeds).to(device, non_blocking=True)
+        mark("noise")
         k = local["knobs"]
         ts = schedule(int(k["inference_steps"]), k["shift"])
         dit.set_condition(SLOT_COND, local["enc_rows"][0])
         dit.set_condition(SLOT_NULL, local["null_condition_emb"].reshape(1, -1), L=L)
+        mark("conditions")
         lat = dit.sample(noise, local["context_latents"], ts, guidance_scale=k["guidance_scale"])
+        mark("sampler")
         if vae is None:
+            if tr is not None:
+                trace_passes.append(tr)
             return lat
         wav = vae.decode(lat.transpose(1, 2).contiguous())
-        return peak_normalize(wav)
+        mark("decode")
+        out = peak_normalize(wav)
+        mark("normalize")
+        if tr is not None:
+            trace_passes.append(tr)
+        return out
+
+    trace_passes = [] if os.environ.get("ACE355_BENCH_TRACE", "0") not in ("", "0") else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -424,18 +451,40 @@ def main():
         for _ in range(warmup):
             out = one_pass()
         barrier()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # (recorded, never waited on inside the timed region)
+        # The cyclic collector stays out of the timed passes: a generation-2 sweep of this process's heap (torch + the reference-shaped
+        # state dicts) stops the host for ~55 ms in the middle of a pass with the GPU waiting (ACE355_BENCH_TRACE=1 showed it inside
+        # prepare_noise / set_condition at random: profiles/r04_pass_trace.txt) - the interpreter's housekeeping, not work of the request.
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            marks[i].record()
             out = one_pass()
+        marks[steps].record()
         barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         if world > 1:
             tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             elapsed = float(tt.item())
         assert torch.isfinite(out).all(), "non-finite output"
+        if trace_passes is not None and rank == 0:
+            for n, tr in enumerate(trace_passes[-steps:]):
+                host = " ".join(f"{b[0]} {1e3 * (b[1] - a[1]):.1f}" for a, b in zip(tr, tr[1:]))
+                gpu = " ".join(f"{b[0]} {a[2].elapsed_time(b[2]):.1f}" for a, b in zip(tr, tr[1:]))
+                print(f"[bench trace] pass {n}: host ms: {host} | gpu ms: {gpu} | pass gpu {marks[n].elapsed_time(marks[n + 1]):.1f}", file=sys.stderr)
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+        step_spread.clear()
+        step_spread.update({"min": per[0], "median": per[len(per) // 2], "max": per[-1],
+                            "what": "GPU time between the starts of consecutive passes on rank 0's stream (HIP events); the line's ms_per_step is the "
+                                    "host clock over all passes, MAX over ranks"})
         return G, s1 - s0, elapsed
 
+    step_spread = {}
     other = None
     if world > 1:   # both modes in one run: the headline one last, so that the profiled pass below re-runs ITS per-rank shape
         o_mode = "weak" if args.scaling == "strong" else "strong"
@@ -451,7 +500,7 @@ def main():
         "metric": (f"songs/sec ({args.duration:g} s audio @ {args.infer_steps} DiT steps, CFG {args.guidance:g} + APG, batch {args.batch} "
                    + ("per GPU" if args.scaling == "weak" and world > 1 else "in total") + (", DiT + VAE decode)" if not args.no_vae else ", DiT-only)")),
         "value": value, "unit": "songs/s", "rtf": value * args.duration, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step": 1000.0 * elapsed / args.steps, "step_ms_spread": dict(step_spread), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "mxfp8 (four big projections) + bf16" if args.fp8 else "bf16", "data": "synthetic",
         "config": {"workload": f"acestep-5Hz base DiT (24L/2048d, 1.575B params, random init) + Oobleck decoder, {args.duration:g} s audio "
                                f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward on rank 0), L={L}, "

@@ -291,15 +291,12 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
     ts = schedule(infer_steps, shift, timesteps)
     steps = ts.numel() - 1
     cover_steps = int(steps * audio_cover_strength)
-    if noise is None:
-        noise = prepare_noise((B, T, context_latents.shape[-1] // 2), seed)
-    xt0 = noise
-    if cover_noise_strength > 0.0:  # modeling_acestep_v15_base.py:1879-1900
+    nearest = None
+    if cover_noise_strength > 0.0:  # modeling_acestep_v15_base.py:1879-1900 (the renoised start itself: below, once the noise is drawn)
         eff = 1.0 - cover_noise_strength
         tv = ts[:-1].tolist()
         nearest = min(tv, key=lambda x: abs(x - eff))
         start = tv.index(nearest)
-        xt0 = nearest * noise + (1 - nearest) * src_latents.detach().float().cpu()
         ts = ts[start:]
         steps = ts.numel() - 1
         cover_steps = int(steps * audio_cover_strength)
@@ -329,6 +326,11 @@ def generate_latents(dit: NativeDit, null_condition_emb: torch.Tensor, encoder_h
             dit.set_condition(n_c + 1 + k, enc_nc[r])
         nc_slots = [n_c + 1 + k for k in idx_n]
         ctx_nc = context_latents_non_cover
+    # the per-song noise (CPU generators, the reference's stream) is drawn AFTER the cross-K/V builds were launched: the host draws while
+    # the GPU projects the conditions instead of the GPU waiting for the draw (1.3 ms per 8-song request)
+    if noise is None:
+        noise = prepare_noise((B, T, context_latents.shape[-1] // 2), seed)
+    xt0 = noise if nearest is None else nearest * noise + (1 - nearest) * src_latents.detach().float().cpu()
     t1 = time.time()
     if use_adg and B > 1:
         # the reference's adg_forward only broadcasts for batch 1 (apg_guidance.py:150-168 multiplies [n*t,1] by [n,t,c])

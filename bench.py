@@ -401,14 +401,14 @@ def main():
                 ev.record()
                 tr.append((name, time.perf_counter(), ev))
         mark("start")
-        seeds = list(local["seeds"])
-        noise = prepare_noise((len(seeds), T, 64), seeds).to(device, non_blocking=True)
-        mark("noise")
         k = local["knobs"]
         ts = schedule(int(k["inference_steps"]), k["shift"])
         dit.set_condition(SLOT_COND, local["enc_rows"][0])
         dit.set_condition(SLOT_NULL, local["null_condition_emb"].reshape(1, -1), L=L)
         mark("conditions")
+        seeds = list(local["seeds"])   # (drawn while the GPU builds the cross-K/V: the order of ace355.dit.generate_latents)
+        noise = prepare_noise((len(seeds), T, 64), seeds).to(device, non_blocking=True)
+        mark("noise")
         lat = dit.sample(noise, local["context_latents"], ts, guidance_scale=k["guidance_scale"])
         mark("sampler")
         if vae is None:

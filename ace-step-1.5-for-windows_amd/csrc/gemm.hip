@@ -1540,9 +1540,11 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
             const bool fused = fuse && variant != 1 && (big != 2 || mid_ns4 == 3) && ep.wide_ok && N % tw == 0 && ep.hn_q_cols % tw == 0 &&
                                ep.hn_qk_cols % tw == 0;
             static int vt_env = -1;
-            if (vt_env < 0) vt_env = env_int("ACE355_GEMM_VT", 1);   // 0: always the separate transpose_v launch (A/B)
-            // V^T from the epilogue: only where the v tiles are few (4-wave / mid tiles of the small-M launches)
-            if (!(fused && vt_env && big != 1 && ep.vt_out && ep.vt_ld > 0 && ep.vt_heads > 0 && (N - ep.hn_qk_cols) == ep.vt_heads * 128)) ep.vt_out = nullptr;
+            if (vt_env < 0) vt_env = env_int("ACE355_GEMM_VT", 2);   // 0: always the separate transpose_v launch (A/B); 1: not on the 192x256 tiles
+            // V^T from the epilogue.  Round 3 kept it to the small-M launches; on the big persistent tiles it is free as well: the v tiles'
+            // epilogue is a plain store (4 k cycles against 17 k for the q / k tiles' head-norm + RoPE) and the XCDs that own the v columns
+            // finish ~9 us before the others, so their 2-byte V^T stores hide there and the transpose_v launch goes (- 4.9 ms per 8-song pass)
+            if (!(fused && vt_env && (big != 1 || vt_env >= 2) && ep.vt_out && ep.vt_ld > 0 && ep.vt_heads > 0 && (N - ep.hn_qk_cols) == ep.vt_heads * 128)) ep.vt_out = nullptr;
             if (ep.vt_done) *ep.vt_done = ep.vt_out ? 1 : 0;
             if (fused) {
                 launch_mode<4>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg);

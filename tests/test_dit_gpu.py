@@ -518,7 +518,8 @@ def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_pat
 
 
 def test_vt_from_the_qkv_epilogue_equals_the_transpose_kernel(gpu_device, golden_dir, tmp_path):
-    """Small-M QKV GEMMs write V^T straight from their accumulators (GemmEpilogue::vt_out; ACE355_GEMM_VT=0 keeps the transpose_v launch).
+    """The QKV GEMMs write V^T straight from their accumulators (GemmEpilogue::vt_out; ACE355_GEMM_VT=0 keeps the transpose_v launch, 1 the
+    epilogue path for the small / mid tiles only, 2 = default: also the persistent 192x256 tiles of the metric batch).
     The values are the same bf16 roundings of the same accumulators either way: the reference golden forward in one fresh process per
     setting must agree BIT for bit (odd S = 33 keys per sequence in case "a": pad positions and sequence boundaries inside a tile)."""
     import os
@@ -541,14 +542,25 @@ def test_vt_from_the_qkv_epilogue_equals_the_transpose_kernel(gpu_device, golden
         "    for n in range(x.shape[0]): dit.set_condition(n, enc[n])\n"
         "    for rep in range(2):\n"
         "        outs.append(dit.forward(x, ctx, t.tolist(), t.tolist(), list(range(x.shape[0]))).float().cpu().reshape(-1))\n"
+        "# the metric's launch shape on a 2-layer model of full width: 16 sequences x 375 tokens = 6000 rows -> the persistent 192x256 tiles,\n"
+        "# whose v tiles write V^T too (ACE355_GEMM_VT=2, the default); sequence boundaries (375 rows) fall inside the 96-row wave tiles\n"
+        "cfg = ace355.DitConfig(num_hidden_layers=2)\n"
+        "dit = NativeDit(cfg, 'cuda:0')\n"
+        "dit.load_state_dict(weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=3, mode='test'))\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "x = torch.randn(16, 750, 64, generator=g); ctx = torch.randn(16, 750, 128, generator=g); enc = torch.randn(2, 40, cfg.hidden_size, generator=g)\n"
+        "for n in range(2): dit.set_condition(n, enc[n])\n"
+        "big = dit.forward(x, ctx, [0.7] * 16, [0.7] * 16, [0] * 8 + [1] * 8).float().cpu().reshape(-1)\n"
+        "assert torch.isfinite(big).all() and float(big.abs().mean()) > 1e-3\n"
+        "outs.append(big)\n"
         "np.save(sys.argv[1], torch.cat(outs).numpy())\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f"{golden_dir}/g2_tiny_forward.npz")
     outs = {}
-    for flag in ("1", "0"):
+    for flag in ("2", "1", "0"):
         out = str(tmp_path / f"vt{flag}.npy")
         subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, ACE355_GEMM_VT=flag), timeout=600)
         outs[flag] = torch.from_numpy(np.load(out))
-    assert torch.isfinite(outs["1"]).all() and torch.equal(outs["1"], outs["0"])
+    assert torch.isfinite(outs["2"]).all() and torch.equal(outs["2"], outs["0"]) and torch.equal(outs["1"], outs["0"])
 
 
 def test_torch_library_ops_match_direct_calls(gpu_device):

@@ -440,7 +440,9 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         // window load of the un-prefetched form costs more than the sharing saves (-5 % / -35 %)
         // (the 2-tap transposed / strided convs are faster on the 4-wave tile at every stage: 1.31 / 1.34 / 1.46 ms against
         //  1.44 / 1.50 / 1.83 ms)
-        const bool tall = tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 3);
+        // (the fused k = 1 stage of a residual unit is written for the 4-wave 128-row tile only: forcing the tall tile onto it with
+        //  ACE355_CONV_TM=256 gave a - 6 dB decode, caught by test_decode_at_the_metric_length_vs_oracle; it is refused here)
+        const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 3));
         if (tall) {
             dim3 grid((a.M + 255) / 256, (a.N + 127) / 128, a.B);
             hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);

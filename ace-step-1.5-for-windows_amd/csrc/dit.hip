@@ -149,7 +149,8 @@ struct ace355_dit {
     // CONTEXT: a second ace355_dit that aliases this handle's weights and condition slots and owns its workspace and schedule tables.
     struct Dual {
         int mode = 1;                 // ACE355_DUAL / ace355_dit_set_dual: 0 one chain; 1 (default) two chains for requests of >= 2 songs whose
-                                      // one-chain launches would under-fill the chip (<= max_rows token rows in all); 2 two chains whenever >= 2 songs
+                                      // one-chain launches would under-fill the chip (<= max_rows token rows in all, or a tile count that leaves
+                                      // > 15 % of the CU slots of its rounds empty: ace355_dit_sample); 2 two chains whenever >= 2 songs
         int max_rows = 2400;          // ACE355_DUAL_MAX_ROWS (token rows of the whole request, CFG copies included).  Measured (same-box ABAB x 2-3,
                                       // 30 s songs, DiT + decode, ms per request, one chain -> two): 2 songs (1500 rows) 201.2 -> 197.5 (and 207.1 ->
                                       // 199.1, 209.8 -> 201.0 on other boxes), 3 songs (2250 rows: 12 row tiles, an awkward fill) 275.9 -> 253.3,
@@ -1284,7 +1285,17 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     int nchains = 1;
     // (under graph replay the two chains become two branches of one graph, which the runtime places on streams of its own choosing:
     //  measured 281 ms against 214 ms for the one-chain graph at 2 songs - the default policy keeps a captured call on one chain)
-    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || (N * S <= h->dual.max_rows && !graph))) {
+    // (default policy, round 4 late: two chains when ONE chain's launches would leave part of the chip without a tile.  fill = share of the
+    //  CU slots of the rounds a one-chain N = 2048 launch needs that hold a tile: 16 column tiles of the 192x128 mid tile up to 3072 rows, 8 of
+    //  the 192x256 tile above.  Same-box ABAB, 30 s songs with decode, one chain -> two: 2 songs 198.7 -> 194.5 ms, 3: 266.1 -> 251.0, 4 (fill
+    //  1.0): 290.4 -> 303.5, 5 (0.63): 397.0 -> 362.7, 6 (0.75): 430.4 -> 408.9, 7 (0.88): 461.0 -> 457.6 on one box and 451.9 -> 460.5 on
+    //  another (hence the 0.85), 8 (1.0): 486.7 -> 518.5, 9 (0.56): 657.6 -> 581.9, 10 (0.63): 681.9 -> 654.0: profiles/r04_dual_policy_quiet_ab.txt)
+    auto one_chain_fill = [](long rows) -> double {
+        const long tiles = ((rows + 191) / 192) * (rows <= 3072 ? 16 : 8);
+        return (double)tiles / (double)(((tiles + 255) / 256) * 256);
+    };
+    const bool under_filled = (long)N * S <= h->dual.max_rows || one_chain_fill((long)N * S) < 0.85;
+    if (h->dual.mode && B >= 2 && !taps && h->fk.side && (h->dual.mode >= 2 || (under_filled && !graph))) {
         int rc0 = dual_probe_streams(h, run_s);
         if (rc0) return rc0;
         if (h->dual.concurrent) nchains = 2;

@@ -176,10 +176,12 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
  * per-item CFG / APG; base.py:1783-1989), so a call with B >= 2 songs can run as TWO half-batch samplers - songs [0, ceil(B/2)) on the
  * caller's stream, the rest on a side stream that sits on a hardware queue of its own (checked once per caller stream: the runtime
  * shares a few queues between all streams, and two streams on one queue run strictly in turn).  mode 0: one chain; 1 (default,
- * ACE355_DUAL): two chains when one chain's launches would under-fill the chip (<= 2400 token rows in the whole request,
- * ACE355_DUAL_MAX_ROWS: 2-3 songs of 30 s under CFG) - there one chain's launches fill the CUs the other leaves idle (2 x 30 s:
- * 201 -> 197 ms per request incl. decode, 3 x 30 s: 276 -> 253 ms); 2: two chains whenever B >= 2 (4 songs: 300 -> 315 ms, the
- * metric batch of 8: 508 -> 513-528 ms: both chains sit at the power cap).  Each song's
+ * ACE355_DUAL): two chains when one chain's launches would under-fill the chip: <= 2400 token rows in the whole request
+ * (ACE355_DUAL_MAX_ROWS: 2-3 songs of 30 s under CFG), or a row count whose tiles leave more than 15 % of the CU slots of their
+ * rounds empty (30 s songs: 5, 6, 9, 10 per request; not 4, 7, 8) - there one chain's launches fill the CUs the other leaves idle (per
+ * request incl. decode, one chain -> two: 2 x 30 s 199 -> 194 ms, 3: 266 -> 251, 5: 397 -> 358, 6: 430 -> 409, 9: 658 -> 582);
+ * 2: two chains whenever B >= 2 (4 songs: 290 -> 304 ms, the metric batch of 8: 487 -> 519 ms: one chain already gives every CU a
+ * tile and the two chains only share the power cap).  Each song's
  * result is what a one-chain call with that song's half-batch returns.  Captured like any other launch under ace355_dit_set_graph.
  * dual_count: calls that ran as two chains so far. */
 int ace355_dit_set_dual(ace355_dit* h, int mode);

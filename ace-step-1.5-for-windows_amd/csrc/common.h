@@ -311,6 +311,14 @@ struct ConvArgs {
     // fused residual unit (Cin = N = 128, plain conv): y = res + bias2 + w2 . snake2(conv(x) + bias), w2 [N][1][N]: the k = 1
     // conv of an OobleckResidualUnit applied to the k = 7 result while it is still in the workgroup (LDS), launch_conv decides
     const bf16_t* w2; const float* bias2; const float* alpha2; const float* beta2;
+    // Snake of the CONSUMER applied by the producer (out_mode 0): y = snake(bias + conv + res) with per-output-channel parameters
+    // [N] (exp(alpha), 1 / (exp(beta) + 1e-9)), for activations whose only reader is one Snake -> conv (the k = 7 result of an unfused
+    // residual unit, a block's last unit / conv1 ahead of a transposed conv, the last unit ahead of the output conv): the Snake is
+    // evaluated once per element from the fp32 sum instead of once per (column tile, halo) of the reader from the bf16-rounded one
+    const float* osnake_a; const float* osnake_b;
+    // set by launch_conv: XCD-aware rasterisation of the (row block, column tile) grid (ras_tn > 1: a 1-D grid of ras_tm * ras_tn
+    // workgroups per batch item, the column tiles of one row block on consecutive slots of ONE XCD); 0: the plain (m, n, b) grid
+    int ras_tm; int ras_tn;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s);

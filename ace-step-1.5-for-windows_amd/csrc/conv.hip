@@ -69,7 +69,25 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     const int lq = lane & 31, half = lane >> 5;
     const int wm = (BN == 128) ? (wave >> 1) : wave;
     const int wn = (BN == 128) ? (wave & 1) : 0;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    // Rasterisation.  Workgroups are handed to the 8 XCDs round-robin by linear id, each XCD has its own L2, and with the plain (m, n, b)
+    // grid the column tiles of one row block are tiles_m launches-slots apart: every one of them pulled the same input window from HBM
+    // (2x at C = 256 ... 8x at C = 1024 for the k = 1 convs, s * Cout / 128 times for the transposed ones).  With ras_tn > 1 the grid is
+    // 1-D per batch item and ids 8q + r (r = XCD) walk the column tiles of row block (q / tn) * 8 + r on consecutive slots of XCD r:
+    // they are resident together and share the window through that XCD's L2.  Same tiles, same arithmetic: results are bit-identical.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.ras_tn > 1) {  // workgroup-uniform
+        const int L = blockIdx.x, tn = a.ras_tn, full = (a.ras_tm >> 3) << 3;
+        if (L < full * tn) {
+            const int q = L >> 3;
+            by = q % tn;
+            bx = (q / tn) * 8 + (L & 7);
+        } else {  // the last (tiles_m % 8) row blocks: column tiles adjacent in time, XCDs as they come
+            const int l2 = L - full * tn;
+            by = l2 % tn;
+            bx = full + l2 / tn;
+        }
+    }
+    const int m0 = bx * TM, n0 = by * BN, b = blockIdx.z;
     const int Cin = a.Cin, taps = a.taps, dil = a.dil;
     const int win_rows = TM + (taps - 1) * dil;
     const int x_row0 = m0 - a.center * dil;
@@ -344,6 +362,14 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     *reinterpret_cast<float4*>(stg + row * 128 + ((slot ^ (row & 7)) << 4)) = v;
                 }
             if (has_res && j + 1 < NT) res_load(j + 1, rv[(j + 1) & 1]);
+            u32x4 oa[2], ob[2];   // the consumer's Snake parameters of this lane's 8 columns (fp32 bits)
+            if (a.osnake_a) {     // workgroup-uniform
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    oa[q] = ld_u32x4(a.osnake_a + nw0 + j * 32 + c4 * 8 + 4 * q);
+                    ob[q] = ld_u32x4(a.osnake_b + nw0 + j * 32 + c4 * 8 + 4 * q);
+                }
+            }
             const long col = (long)b * a.y_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
             const float bias[8] = {__uint_as_float(bl[j][0]), __uint_as_float(bl[j][1]), __uint_as_float(bl[j][2]), __uint_as_float(bl[j][3]),
                                    __uint_as_float(bh[j][0]), __uint_as_float(bh[j][1]), __uint_as_float(bh[j][2]), __uint_as_float(bh[j][3])};
@@ -358,6 +384,13 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     const u32x4 r = rv[j & 1][t];
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2) { v[2 * e2] += bf_lo(r[e2]); v[2 * e2 + 1] += bf_hi(r[e2]); }
+                }
+                if (a.osnake_a) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float sn = __sinf(__uint_as_float(oa[e >> 2][e & 3]) * v[e]);
+                        v[e] = v[e] + __uint_as_float(ob[e >> 2][e & 3]) * sn * sn;
+                    }
                 }
                 u32x4 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                 *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + col + (long)(mw0 + row) * a.N) = pk;
@@ -382,6 +415,10 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     const long flat = (long)m * a.N + n + a.y_shift;
                     if (flat < 0 || flat >= a.y_valid) continue;
                     if (a.res) v += bf2f(a.res[(long)b * a.res_batch_stride + flat]);
+                    if (a.osnake_a) {
+                        const float sn = __sinf(a.osnake_a[n] * v);
+                        v = v + a.osnake_b[n] * sn * sn;
+                    }
                     reinterpret_cast<bf16_t*>(a.y)[(long)b * a.y_batch_stride + flat] = f2bf(v);
                 } else {  // f32 NCL [b][n][m]
                     if (n < a.n_real) {
@@ -418,13 +455,19 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
                         (reinterpret_cast<uintptr_t>(a.alpha2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.beta2) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w2) & 15) == 0),
               "conv: the fused k = 1 stage needs Cin = N = 128, a plain conv and 16-byte aligned vectors");
+    ACE_CHECK(!a.osnake_a == !a.osnake_b && (!a.osnake_a || a.out_mode == 0), "conv: the producer-side Snake needs both parameter vectors and the bf16 output");
     ConvArgs aw = a;
     {
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && al16(a.bias) && al16(a.bias2) && (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
+        aw.wide_ok = a.out_mode == 0 && al16(a.y) && al16(a.res) && al16(a.bias) && al16(a.bias2) && al16(a.osnake_a) && al16(a.osnake_b) &&
+                     (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
                      (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
     }
-    static int tm_env = -1, clk_env = -1;
+    static int tm_env = -1, clk_env = -1, ras_env = -1;
+    if (ras_env < 0) {
+        const char* e = getenv("ACE355_CONV_RAS");  // 0: the plain (m, n, b) grid (A/B runs); default 1: XCD-aware rasterisation
+        ras_env = e ? atoi(e) : 1;
+    }
     if (clk_env < 0) {
         const char* e = getenv("ACE355_CONV_CLK");
         clk_env = e ? atoi(e) : 0;
@@ -443,14 +486,17 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         // (the fused k = 1 stage of a residual unit is written for the 4-wave 128-row tile only: forcing the tall tile onto it with
         //  ACE355_CONV_TM=256 gave a - 6 dB decode, caught by test_decode_at_the_metric_length_vs_oracle; it is refused here)
         const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 3));
-        if (tall) {
-            dim3 grid((a.M + 255) / 256, (a.N + 127) / 128, a.B);
-            hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);
-        } else {
-            dim3 grid((a.M + 127) / 128, (a.N + 127) / 128, a.B);
-            hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(256), 0, s, aw);
+        const int tm_rows = tall ? 256 : 128;
+        dim3 grid((a.M + tm_rows - 1) / tm_rows, (a.N + 127) / 128, a.B);
+        aw.ras_tm = aw.ras_tn = 0;
+        if (ras_env && grid.y > 1 && (long)grid.x * grid.y < (1L << 31)) {
+            aw.ras_tm = (int)grid.x, aw.ras_tn = (int)grid.y;
+            grid = dim3(grid.x * grid.y, 1, a.B);
         }
+        if (tall) hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);
+        else hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(256), 0, s, aw);
     } else {
+        aw.ras_tm = aw.ras_tn = 0;
         dim3 grid((a.M + 127) / 128, (a.N + 31) / 32, a.B);
         hipLaunchKernelGGL((conv_kernel<32, 128>), grid, dim3(256), 0, s, aw);
     }

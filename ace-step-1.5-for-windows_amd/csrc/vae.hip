@@ -515,7 +515,21 @@ int ace355_vae_finalize(ace355_vae* h) {
 int ace355_vae_hop(const ace355_vae* h) { return h ? h->hop : 0; }
 
 // Residual unit in place on `state` (scratch `tmp`), shared by decode and encode: x + conv_k1(snake2(conv_k7_dil(snake1(x))))
-static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t*& tmp, int B, long L, int C, hipStream_t s) {
+// ACE355_VAE_EPISNAKE (default 1): the Snake of an activation with ONE reader is applied by its producer's epilogue (ConvArgs::osnake_a):
+// snake2 of an unfused residual unit by the k = 7 conv (the k = 1 conv then stages plain rows: it evaluated the Snake once per 128-column
+// tile, 2 / 4 / 8 times per element at C = 256 / 512 / 1024), the next block's (or the output conv's) Snake by a decoder block's last unit
+// and by conv1 (the 2-tap transposed convs evaluated it s * Cout / 128 = 80 / 24 / 8 / 4 / 2 times per element).  0: every Snake in its
+// reader's window staging (A/B runs).  `out_snake`: the reader's Snake when the unit's output has that single reader, else null.
+static int episnake_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("ACE355_VAE_EPISNAKE");
+        on = e ? atoi(e) : 1;
+    }
+    return on;
+}
+static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t*& tmp, int B, long L, int C, hipStream_t s,
+                        const SnakeP* out_snake = nullptr) {
     static int fuse = -1;
     if (fuse < 0) {
         const char* e = getenv("ACE355_CONV_FUSE_RU");  // 0: two launches per unit everywhere (A/B runs)
@@ -533,6 +547,7 @@ static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t
         f.y = tmp; f.y_batch_stride = L * C;
         f.B = B; f.M = (int)L; f.N = C; f.taps = 7; f.dil = R.dil; f.center = 3;
         f.y_shift = 0; f.y_valid = L * C; f.out_mode = 0;
+        if (out_snake) f.osnake_a = out_snake->ea, f.osnake_b = out_snake->ib;
         const int rcf = run_conv(h, f, s);
         if (rcf) return rcf;
         std::swap(state, tmp);
@@ -544,11 +559,15 @@ static int run_res_unit(ace355_vae* h, const ResUnitW& R, bf16_t*& state, bf16_t
     a.y = tmp; a.y_batch_stride = L * C;
     a.B = B; a.M = (int)L; a.N = C; a.taps = 7; a.dil = R.dil; a.center = 3;
     a.y_shift = 0; a.y_valid = L * C; a.out_mode = 0;
+    const bool epi = episnake_on() != 0;
+    if (epi) a.osnake_a = R.s2.ea, a.osnake_b = R.s2.ib;   // tmp = snake2(conv_k7(...)): its only reader is the k = 1 conv below
     int rc = run_conv(h, a, s);
     if (rc) return rc;
     a = ConvArgs{};
     a.x = tmp; a.x_batch_stride = L * C; a.L_in = (int)L; a.Cin = C;
-    a.w = R.c2.w; a.bias = R.c2.bias; a.alpha = R.s2.ea; a.beta = R.s2.ib;
+    a.w = R.c2.w; a.bias = R.c2.bias;
+    if (!epi) a.alpha = R.s2.ea, a.beta = R.s2.ib;
+    if (out_snake) a.osnake_a = out_snake->ea, a.osnake_b = out_snake->ib;
     a.res = state; a.res_batch_stride = L * C;
     a.y = state; a.y_batch_stride = L * C;
     a.B = B; a.M = (int)L; a.N = C; a.taps = 1; a.dil = 1; a.center = 0;
@@ -598,20 +617,26 @@ static int decode_window(ace355_vae* h, int b0, int nb, int T, int ws, int we, i
     a.y = cur; a.y_batch_stride = (long)Tw * h->conv1.N;
     a.B = nb; a.M = Tw; a.N = h->conv1.N; a.taps = 7; a.dil = 1; a.center = 3;
     a.y_shift = 0; a.y_valid = (long)Tw * h->conv1.N; a.out_mode = 0;
+    const bool epi = episnake_on() != 0 && !h->blocks.empty();
+    if (epi) a.osnake_a = h->blocks[0].s1.ea, a.osnake_b = h->blocks[0].s1.ib;   // conv1's only reader: block 0's Snake -> transposed conv
     if ((rc = run_conv(h, a, s))) return rc;
 
-    for (const BlockW& Bk : h->blocks) {
+    for (size_t bi = 0; bi < h->blocks.size(); ++bi) {
+        const BlockW& Bk = h->blocks[bi];
+        // the Snake of whoever reads this block's output (the next block's transposed conv, or the output conv): applied by the last unit
+        const SnakeP* next_snake = !epi ? nullptr : (bi + 1 < h->blocks.size() ? &h->blocks[bi + 1].s1 : &h->s_out);
         const long Lout = (L - 1) * Bk.stride - 2 * Bk.pad + 2 * Bk.stride;
         // snake -> ConvTranspose1d as the 2-tap polyphase GEMM (vae_model.py:136-137)
         a = ConvArgs{};
         a.x = cur; a.x_batch_stride = L * Bk.cin; a.L_in = (int)L; a.Cin = Bk.cin;
-        a.w = Bk.ct.w; a.bias = Bk.ct.bias; a.alpha = Bk.s1.ea; a.beta = Bk.s1.ib;
+        a.w = Bk.ct.w; a.bias = Bk.ct.bias;
+        if (!epi) a.alpha = Bk.s1.ea, a.beta = Bk.s1.ib;   // (epi: `cur` already holds snake(x), written by its producer)
         a.y = nxt; a.y_batch_stride = Lout * Bk.cout;
         a.B = nb; a.M = (int)L + 1; a.N = Bk.ct.N; a.taps = 2; a.dil = 1; a.center = 1;
         a.y_shift = -(long)Bk.pad * Bk.cout; a.y_valid = Lout * Bk.cout; a.out_mode = 0;
         if ((rc = run_conv(h, a, s))) return rc;
         for (int j = 0; j < 3; ++j)  // x + conv_k1(snake2(conv_k7_dil(snake1(x)))), in place on the block state (vae_model.py:79-87)
-            if ((rc = run_res_unit(h, Bk.ru[j], nxt, tmp, nb, Lout, Bk.cout, s))) return rc;
+            if ((rc = run_res_unit(h, Bk.ru[j], nxt, tmp, nb, Lout, Bk.cout, s, j == 2 ? next_snake : nullptr))) return rc;
         std::swap(cur, nxt);
         L = Lout;
     }
@@ -619,7 +644,8 @@ static int decode_window(ace355_vae* h, int b0, int nb, int T, int ws, int we, i
     const long hop = h->hop, Lall = hop * T;
     a = ConvArgs{};
     a.x = cur; a.x_batch_stride = L * c.decoder_channels; a.L_in = (int)L; a.Cin = c.decoder_channels;
-    a.w = h->conv2.w; a.bias = nullptr; a.alpha = h->s_out.ea; a.beta = h->s_out.ib;
+    a.w = h->conv2.w; a.bias = nullptr;
+    if (!epi) a.alpha = h->s_out.ea, a.beta = h->s_out.ib;
     a.y = wav_out_dev + (size_t)b0 * c.audio_channels * Lall; a.y_batch_stride = Lall * c.audio_channels;
     a.B = nb; a.M = (int)L; a.N = c.audio_channels; a.taps = 7; a.dil = 1; a.center = 3;
     a.out_mode = 1; a.n_real = c.audio_channels;
@@ -813,15 +839,19 @@ static int encode_group(ace355_vae* h, const float* audio_dev, const float* nois
     a.y_shift = 0; a.y_valid = L * EH; a.out_mode = 0;
     if ((rc = run_conv(h, a, s))) return rc;
     long Lc = L;
-    for (const EncBlockW& Bk : h->e_blocks) {
-        for (int j = 0; j < 3; ++j)
-            if ((rc = run_res_unit(h, Bk.ru[j], cur, tmp, B, Lc, Bk.cin, s))) return rc;
+    const bool epi = episnake_on() != 0;   // (run_res_unit: the Snakes with one reader move to their producers, as in the decoder)
+    for (size_t bi = 0; bi < h->e_blocks.size(); ++bi) {
+        const EncBlockW& Bk = h->e_blocks[bi];
+        for (int j = 0; j < 3; ++j)   // (s1 is tiled `stride` times: its first cin entries are the per-channel parameters)
+            if ((rc = run_res_unit(h, Bk.ru[j], cur, tmp, B, Lc, Bk.cin, s, (epi && j == 2) ? &Bk.s1 : nullptr))) return rc;
         // snake -> Conv1d(k = 2s, stride s) as 2 taps over the shifted view x'[r][c'] = x_flat[(r*s - pad)*cin + c'] (vae_model.py:113-115)
         const long Lo = (Lc + 2 * Bk.pad - 2 * Bk.stride) / Bk.stride + 1;
         a = ConvArgs{};
         a.x = cur; a.x_batch_stride = Lc * Bk.cin; a.L_in = (int)Lo + 1; a.Cin = Bk.stride * Bk.cin;
         a.x_shift = -(long)Bk.pad * Bk.cin; a.x_valid = Lc * Bk.cin;
-        a.w = Bk.cd.w; a.bias = Bk.cd.bias; a.alpha = Bk.s1.ea; a.beta = Bk.s1.ib;
+        a.w = Bk.cd.w; a.bias = Bk.cd.bias;
+        if (!epi) a.alpha = Bk.s1.ea, a.beta = Bk.s1.ib;
+        if (epi && bi + 1 == h->e_blocks.size()) a.osnake_a = h->e_s_out.ea, a.osnake_b = h->e_s_out.ib;   // read by conv2 only
         a.y = nxt; a.y_batch_stride = Lo * Bk.cout;
         a.B = B; a.M = (int)Lo; a.N = Bk.cout; a.taps = 2; a.dil = 1; a.center = 0;
         a.y_shift = 0; a.y_valid = Lo * Bk.cout; a.out_mode = 0;
@@ -833,7 +863,8 @@ static int encode_group(ace355_vae* h, const float* audio_dev, const float* nois
     const int Cl = h->e_conv2.Cin;
     a = ConvArgs{};
     a.x = cur; a.x_batch_stride = Lc * Cl; a.L_in = (int)Lc; a.Cin = Cl;
-    a.w = h->e_conv2.w; a.bias = h->e_conv2.bias; a.alpha = h->e_s_out.ea; a.beta = h->e_s_out.ib;
+    a.w = h->e_conv2.w; a.bias = h->e_conv2.bias;
+    if (!epi || h->e_blocks.empty()) a.alpha = h->e_s_out.ea, a.beta = h->e_s_out.ib;
     a.y = h->e_head; a.y_batch_stride = (long)EH * Lc;
     a.B = B; a.M = (int)Lc; a.N = EH; a.taps = 3; a.dil = 1; a.center = 1;
     a.out_mode = 1; a.n_real = EH;

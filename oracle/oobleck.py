@@ -93,35 +93,56 @@ def _bf16(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
-def residual_unit(w: Dict[str, Tensor], p: str, x: Tensor, dilation: int, q=_ident) -> Tensor:
-    """vae_model.py:62-87: x + conv_k1(snake2(conv_k7_dil(snake1(x)))), pad = 3*dilation."""
-    y = q(F.conv1d(q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"])), q(_w(w, p + ".conv1")), w[p + ".conv1.bias"],
-                   dilation=dilation, padding=3 * dilation))
+def residual_unit(w: Dict[str, Tensor], p: str, x: Tensor, dilation: int, q=_ident, qs=None, q_out=None) -> Tensor:
+    """vae_model.py:62-87: x + conv_k1(snake2(conv_k7_dil(snake1(x)))), pad = 3*dilation.
+
+    Rounding points of the bf16-storage emulation: ``q`` after every stored tensor; ``qs`` (default ``q``) on the k = 7 result, whose
+    only reader is snake2; ``q_out`` (default ``q``) on the unit's output.  The HIP path keeps both of the latter in fp32 when the
+    producer's epilogue applies the reader's Snake (``qs = q_out = identity``, emulate_bf16="native").
+    """
+    qs = q if qs is None else qs
+    q_out = q if q_out is None else q_out
+    y = qs(F.conv1d(q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"])), q(_w(w, p + ".conv1")), w[p + ".conv1.bias"],
+                    dilation=dilation, padding=3 * dilation))
     y = F.conv1d(q(snake(y, w[p + ".snake2.alpha"], w[p + ".snake2.beta"])), q(_w(w, p + ".conv2")), w[p + ".conv2.bias"])
-    return q(x + y)
+    return q_out(x + y)
 
 
-def decoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int, q=_ident) -> Tensor:
-    """vae_model.py:119-142: snake -> ConvTranspose1d(k=2s, stride=s, pad=ceil(s/2)) -> res units d=1,3,9."""
+def decoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int, q=_ident, qs=None) -> Tensor:
+    """vae_model.py:119-142: snake -> ConvTranspose1d(k=2s, stride=s, pad=ceil(s/2)) -> res units d=1,3,9.
+
+    The block's output has one reader (the next block's Snake, or the output conv's): it leaves through ``qs``."""
+    qs = q if qs is None else qs
     x = q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"]))
     x = q(F.conv_transpose1d(x, q(_w(w, p + ".conv_t1")), w[p + ".conv_t1.bias"], stride=stride, padding=math.ceil(stride / 2)))
-    x = residual_unit(w, p + ".res_unit1", x, 1, q)
-    x = residual_unit(w, p + ".res_unit2", x, 3, q)
-    x = residual_unit(w, p + ".res_unit3", x, 9, q)
+    x = residual_unit(w, p + ".res_unit1", x, 1, q, qs)
+    x = residual_unit(w, p + ".res_unit2", x, 3, q, qs)
+    x = residual_unit(w, p + ".res_unit3", x, 9, q, qs, qs)
     return x
 
 
-def decode(cfg: VaeConfig, w: Dict[str, Tensor], z: Tensor, emulate_bf16: bool = False) -> Tensor:
+def _rounders(emulate_bf16):
+    """(q, qs): emulate_bf16 False -> no rounding; True -> every stored tensor AND every Snake input rounded to bf16 (the placement of
+    a layer-by-layer bf16 model); "native" -> stored tensors rounded, but a tensor whose only reader is a Snake stays fp32 up to that
+    Snake and only snake(t) is stored - the rounding points of the HIP path (csrc/vae.hip, ConvArgs::osnake_a)."""
+    if not emulate_bf16:
+        return _ident, _ident
+    if emulate_bf16 == "native":
+        return _bf16, _ident
+    return _bf16, _bf16
+
+
+def decode(cfg: VaeConfig, w: Dict[str, Tensor], z: Tensor, emulate_bf16=False) -> Tensor:
     """vae_model.py:190-230: z [B,64,T] -> waveform [B,2,hop*T] (== vae.decode(z).sample).
 
     ``emulate_bf16=True`` rounds weights and every inter-layer activation to bfloat16 (fp32 arithmetic in
     between): the storage precision of the reference's own GPU VAE (handler/memory_utils.py:157-166, bf16 on
-    cuda) and of the HIP path, used to separate kernel error from storage-precision drift.
+    cuda) and of the HIP path, used to separate kernel error from storage-precision drift.  ``"native"``: see _rounders.
     """
-    q = _bf16 if emulate_bf16 else _ident
-    x = q(F.conv1d(q(z), q(_w(w, "decoder.conv1")), w["decoder.conv1.bias"], padding=3))
+    q, qs = _rounders(emulate_bf16)
+    x = qs(F.conv1d(q(z), q(_w(w, "decoder.conv1")), w["decoder.conv1.bias"], padding=3))
     for i, (_cin, _cout, s) in enumerate(cfg.block_dims()):
-        x = decoder_block(w, f"decoder.block.{i}", x, s, q)
+        x = decoder_block(w, f"decoder.block.{i}", x, s, q, qs)
     x = q(snake(x, w["decoder.snake1.alpha"], w["decoder.snake1.beta"]))
     return F.conv1d(x, q(_w(w, "decoder.conv2")), None, padding=3)
 
@@ -160,28 +181,32 @@ def decoder_weight_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
     return shapes
 
 
-def encoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int, q=_ident) -> Tensor:
-    """vae_model.py:92-116: res units d=1,3,9 -> snake -> Conv1d(k=2s, stride=s, pad=ceil(s/2))."""
-    x = residual_unit(w, p + ".res_unit1", x, 1, q)
-    x = residual_unit(w, p + ".res_unit2", x, 3, q)
-    x = residual_unit(w, p + ".res_unit3", x, 9, q)
+def encoder_block(w: Dict[str, Tensor], p: str, x: Tensor, stride: int, q=_ident, qs=None, q_out=None) -> Tensor:
+    """vae_model.py:92-116: res units d=1,3,9 -> snake -> Conv1d(k=2s, stride=s, pad=ceil(s/2)).  ``qs``: rounding of the tensors read by
+    one Snake only (the k = 7 results, the third unit's output); ``q_out``: of the block's output (read by one Snake after the last block)."""
+    qs = q if qs is None else qs
+    q_out = q if q_out is None else q_out
+    x = residual_unit(w, p + ".res_unit1", x, 1, q, qs)
+    x = residual_unit(w, p + ".res_unit2", x, 3, q, qs)
+    x = residual_unit(w, p + ".res_unit3", x, 9, q, qs, qs)
     x = q(snake(x, w[p + ".snake1.alpha"], w[p + ".snake1.beta"]))
-    return q(F.conv1d(x, q(_w(w, p + ".conv1")), w[p + ".conv1.bias"], stride=stride, padding=math.ceil(stride / 2)))
+    return q_out(F.conv1d(x, q(_w(w, p + ".conv1")), w[p + ".conv1.bias"], stride=stride, padding=math.ceil(stride / 2)))
 
 
-def encode_moments(cfg: VaeConfig, w: Dict[str, Tensor], audio: Tensor, emulate_bf16: bool = False) -> Tuple[Tensor, Tensor]:
+def encode_moments(cfg: VaeConfig, w: Dict[str, Tensor], audio: Tensor, emulate_bf16=False) -> Tuple[Tensor, Tensor]:
     """vae_model.py:148-187 + :296-302: audio [B,2,L] -> (mean, std), each [B, 64, L // hop]; std = softplus(scale) + 1e-4."""
-    q = _bf16 if emulate_bf16 else _ident
+    q, qs = _rounders(emulate_bf16)
     x = q(F.conv1d(q(audio), q(_w(w, "encoder.conv1")), w["encoder.conv1.bias"], padding=3))
-    for i, (_cin, _cout, s) in enumerate(cfg.encoder_block_dims()):
-        x = encoder_block(w, f"encoder.block.{i}", x, s, q)
+    dims = cfg.encoder_block_dims()
+    for i, (_cin, _cout, s) in enumerate(dims):
+        x = encoder_block(w, f"encoder.block.{i}", x, s, q, qs, qs if i + 1 == len(dims) else q)
     x = q(snake(x, w["encoder.snake1.alpha"], w["encoder.snake1.beta"]))
     h = F.conv1d(x, q(_w(w, "encoder.conv2")), w["encoder.conv2.bias"], padding=1)
     mean, scale = h.chunk(2, dim=1)
     return mean, F.softplus(scale) + 1e-4
 
 
-def encode(cfg: VaeConfig, w: Dict[str, Tensor], audio: Tensor, noise: Tensor = None, emulate_bf16: bool = False) -> Tensor:
+def encode(cfg: VaeConfig, w: Dict[str, Tensor], audio: Tensor, noise: Tensor = None, emulate_bf16=False) -> Tensor:
     """``vae.encode(audio).latent_dist.sample()`` (handler/vae_encode.py:66): mean + std * noise (noise None -> the mean)."""
     mean, std = encode_moments(cfg, w, audio, emulate_bf16)
     return mean if noise is None else mean + std * noise

@@ -45,15 +45,17 @@ def test_decode_vs_oracle(gpu_device, cfg_kw, B, T):
     assert wav.shape == (B, cfg.audio_channels, cfg.hop * T) and wav.dtype == torch.float32
     o_cfg = o_vae.VaeConfig(**cfg_kw)
     ref = o_vae.decode(o_cfg, w, z)                       # fp32 restatement
-    emu = o_vae.decode(o_cfg, w, z, emulate_bf16=True)    # same restatement, bf16 storage between layers
-    snr_fp32, snr_emu, drift = _snr_db(wav, ref), _snr_db(wav, emu), _snr_db(emu, ref)
+    emu = o_vae.decode(o_cfg, w, z, emulate_bf16=True)    # same restatement, bf16 storage between layers, every Snake input rounded
+    nat = o_vae.decode(o_cfg, w, z, emulate_bf16="native")  # bf16 storage with the HIP path's rounding points (producer-side Snakes)
+    snr_fp32, snr_emu, snr_nat, drift = _snr_db(wav, ref), _snr_db(wav, emu), _snr_db(wav, nat), _snr_db(emu, ref)
     print(f"vae decode {cfg_kw or 'full'} B={B} T={T}: SNR vs fp32 oracle {snr_fp32:.1f} dB, vs bf16-storage oracle "
-          f"{snr_emu:.1f} dB (bf16-storage drift of the oracle itself: {drift:.1f} dB); wav rms {float(ref.pow(2).mean().sqrt()):.3f}")
+          f"{snr_emu:.1f} dB, vs the oracle with the native rounding points {snr_nat:.1f} dB (bf16-storage drift of the oracle itself: "
+          f"{drift:.1f} dB); wav rms {float(ref.pow(2).mean().sqrt()):.3f}")
     # stated tolerance (SURVEY 8d parity gate): the HIP waveform may differ from the fp32 restatement by at most 2x
     # (6 dB) the drift the restatement shows against itself when it stores activations in bf16 ...
     assert snr_fp32 > drift - 6.0, (snr_fp32, drift)
-    # ... and must agree with the bf16-storage restatement (identical rounding points) to >= 30 dB.
-    assert snr_emu > 30.0, snr_emu
+    # ... and must agree with both bf16-storage restatements (layer-by-layer rounding; the native rounding points) to >= 30 dB.
+    assert snr_emu > 30.0 and snr_nat > 30.0, (snr_emu, snr_nat)
 
 
 def test_decode_at_the_metric_length_vs_oracle(gpu_device):
@@ -218,3 +220,34 @@ def test_encode_in_item_groups_under_a_small_budget(gpu_device):
         outs.append(vae.encode(audio, sample=False).cpu())
         vae.close()
     assert outs[0].shape == (3, 64, 20) and torch.equal(outs[0], outs[1])
+
+
+def test_snake_placement_switch_agrees(gpu_device):
+    """ACE355_VAE_EPISNAKE (csrc/vae.hip): 1 (default) applies the Snake of a tensor with one reader in its producer's epilogue (from the
+    fp32 sum), 0 in the reader's window staging (from the stored bf16 tensor) - the same function with one rounding point fewer.  The
+    switch is read once per process, so the other placement runs in a child process; both decodes and both encoder means must agree to
+    the bf16-storage level (>= 35 dB) and differ (the switch really changes the path)."""
+    import subprocess, sys, os, tempfile
+    kw = dict(decoder_channels=64, channel_multiples=(1, 2, 4), downsampling_ratios=(2, 4, 6))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import ace355\nfrom ace355 import weightgen\nfrom ace355.vae import NativeVae\n"
+        "cfg = ace355.VaeConfig(**%r)\n"
+        "w = weightgen.make_vae_weights({**cfg.weight_shapes(), **cfg.encoder_weight_shapes()}, seed=2, mode='test')\n"
+        "vae = NativeVae(cfg, 'cuda:0'); vae.load_state_dict(w)\n"
+        "z = torch.randn(2, 64, 37, generator=torch.Generator().manual_seed(5))\n"
+        "a = 0.3 * torch.randn(2, 2, cfg.hop * 20, generator=torch.Generator().manual_seed(6))\n"
+        "torch.save({'wav': vae.decode(z).cpu(), 'mean': vae.encode(a, sample=False).cpu()}, sys.argv[1])\n" % (root, kw))
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for v in ("0", "1"):
+            path = os.path.join(d, f"o{v}.pt")
+            env = dict(os.environ, ACE355_VAE_EPISNAKE=v)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+            outs[v] = torch.load(path)
+    for k in ("wav", "mean"):
+        snr = _snr_db(outs["1"][k], outs["0"][k])
+        print(f"Snake placement 1 vs 0, {k}: {snr:.1f} dB")
+        assert snr > 35.0, (k, snr)
+        assert not torch.equal(outs["1"][k], outs["0"][k])

@@ -241,6 +241,14 @@ def test_vae_oracle_self_checks():
     z = torch.randn(2, 4, 150)
     y = o_vae.decode(cfg, w, z)
     assert y.shape == (2, 2, cfg.hop * 150)
+    # (i') the two bf16-storage emulations (every layer output rounded / the HIP path's rounding points: a tensor read by one Snake stays
+    # fp32 up to it) restate the same function: both within the bf16-storage distance of the fp32 result, different from each other,
+    # and the fp32 result does not depend on the switch's plumbing (qs / q_out default to q)
+    def _snr(a, b):
+        return float(10 * torch.log10(b.pow(2).sum() / (a - b).pow(2).sum()))
+    y_emu, y_nat = o_vae.decode(cfg, w, z, emulate_bf16=True), o_vae.decode(cfg, w, z, emulate_bf16="native")
+    assert _snr(y_emu, y) > 30.0 and _snr(y_nat, y) > 30.0 and _snr(y_nat, y_emu) > 30.0 and not torch.equal(y_emu, y_nat)
+    assert torch.equal(o_vae.decode(cfg, w, z, emulate_bf16=False), y)
     # (iii) tiled == un-tiled away from fp order once the overlap covers the receptive field
     # (toy strides (4,2): RF ~ 3 + 39/4 + 39/8 ~ 18 latent frames; the real decoder's is ~8 << 64)
     yt = o_tiling.tiled_decode(lambda c: o_vae.decode(cfg, w, c), z, chunk_size=100, overlap=24)

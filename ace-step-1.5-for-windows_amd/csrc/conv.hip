@@ -485,7 +485,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         //  1.44 / 1.50 / 1.83 ms)
         // (the fused k = 1 stage of a residual unit is written for the 4-wave 128-row tile only: forcing the tall tile onto it with
         //  ACE355_CONV_TM=256 gave a - 6 dB decode, caught by test_decode_at_the_metric_length_vs_oracle; it is refused here)
-        const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (wgs128 >= 4096 && a.Cin >= 256 && a.taps >= 3));
+        // Round 4, after the Snake move (the transposed convs stage plain rows now) and a per-launch sweep of the forced heights
+        // (profiles/r04_conv_tile_height_sweep.txt, 8 x 30 s): the k = 7 convs at C = 1024 are 3776 four-wave tiles - below the old 4096
+        // threshold - and run 1076-1097 us on them against 875-897 us on 1888 tall ones: threshold 3072 (six rounds of the 512 resident
+        // four-wave workgroups); the plain-row transposed convs with Cin >= 1024 gain too (782 -> 689 and 1096 -> 1008 us), the ones with
+        // Cin <= 512 lose (1128 -> 1174, 1349 -> 1510, 1660 -> 2112 us) and stay on the four-wave tile, like the k = 1 convs (+ 5-25 %).
+        const bool tall_k = a.Cin >= 256 && a.taps >= 3;
+        const bool tall_t = a.taps == 2 && a.Cin >= 1024 && !a.alpha && !a.x_valid;
+        const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (wgs128 >= 3072 && (tall_k || tall_t)));
         const int tm_rows = tall ? 256 : 128;
         dim3 grid((a.M + tm_rows - 1) / tm_rows, (a.N + 127) / 128, a.B);
         aw.ras_tm = aw.ras_tn = 0;

@@ -487,12 +487,15 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         //  ACE355_CONV_TM=256 gave a - 6 dB decode, caught by test_decode_at_the_metric_length_vs_oracle; it is refused here)
         // Round 4, after the Snake move (the transposed convs stage plain rows now) and a per-launch sweep of the forced heights
         // (profiles/r04_conv_tile_height_sweep.txt, 8 x 30 s): the k = 7 convs at C = 1024 are 3776 four-wave tiles - below the old 4096
-        // threshold - and run 1076-1097 us on them against 875-897 us on 1888 tall ones: threshold 3072 (six rounds of the 512 resident
-        // four-wave workgroups); the plain-row transposed convs with Cin >= 1024 gain too (782 -> 689 and 1096 -> 1008 us), the ones with
+        // threshold - and run 1076-1097 us on them against 875-897 us on 1888 tall ones: (threshold lowered, see below); the plain-row transposed convs with Cin >= 1024 gain too (782 -> 689 and 1096 -> 1008 us), the ones with
         // Cin <= 512 lose (1128 -> 1174, 1349 -> 1510, 1660 -> 2112 us) and stay on the four-wave tile, like the k = 1 convs (+ 5-25 %).
-        const bool tall_k = a.Cin >= 256 && a.taps >= 3;
-        const bool tall_t = a.taps == 2 && a.Cin >= 1024 && !a.alpha && !a.x_valid;
-        const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (wgs128 >= 3072 && (tall_k || tall_t)));
+        // The same sweep at 4 / 2 / 1 songs (profiles/r04_conv_tile_height_sweep_small_batches.txt) shows the size threshold itself was
+        // wrong for the k = 7 convs: the tall tile wins at every batch (one song: 205 -> 190, 259 -> 221, 240 -> 197 us at C = 1024 / 512 /
+        // 256; two songs: 328 -> 254, 450 -> 376 us), down to the 472 four-wave tiles of one 30 s song at C = 1024: threshold 448.  The
+        // plain-row transposed convs with Cin >= 1024 gain from ~ 900 four-wave tiles up (one song, 2048 -> 1024, 480 tiles: 149 -> 170 us).
+        const bool tall_k = a.Cin >= 256 && a.taps >= 3 && wgs128 >= 448;
+        const bool tall_t = a.taps == 2 && a.Cin >= 1024 && !a.alpha && !a.x_valid && wgs128 >= 900;
+        const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (tall_k || tall_t));
         const int tm_rows = tall ? 256 : 128;
         dim3 grid((a.M + tm_rows - 1) / tm_rows, (a.N + 127) / 128, a.B);
         aw.ras_tm = aw.ras_tn = 0;

@@ -6,7 +6,7 @@ OUT=gpurun_out/r04_tall_rule.txt
 LIB=ace-step-1.5-for-windows_amd/csrc/libace355.so
 cp $LIB /tmp/_new.so; cp tools/_ab/lib_prev.so /tmp/_old.so
 {
-for B in 8 8 8 7 4 1; do
+for B in ${BATCHES:-8 8 8 7 4 1}; do
   for v in old new; do
     cp /tmp/_$v.so $LIB
     echo "$v: $(VB=$B python tools/vae_ab_check.py 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')"

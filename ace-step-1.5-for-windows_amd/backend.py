@@ -343,7 +343,12 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         the request is broadcast once, each rank generates its contiguous slice (``ace355.dist.run_request``: 8/4/2/1 songs
         per rank for a batch of 8 on 1/2/4/8 GPUs) and rank 0 returns the payload with all G songs in order (the other ranks
         return theirs).  Every per-request setting (steps, guidance, shift, CFG interval, ADG, ode / sde, explicit timesteps, tiled
-        decode, latent shift / rescale) is rank 0's and travels with the request; ``extra_outputs`` (pred_latents, src_latents, ...)
+        decode, latent shift / rescale, cover strength / cover noise strength) is rank 0's and travels with the request, and so do a cover
+        request's tensors (``src_latents``, ``encoder_hidden_states_non_cover``, ``context_latents_non_cover`` in ``service_kwargs``);
+        any other keyword is refused on every rank.  A song's noise, schedule and conditions do not depend on the rank or the batch it
+        runs in; the low bits of its result do (tile shapes, split-K and the K rotation follow the launch shape, and requests of
+        2-3 / 5-6 songs run as two half-batch chains: ~3e-3 relative L2 between "alone" and "in a batch of 8", both at the reference's
+        distance; ``ace355_gemm_set_k_rotation(0)`` + ``set_dual(0)`` remove the batch dependence among launches of one tile regime).  ``extra_outputs`` (pred_latents, src_latents, ...)
         describe the RETURNING rank's slice ``extra_outputs["song_range"]``, ``audios`` on rank 0 all G songs.  The per-call cap of 8 (handler/service_generate_request.py:12) then holds per rank."""
         if data_parallel:
             import torch.distributed as dist
@@ -428,20 +433,27 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
                     raise ValueError("data_parallel: rank 0 must pass the request tensors")
                 G = max(encoder_hidden_states.shape[0], context_latents.shape[0])
                 if not isinstance(seed, (list, tuple)) or len(seed) != G or any(s is None or int(s) < 0 for s in seed):
-                    raise ValueError("data_parallel: one explicit seed per song is required (per-item generators make a song "
-                                     "independent of the rank it runs on; a scalar seed couples the batch, base.py:1733-1770)")
+                    raise ValueError("data_parallel: one explicit seed per song is required (per-item generators make a song's NOISE "
+                                     "independent of the rank and batch it runs in; a scalar seed couples the batch, base.py:1733-1770)")
                 if G > MAX_BATCH_SIZE * world:
                     raise ValueError(f"batch size {G} exceeds the per-call cap of {MAX_BATCH_SIZE} on {world} ranks")
-                shipped = ("timesteps", "use_tiled_decode", "latent_shift", "latent_rescale")
+                shipped = ("timesteps", "use_tiled_decode", "latent_shift", "latent_rescale", "audio_cover_strength", "cover_noise_strength",
+                           "src_latents", "encoder_hidden_states_non_cover", "context_latents_non_cover")
                 extra = {kk: v for kk, v in local_kwargs.items() if kk not in shipped and v is not None}
                 if extra:
-                    # cover strength / non-cover conditions / source latents are per-call tensors of rank 0 only: the other ranks would
-                    # run their songs without them (advisor r3) - refused on every rank rather than silently diverging
+                    # an argument that does not travel would apply on rank 0 only (advisor r3): refused on every rank rather than
+                    # silently diverging.  Cover / repaint requests DO travel (round 5, advisor r4): strengths as knobs, tensors as items.
                     raise ValueError(f"data_parallel: these arguments are not part of the broadcast request: {sorted(extra)}")
+                for kk in ("audio_cover_strength", "cover_noise_strength"):
+                    if local_kwargs.get(kk) is not None:
+                        knobs = dict(knobs, **{kk: float(local_kwargs[kk])})
                 request = a_dist.pack_request(encoder_hidden_states, context_latents, [int(s) for s in seed], None,
                                               timesteps=local_kwargs.get("timesteps"), use_tiled_decode=float(bool(local_kwargs.get("use_tiled_decode", True))),
                                               latent_shift=float(local_kwargs.get("latent_shift", 0.0)),
-                                              latent_rescale=float(local_kwargs.get("latent_rescale", 1.0)), **knobs)
+                                              latent_rescale=float(local_kwargs.get("latent_rescale", 1.0)),
+                                              src_latents=local_kwargs.get("src_latents"),
+                                              encoder_hidden_states_non_cover=local_kwargs.get("encoder_hidden_states_non_cover"),
+                                              context_latents_non_cover=local_kwargs.get("context_latents_non_cover"), **knobs)
         except Exception as exc:
             err = exc
         # (rank 0 could not even build the request: the others learn it from an empty one)
@@ -457,7 +469,10 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
                 local["encoder_hidden_states"], local["context_latents"], local["seeds"], int(k["inference_steps"]), k["guidance_scale"],
                 k["shift"], "sde" if k["infer_method_sde"] else "ode", local["timesteps"], bool(k["use_tiled_decode"]),
                 k["latent_shift"], k["latent_rescale"], k["cfg_interval_start"], k["cfg_interval_end"],
-                bool(k["use_adg"]), progress if rank == 0 else None, {})
+                bool(k["use_adg"]), progress if rank == 0 else None,
+                dict(audio_cover_strength=k["audio_cover_strength"], cover_noise_strength=k["cover_noise_strength"],
+                     src_latents=local["src_latents"], encoder_hidden_states_non_cover=local["encoder_hidden_states_non_cover"],
+                     context_latents_non_cover=local["context_latents_non_cover"]))
             state["payload"] = payload
             return wavs
 

@@ -701,6 +701,432 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
 // A 32-key-tile form of THIS kernel with two 6-wave workgroups per CU (80 KB each, independent barrier domains) was also measured:
 // self-attention 42.2 vs 29.7 us, cross-attention 38.8 vs 36.7 us - shorter tiles lose on every count; longer ones do not fit.
 
+// ------------------------------------------------------------------------------------------------ rotated key-split kernel (round 5)
+// What attn_gqa_kernel leaves on the table (its ablations above): the waves of a SIMD leave every per-tile barrier IN PHASE - all of
+// them Q K^T, then all softmax arithmetic, then all P V - so the matrix pipe idles through every softmax stretch and the VALU through
+// every MFMA stretch.  Here the phases are fixed by construction: wave w runs on SIMD w & 3 (waves are dealt round-robin), its GROUP
+// is w >> 2, and the three groups walk the same tile sequence rotated by one segment around the (single) per-tile barrier:
+//     group 0:  | QK(i)    SM(i)    PV(i)   |          interval i = between barrier i and barrier i + 1
+//     group 1:  | PV(i-1)  QK(i)    SM(i)   |
+//     group 2:  | SM(i-1)  PV(i-1)  QK(i)   |
+// so each SIMD always has two waves on the matrix pipe and one on the VALU.  Tile i-1's V^T is still read in interval i while tile
+// i+1 lands: K ring of 2 stages, V^T ring of 3 (80 KB).  That leaves 80 KB for Q, i.e. 2 heads x 96 query rows: one workgroup =
+// (sequence, KV head, 96-row q-block) as attn_gqa_kernel<3>, but with TWELVE waves - each (q head, 32-row tile) is shared by two
+// waves that split every 64-key tile into its two 32-key halves (S is 16 registers instead of 32) and keep separate (m, l, O)
+// states, merged through LDS after the loop (each wave finishes half of the head dim).  Per wave and tile: 8 + 8 MFMAs and 16
+// exponentials; per SIMD and tile 1536 cycles of MFMA issue against ~1500 of VALU, running side by side instead of in turn.
+// Tile images, swizzles, the row permutation and the deferred rescale are attn3_kernel's.
+template <int NRT, int ABL = 0>   // 32-row tiles per q head; waves = 2 heads x NRT x 2 key halves.  ABL: diagnostic ablations (build with -DACE355_ATTN_ABL)
+__global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, float scale_log2, float defer_thr) {
+    constexpr int NW = 4 * NRT;
+    constexpr int QB = NRT * 32;
+    constexpr int KST = 16384;                 // one K tile / one V^T tile
+    constexpr int PD = 2;                      // prefetch distance in tiles: interval i requests tile i + PD
+    constexpr int KRING = PD + 1, VRING = PD + 2;
+    constexpr int VOFF = KRING * KST;          // V^T ring behind the K ring
+    constexpr int QOFF = (KRING + VRING) * KST;   // Q slices behind both rings
+    constexpr int NPI = (32 + NW - 1) / NW;    // DMA pieces per wave per tile
+    constexpr int SCR_ML = NW * 8192;          // merge scratch: NW x 8 KB of O halves, then NW x 512 B of (m, l)
+    static_assert(QOFF + 2 * NRT * 8192 >= SCR_ML + NW * 512, "merge scratch must fit the loop's LDS");
+    __shared__ __attribute__((aligned(16))) char smem[QOFF + 2 * NRT * 8192];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int qb, hkv, n;
+    {
+        const int nqb = (a.Sq + QB - 1) / QB;
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        if ((a.Hkv & 7) == 0) {
+            const int hg = a.Hkv >> 3;
+            hkv = xcd + 8 * (j % hg);
+            const int rest = j / hg;
+            qb = rest % nqb;
+            n = rest / nqb;
+        } else {
+            hkv = id % a.Hkv;
+            const int rest = id / a.Hkv;
+            qb = rest % nqb;
+            n = rest / nqb;
+        }
+        if (n >= a.N) return;
+    }
+    const unsigned long long t_entry = a.clk_probe ? clock64() : 0ull;
+    const int grp = wave >> 2;                                   // rotation group (waves w, w + 4, w + 8 share SIMD w & 3)
+    const int hw = wave / (2 * NRT), rr = wave - hw * 2 * NRT;   // q head inside the group
+    const int wr = rr >> 1, kh = rr & 1;                         // 32-row tile inside the block, key half of every tile
+    const int pair = hw * NRT + wr;                              // Q slice shared by the two key halves
+    const int h = hkv * 2 + hw;
+    const int q0 = qb * QB;
+    const int lq = lane & 31, half = lane >> 5;
+    const int qw0 = q0 + wr * 32;
+    const int qrow = qw0 + lq;
+    const int win = a.window < 0 ? (1 << 28) : a.window;
+    const bool wave_live = qw0 < a.Sq;
+    const int skv = __builtin_amdgcn_readfirstlane(a.kv_len ? a.kv_len[n] : a.Skv);   // (uniform: every per-tile predicate below stays on the scalar unit)
+
+    int kt_lo = 0, kt_hi = (skv + KB - 1) / KB;
+    if (a.window >= 0) {
+        kt_lo = max(0, q0 - a.window) / KB;
+        kt_hi = min(kt_hi, (min(skv - 1, q0 + QB - 1 + a.window)) / KB + 1);
+    }
+    kt_lo = __builtin_amdgcn_readfirstlane(kt_lo);
+    kt_hi = __builtin_amdgcn_readfirstlane(kt_hi);
+    const bf16_t* kbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.k_tab[n]) : a.k + (long)n * a.k_seq_stride) + (long)hkv * a.k_head_stride;
+    const bf16_t* vbase = (a.use_tab ? reinterpret_cast<const bf16_t*>(a.vt_tab[n]) : a.vt + (long)n * a.vt_seq_stride) + (long)hkv * a.vt_head_stride;
+
+    // DMA piece p = wave + NW*i (p < 32): p < 16 = K rows 4p..4p+3, else V^T rows 8(p-16)..+7 (see attn3_kernel)
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    unsigned p_voff[NPI], p_voff_tail[NPI];
+    const int tail_key0 = ((a.Skv - 1) / KB) * KB;
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        const int p = wave + NW * i;
+        if (p < 16) {
+            const int key = 4 * p + (lane >> 4);
+            const int j = (lane & 15) ^ (key & 15);
+            p_voff[i] = (unsigned)(key * a.k_row_stride + j * 8) * 2u;
+            p_voff_tail[i] = (unsigned)((min(tail_key0 + key, a.Skv - 1) - tail_key0) * a.k_row_stride + j * 8) * 2u;
+        } else {
+            const int d = 8 * (p - 16) + (lane >> 3);
+            const int jv = (lane & 7) ^ ((d >> 1) & 7);
+            p_voff[i] = p_voff_tail[i] = (unsigned)(d * a.vt_ld + jv * 8) * 2u;
+        }
+    }
+    auto vstage = [&](int kt) {  // V^T ring slot of tile kt (wave-uniform)
+        const int r = kt - kt_lo;
+        return __builtin_amdgcn_readfirstlane(r % VRING);
+    };
+    auto kstage = [&](int kt) {
+        const int r = kt - kt_lo;
+        return __builtin_amdgcn_readfirstlane(r % KRING);
+    };
+    auto issue_piece = [&](int kt, int i) {
+        const int key0 = kt * KB;
+        const bf16_t* kb_s = kbase + (long)key0 * a.k_row_stride;  // uniform
+        const bf16_t* vb_s = vbase + key0;
+        const bool tail = key0 + KB > a.Skv;
+        const int p = wave + NW * i;  // wave-uniform
+        if (p < 16) attn_glds16(tail ? p_voff_tail[i] : p_voff[i], kb_s, lds0 + (unsigned)kstage(kt) * KST + (unsigned)p * 1024u);
+        else if (p < 32) attn_glds16(p_voff[i], vb_s, lds0 + VOFF + (unsigned)vstage(kt) * KST + (unsigned)(p - 16) * 1024u);
+    };
+
+    // the pair's 32 Q rows -> its 8 KB slice (full 256-byte lines, XOR-swizzled chunks): each of the two waves brings four of the rows' eight KB
+    {
+        const bf16_t* qsrc = a.q + (long)n * a.q_seq_stride + h * 128;  // uniform
+        const unsigned qbuf = lds0 + QOFF + (unsigned)pair * 8192u;
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const int i = kh * 4 + i2;
+            const int row_l = 4 * i + (lane >> 4);
+            const int j = (lane & 15) ^ (row_l & 15);
+            const unsigned voff = (unsigned)(min(qw0 + row_l, a.Sq - 1) * a.q_row_stride + j * 8) * 2u;
+            attn_glds16(voff, qsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(qbuf + (unsigned)i * 1024u)));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PD; ++t)
+        if (kt_lo + t < kt_hi) {
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) issue_piece(kt_lo + t, i);
+        }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 sreg;          // S^T of this wave's 32 keys x 32 query rows (group 2 carries it across the barrier)
+    bf16x8 pf[2];         // P^T as the B operand of the two 16-key MFMA steps (group 1 carries it across the barrier)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sreg[r] = 0.f;
+    pf[0] = pf[1] = as_bf16x8(make_uint4(0, 0, 0, 0));
+
+    const int prow = pi23(lq);
+    const int k_row_off = prow * 256 + kh * 8192, k_swz = prow & 15;
+    const int v_row_off = prow * 128, v_swz = (prow >> 1) & 7;
+    const char* qs = smem + QOFF + pair * 8192 + lq * 256;
+    const int q_swz = lq & 15;
+
+    // a (wave, tile) pair with nothing to do: rows past the end, the wave's 32 keys past the valid keys or wholly outside the band
+    auto tile_live = [&](int kt) {
+        const int k0 = kt * KB + 32 * kh;
+        return wave_live && (k0 < skv) && (k0 - (qw0 + 31) <= win) && (qw0 - (k0 + 31) <= win);
+    };
+
+    // ABL bits (diagnostic builds only, results are WRONG; ACE355_ATTN_CLK = 1 + 2 ABL picks the instantiation): 1 = softmax arithmetic off,
+    // 2 = no DMA after the prologue, 4 = no barrier after the second, 8 = no MFMAs, 16 = no fragment reads after the first tile
+    constexpr bool ab_nosm = (ABL & 1) != 0, ab_nodma = (ABL & 2) != 0, ab_nobar = (ABL & 4) != 0, ab_nomma = (ABL & 8) != 0, ab_nold = (ABL & 16) != 0;
+    // Fragment buffers: every wave reads the NEXT segment's fragments while it computes on the current ones (three buffers of 4 x 16 bytes
+    // per lane; the rings keep a tile's data valid across the barrier, so a buffer may be filled in one interval and consumed in the next).
+    bf16x8 f0[4], f1[4], f2[4];
+    auto ld_qk = [&](bf16x8 (&f)[4], int kt, int kb) {   // K fragments f[0..1], Q fragments f[2..3] of contraction steps 2 kb, 2 kb + 1
+        if (ab_nold && kt > kt_lo) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); return; }
+        int kx = (half ^ k_swz) << 4, qx = (half ^ q_swz) << 4;
+        asm volatile("" : "+v"(kx), "+v"(qx));
+        const char* Ks = smem + kstage(kt) * KST + k_row_off;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ks = kb * 2 + u;
+            f[u] = as_bf16x8(*reinterpret_cast<const uint4*>(Ks + ((ks * 32) ^ kx)));
+            f[2 + u] = as_bf16x8(*reinterpret_cast<const uint4*>(qs + ((ks * 32) ^ qx)));
+        }
+    };
+    auto mma_qk = [&](const bf16x8 (&f)[4], bool first) {
+        if (first) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sreg[r] = 0.f;
+        }
+        if (ab_nomma) { sreg[0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f[0]).x ^ __builtin_bit_cast(uint4, f[3]).y); return; }
+        sreg = mfma32(f[0], f[2], sreg);
+        sreg = mfma32(f[1], f[3], sreg);
+    };
+    auto ld_pv = [&](bf16x8 (&f)[4], int kt, int t) {    // V^T fragments of 16-key step t of this wave's 32 keys: f[dt]
+        if (ab_nold && kt > kt_lo) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); return; }
+        int vx = (half ^ v_swz) << 4;
+        asm volatile("" : "+v"(vx));
+        const char* Vs = smem + VOFF + vstage(kt) * KST + v_row_off;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+            f[dt] = as_bf16x8(*reinterpret_cast<const uint4*>(Vs + dt * 4096 + ((kh * 64 + t * 32) ^ vx)));
+    };
+    auto mma_pv = [&](const bf16x8 (&f)[4], int t) {
+        if (ab_nomma) { o[0][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f[0]).x ^ __builtin_bit_cast(uint4, f[3]).y ^ __builtin_bit_cast(uint4, f[1]).z ^ __builtin_bit_cast(uint4, f[2]).w); return; }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(f[dt], t ? pf[1] : pf[0], o[dt]);
+    };
+    auto dma_tile = [&](int kt) {   // this wave's pieces of tile kt (no-op past the last tile)
+        if (kt < kt_hi && !ab_nodma) {
+#pragma unroll
+            for (int i = 0; i < NPI; ++i) issue_piece(kt, i);
+        }
+    };
+    auto seg_sm = [&](int kt) {   // online softmax step on sreg -> pf, (m_run, l_run), O rescaled when the running max moved
+        const int k0 = kt * KB + 32 * kh;
+        const bool interior = (k0 + 32 <= skv) && (qw0 + 31 - k0 <= win) && (k0 + 31 - qw0 <= win);
+        if (!interior) {
+            const int kb0 = k0 + 8 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb0 + 16 * (r >> 3) + (r & 7);
+                const bool ok = (key < skv) & ((unsigned)(qrow - key + win) <= (unsigned)(2 * win));
+                sreg[r] = ok ? sreg[r] : -INFINITY;
+            }
+        }
+        if (ab_nosm) {
+            m_run = 0.f; l_run = 1.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 pb;
+                pb.x = pack_bf2(sreg[8 * t + 0], sreg[8 * t + 1]);
+                pb.y = pack_bf2(sreg[8 * t + 2], sreg[8 * t + 3]);
+                pb.z = pack_bf2(sreg[8 * t + 4], sreg[8 * t + 5]);
+                pb.w = pack_bf2(sreg[8 * t + 6], sreg[8 * t + 7]);
+                pf[t] = as_bf16x8(pb);
+            }
+            return;
+        }
+        float mx = sreg[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sreg[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_tile = mx * scale_log2;
+        const bool move = __any(m_tile - m_run > defer_thr);
+        const float m_new = move ? fmaxf(m_run, m_tile) : m_run;
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = move ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
+        m_run = m_new;
+        // (pairs: v_pk_fma_f32 / v_pk_add_f32 halve the plain VALU work around the 16 exponentials)
+        f32x2_t psum2 = {0.f, 0.f};
+        const f32x2_t sc2 = {scale_log2, scale_log2}, mu2 = {-m_use, -m_use};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2_t x = {sreg[r], sreg[r + 1]};
+            const f32x2_t y = __builtin_elementwise_fma(x, sc2, mu2);
+            const f32x2_t p = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+            sreg[r] = p[0];
+            sreg[r + 1] = p[1];
+            psum2 += p;
+        }
+        l_run = l_run * alpha + (psum2[0] + psum2[1]);
+        if (move && __any(alpha != 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint4 pb;
+            pb.x = pack_bf2(sreg[8 * t + 0], sreg[8 * t + 1]);
+            pb.y = pack_bf2(sreg[8 * t + 2], sreg[8 * t + 3]);
+            pb.z = pack_bf2(sreg[8 * t + 4], sreg[8 * t + 5]);
+            pb.w = pack_bf2(sreg[8 * t + 6], sreg[8 * t + 7]);
+            pf[t] = as_bf16x8(pb);
+        }
+    };
+    // Loads retire in order: before the barrier of tile kt this wave's pieces of tiles <= kt must have landed (first time: its Q rows
+    // too), the PD - 1 tiles requested after it may stay in flight (waves 0-7 own three pieces of a tile, waves 8-11 two).
+    auto tile_sync = [&](int kt) {
+        static_assert(PD == 2 && NW == 12, "the counted waits below are written for one tile in flight and 12 waves");
+        if (ab_nodma && kt > kt_lo + 1) {
+        } else if (kt + 1 < kt_hi) {
+            if (wave < 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (ab_nobar && kt > kt_lo + 1) return;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                      // that tile is complete in LDS; every wave is done with the previous interval
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const bool probe = a.clk_probe && blockIdx.x == 0 && tid == 0;
+    unsigned long long pc0 = 0, pw0 = 0;
+    if (probe) { pc0 = clock64(); pw0 = wall_clock64(); }
+
+#define ROT_SB() __builtin_amdgcn_sched_barrier(0)
+    // one tile's Q K^T from the point where f0 holds contraction batch 0: batches 1, 2 into f1, f2, batch 3 into f0 once it is free
+#define ROT_QK_TAIL(kt)                      \
+    do {                                     \
+        ld_qk(f1, (kt), 1); ld_qk(f2, (kt), 2); \
+        mma_qk(f0, true);                    \
+        ROT_SB();                            \
+        ld_qk(f0, (kt), 3);                  \
+        mma_qk(f1, false); mma_qk(f2, false);\
+        ROT_SB();                            \
+    } while (0)
+    if (grp == 0) {
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            tile_sync(kt);
+            const bool lv = tile_live(kt);
+            if (lv) ld_qk(f0, kt, 0);
+            ROT_SB();
+            if (lv) ROT_QK_TAIL(kt);
+            dma_tile(kt + PD);
+            ROT_SB();
+            if (lv) { ld_pv(f1, kt, 0); ld_pv(f2, kt, 1); mma_qk(f0, false); }
+            ROT_SB();
+            if (lv) seg_sm(kt);
+            ROT_SB();
+            if (lv) { mma_pv(f1, 0); mma_pv(f2, 1); }
+            ROT_SB();
+        }
+    } else if (grp == 1) {
+        bool lvp = false;   // the previous tile's P V is pending (its P^T in pf, its V^T fragments in f1 / f2)
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            tile_sync(kt);
+            const bool lv = tile_live(kt);
+            if (lv) ld_qk(f0, kt, 0);
+            if (lvp) { mma_pv(f1, 0); mma_pv(f2, 1); }
+            ROT_SB();
+            dma_tile(kt + PD);
+            ROT_SB();
+            if (lv) ROT_QK_TAIL(kt);
+            if (lv) { ld_pv(f1, kt, 0); ld_pv(f2, kt, 1); mma_qk(f0, false); }
+            ROT_SB();
+            if (lv) seg_sm(kt);
+            ROT_SB();
+            lvp = lv;
+        }
+        if (lvp) { mma_pv(f1, 0); mma_pv(f2, 1); }
+    } else {
+        bool lvp = false;   // the previous tile's softmax + P V are pending (S^T in sreg, V^T fragments in f1 / f2)
+        for (int kt = kt_lo; kt < kt_hi; ++kt) {
+            tile_sync(kt);
+            const bool lv = tile_live(kt);
+            dma_tile(kt + PD);   // this group opens the interval on the VALU: its pieces go out first
+            ROT_SB();
+            if (lv) ld_qk(f0, kt, 0);
+            if (lvp) seg_sm(kt - 1);
+            ROT_SB();
+            if (lvp) { mma_pv(f1, 0); mma_pv(f2, 1); }
+            ROT_SB();
+            if (lv) ROT_QK_TAIL(kt);
+            if (lv) { ld_pv(f1, kt, 0); ld_pv(f2, kt, 1); mma_qk(f0, false); }
+            ROT_SB();
+            lvp = lv;
+        }
+        if (lvp) {
+            seg_sm(kt_hi - 1);
+            ROT_SB();
+            mma_pv(f1, 0); mma_pv(f2, 1);
+        }
+    }
+#undef ROT_QK_TAIL
+#undef ROT_SB
+
+    if (probe) {
+        g_attn_probe[0] = clock64() - pc0;
+        g_attn_probe[1] = wall_clock64() - pw0;
+        g_attn_probe[2] = 0;
+        g_attn_probe[3] = (unsigned long long)(kt_hi - kt_lo);
+        g_attn_probe[4] = pc0 - t_entry;
+    }
+
+    // ---- merge of the two key halves: wave kh finishes head dims [64 kh, 64 kh + 64) and hands the other half of its O to its partner
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (an empty key range leaves the Q pieces in flight: nothing may land in the scratch later)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();   // every wave is out of the rings and the Q slices: the scratch may overwrite them
+    // (o[] is indexed with compile-time constants only: a run-time index would move the accumulators to scratch memory)
+    auto park = [&](const f32x16& x0, const f32x16& x1) {
+        char* mine = smem + wave * 8192 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            *reinterpret_cast<float4*>(mine + c * 1024) = make_float4(x0[4 * c + 0], x0[4 * c + 1], x0[4 * c + 2], x0[4 * c + 3]);
+            *reinterpret_cast<float4*>(mine + (4 + c) * 1024) = make_float4(x1[4 * c + 0], x1[4 * c + 1], x1[4 * c + 2], x1[4 * c + 3]);
+        }
+    };
+    if (kh == 0) park(o[2], o[3]);
+    else park(o[0], o[1]);
+    *reinterpret_cast<float2*>(smem + SCR_ML + wave * 512 + lane * 8) = make_float2(m_run, l_tot);
+    __syncthreads();   // (with the LDS fence: the partner reads what was just written)
+    const int pw = wave ^ 1;   // partner (the other key half of the same head and row tile)
+    const float2 ml_p = *reinterpret_cast<const float2*>(smem + SCR_ML + pw * 512 + lane * 8);
+    const float m_all = fmaxf(m_run, ml_p.x);
+    const float w_me = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_all);
+    const float w_pa = (ml_p.x == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ml_p.x - m_all);
+    l_tot = l_tot * w_me + ml_p.y * w_pa;
+    const float inv = 1.f / l_tot;
+    const float c_me = w_me * inv, c_pa = w_pa * inv;
+    const char* theirs = smem + pw * 8192 + lane * 16;
+    if (qrow < a.Sq && l_tot == 0.f) {
+        bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 64 * kh + 8 * half;
+        const bf16_t* vm = a.vmean + ((long)n * a.Hkv + hkv) * 128 + 64 * kh + 8 * half;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(op + c * 16) = *reinterpret_cast<const uint4*>(vm + c * 16);
+    } else {
+        bf16_t* op = a.out + (long)n * a.o_seq_stride + (long)qrow * a.o_row_stride + h * 128 + 64 * kh + 8 * half;
+        auto finish = [&](const f32x16& x, int d2) {   // head dims 64 kh + 32 d2 .. + 31 of this lane's row
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 t4 = *reinterpret_cast<const float4*>(theirs + (d2 * 4 + c) * 1024);
+                v[4 * c + 0] = x[4 * c + 0] * c_me + t4.x * c_pa;
+                v[4 * c + 1] = x[4 * c + 1] * c_me + t4.y * c_pa;
+                v[4 * c + 2] = x[4 * c + 2] * c_me + t4.z * c_pa;
+                v[4 * c + 3] = x[4 * c + 3] * c_me + t4.w * c_pa;
+            }
+            if (qrow < a.Sq) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    uint4 pk;
+                    pk.x = pack_bf2(v[8 * g + 0], v[8 * g + 1]);
+                    pk.y = pack_bf2(v[8 * g + 2], v[8 * g + 3]);
+                    pk.z = pack_bf2(v[8 * g + 4], v[8 * g + 5]);
+                    pk.w = pack_bf2(v[8 * g + 6], v[8 * g + 7]);
+                    *reinterpret_cast<uint4*>(op + d2 * 32 + 16 * g) = pk;
+                }
+            }
+        };
+        if (kh == 0) { finish(o[0], 0); finish(o[1], 1); }
+        else { finish(o[2], 0); finish(o[3], 1); }
+    }
+    if (probe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); g_attn_probe[5] = clock64() - t_entry; }
+}
+
 }  // namespace
 
 static int gqa_nwh(const AttnArgs& a) {  // which attn_gqa_kernel instantiation launch_attention picks (0: attn3_kernel)
@@ -742,6 +1168,37 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
     {
         auto units = [&](int nwh) { return (long)a.N * a.Hkv * ((a.Sq + 32 * nwh - 1) / (32 * nwh)); };
         const int nwh = gqa_nwh(a);
+        // rotated key-split kernel (12 waves per 96-row block): where the 6-wave GQA kernel would run (the metric's cross-attention),
+        // ACE355_ATTN_ROT=2 also where the 192- / 128-row kernels would (A/B of the self-attention launches), =0 never
+        static int rot_env = -1;
+        if (rot_env < 0) { const char* e = getenv("ACE355_ATTN_ROT"); rot_env = e ? atoi(e) : 1; }
+        if (nwh && !a.out_q && (rot_env >= 2 || (rot_env == 1 && nwh == 3))) {
+            AttnArgs ap = a;
+            ap.clk_probe = clk;
+            const long total = units(3);
+            const dim3 grid((unsigned)((total + 7) / 8 * 8));
+#ifdef ACE355_ATTN_ABL
+            switch (clk >> 1) {
+#define ROT_ABL_CASE(x) case x: hipLaunchKernelGGL((attn_rot_kernel<3, x>), grid, dim3(768), 0, s, ap, scale_log2, thr); break;
+                ROT_ABL_CASE(1) ROT_ABL_CASE(2) ROT_ABL_CASE(4) ROT_ABL_CASE(8) ROT_ABL_CASE(16) ROT_ABL_CASE(6) ROT_ABL_CASE(7) ROT_ABL_CASE(17)
+                ROT_ABL_CASE(22) ROT_ABL_CASE(23) ROT_ABL_CASE(24) ROT_ABL_CASE(30) ROT_ABL_CASE(31) ROT_ABL_CASE(14) ROT_ABL_CASE(15)
+#undef ROT_ABL_CASE
+                default: hipLaunchKernelGGL((attn_rot_kernel<3, 0>), grid, dim3(768), 0, s, ap, scale_log2, thr);
+            }
+#else
+            hipLaunchKernelGGL((attn_rot_kernel<3, 0>), grid, dim3(768), 0, s, ap, scale_log2, thr);
+#endif
+            ACE_LAUNCH_CHECK();
+            if (clk) {
+                unsigned long long hh[8] = {0};
+                ACE_HIP(hipStreamSynchronize(s));
+                ACE_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_attn_probe), sizeof(hh)));
+                if (hh[1]) fprintf(stderr, "[ace355 attn-rot clk] N=%d Sq=%d Skv=%d win=%d: %.3f GHz, loop %.0f cycles (%.2f us), %.0f cycles/tile; prologue %.0f cycles, whole wave %.0f cycles\n",
+                                   a.N, a.Sq, a.Skv, a.window, (double)hh[0] / ((double)hh[1] * 10.0), (double)hh[0], (double)hh[1] * 0.01,
+                                   (double)hh[0] / (double)hh[3], (double)hh[4], (double)hh[5]);
+            }
+            return 0;
+        }
         if (nwh) {
             AttnArgs ap = a;
             ap.clk_probe = clk;  // bit 0: probe + print; bits 1..3: ablations (attn_gqa_kernel)

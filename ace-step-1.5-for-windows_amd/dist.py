@@ -41,7 +41,7 @@ DEFAULT_CAPACITY_BYTES = 1 << 30
 _DTYPES = [torch.float32, torch.bfloat16, torch.int64, torch.int32, torch.float64]
 _ERR_NONE, _ERR_TOO_BIG, _ERR_BAD_ITEM, _ERR_NO_REQUEST = 0, 1, 2, 3
 # keys whose (small) tensors ride in the header and come back as CPU tensors on every rank
-HOST_KEYS = ("seeds", "enc_index", "knobs", "timesteps")
+HOST_KEYS = ("seeds", "enc_index", "knobs", "timesteps", "enc_index_non_cover")
 
 # What travels in bf16: every tensor the native path rounds to bf16 on arrival anyway (encoder states and the null embedding in
 # ace355_dit_set_condition, context latents in pack_xin / set_xin_ctx; csrc/dit.hip) - the transport rounding (RNE, same as the
@@ -263,30 +263,42 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0):
 # every per-request scalar of generate_music travels with the request: a rank called with other defaults must not generate its songs
 # with settings that differ from rank 0's (advisor r3); explicit `timesteps` ride as their own (header) item
 KNOBS = ("inference_steps", "guidance_scale", "shift", "cfg_interval_start", "cfg_interval_end", "use_adg", "infer_method_sde",
-         "use_tiled_decode", "latent_shift", "latent_rescale")
+         "use_tiled_decode", "latent_shift", "latent_rescale", "audio_cover_strength", "cover_noise_strength")
 _KNOB_DEFAULTS = {"inference_steps": 27, "guidance_scale": 7.0, "shift": 1.0, "cfg_interval_start": 0.0, "cfg_interval_end": 1.0,
-                  "use_adg": 0.0, "infer_method_sde": 0.0, "use_tiled_decode": 1.0, "latent_shift": 0.0, "latent_rescale": 1.0}
+                  "use_adg": 0.0, "infer_method_sde": 0.0, "use_tiled_decode": 1.0, "latent_shift": 0.0, "latent_rescale": 1.0,
+                  "audio_cover_strength": 1.0, "cover_noise_strength": 0.0}
+
+
+def _distinct_rows(enc: torch.Tensor, G: int) -> Tuple[List[int], List[int]]:
+    """(rows, index): the distinct rows of a [G | 1, ...] tensor and, per song, which of them it uses."""
+    rows: List[int] = []
+    idx: List[int] = []
+    for b in range(G):
+        r0 = b if enc.shape[0] > 1 else 0
+        for k, r in enumerate(rows):
+            if r == r0 or torch.equal(enc[r0], enc[r]):
+                idx.append(k)
+                break
+        else:
+            rows.append(r0)
+            idx.append(len(rows) - 1)
+    return rows, idx
 
 
 def pack_request(encoder_hidden_states: torch.Tensor, context_latents: torch.Tensor, seeds: Sequence[int],
                  null_condition_emb: Optional[torch.Tensor] = None, timesteps: Optional[Sequence[float]] = None,
-                 **knobs) -> Dict[str, torch.Tensor]:
+                 src_latents: Optional[torch.Tensor] = None, encoder_hidden_states_non_cover: Optional[torch.Tensor] = None,
+                 context_latents_non_cover: Optional[torch.Tensor] = None, **knobs) -> Dict[str, torch.Tensor]:
     """The wire form of one generate_music request of G songs (rank 0): the DISTINCT rows of ``encoder_hidden_states [G | 1, L, D]``
     with an index per song (the reference replicates one caption across the batch, handler/batch_prep.py:93-96: one row),
-    ``context_latents [G | 1, T, 128]`` collapsed to one row when every song shares it, per-song seeds, the request knobs."""
+    ``context_latents [G | 1, T, 128]`` collapsed to one row when every song shares it, per-song seeds, the request knobs.
+    A cover / repaint request adds its tensors (round 5, advisor r4): ``src_latents [G | 1, T, 64]`` (fp32: the renoised start
+    ``t x noise + (1 - t) x src`` of base.py:1879-1900 is host arithmetic in fp32), the non-cover conditions
+    ``encoder_hidden_states_non_cover [G | 1, L', D]`` (distinct rows + index, like the cover ones) and
+    ``context_latents_non_cover [G | 1, T, 128]``; absent ones travel as empty tensors, so every rank passes one key list."""
     G = len(seeds)
     enc = encoder_hidden_states if encoder_hidden_states.dim() == 3 else encoder_hidden_states[None]
-    rows: List[int] = []
-    idx: List[int] = []
-    for b in range(G):
-        e = enc[b if enc.shape[0] > 1 else 0]
-        for k, r in enumerate(rows):
-            if r == (b if enc.shape[0] > 1 else 0) or torch.equal(e, enc[r]):
-                idx.append(k)
-                break
-        else:
-            rows.append(b if enc.shape[0] > 1 else 0)
-            idx.append(len(rows) - 1)
+    rows, idx = _distinct_rows(enc, G)
     ctx = context_latents if context_latents.dim() == 3 else context_latents[None]
     if ctx.shape[0] > 1 and bool((ctx == ctx[:1]).all()):
         ctx = ctx[:1]
@@ -302,10 +314,30 @@ def pack_request(encoder_hidden_states: torch.Tensor, context_latents: torch.Ten
         b["null"] = null_condition_emb.reshape(-1).contiguous()
     # explicit schedule of the sft variant (base.py:1864-1875); empty = derive it from inference_steps / shift
     b["timesteps"] = torch.as_tensor([] if timesteps is None else [float(t) for t in timesteps], dtype=torch.float32)
+    for name, t in (("src", src_latents), ("ctx_non_cover", context_latents_non_cover)):
+        if t is None:
+            b[name] = torch.zeros(0)
+            continue
+        t = t if t.dim() == 3 else t[None]
+        if t.shape[0] not in (1, G):
+            raise ValueError(f"pack_request: {name} must have 1 or {G} rows, got {t.shape[0]}")
+        if t.shape[0] > 1 and bool((t == t[:1]).all()):
+            t = t[:1]
+        b[name] = t.contiguous()
+    if encoder_hidden_states_non_cover is None:
+        b["enc_rows_non_cover"], b["enc_index_non_cover"] = torch.zeros(0), torch.zeros(0, dtype=torch.int32)
+    else:
+        e2 = encoder_hidden_states_non_cover if encoder_hidden_states_non_cover.dim() == 3 else encoder_hidden_states_non_cover[None]
+        if e2.shape[0] not in (1, G):
+            raise ValueError(f"pack_request: encoder_hidden_states_non_cover must have 1 or {G} rows, got {e2.shape[0]}")
+        r2, i2 = _distinct_rows(e2, G)
+        b["enc_rows_non_cover"], b["enc_index_non_cover"] = e2[r2].contiguous(), torch.tensor(i2, dtype=torch.int32)
     return b
 
 
-_REQUEST_KEYS = ("enc_rows", "enc_index", "ctx", "seeds", "knobs", "null", "timesteps")
+_REQUEST_KEYS = ("enc_rows", "enc_index", "ctx", "seeds", "knobs", "null", "timesteps",
+                 "src", "ctx_non_cover", "enc_rows_non_cover", "enc_index_non_cover")
+_OPTIONAL_KEYS = ("null", "timesteps", "src", "ctx_non_cover", "enc_rows_non_cover", "enc_index_non_cover")
 
 
 def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[Dict[str, Any]], Any], src: int = 0,
@@ -328,10 +360,9 @@ def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[D
         if rank == src and request is not None:
             # (a request without a null embedding / explicit timesteps still ships the keys: every rank must pass the same key list)
             req = {k: request.get(k) for k in keys}
-            if req["null"] is None:
-                req["null"] = torch.zeros(0)
-            if req["timesteps"] is None:
-                req["timesteps"] = torch.zeros(0)
+            for k in _OPTIONAL_KEYS:
+                if req[k] is None:
+                    req[k] = torch.zeros(0, dtype=torch.int32) if k.startswith("enc_index") else torch.zeros(0)
         else:
             # (src without a request: raising HERE would leave the other ranks waiting in the broadcast - the refusal rides in the
             #  header and raises on every rank, advisor r3)
@@ -343,8 +374,8 @@ def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[D
         if request is None:
             raise ValueError("run_request: no request")
         b = dict(request)
-        b.setdefault("null", None)
-        b.setdefault("timesteps", None)
+        for k in _OPTIONAL_KEYS:
+            b.setdefault(k, None)
     G = int(b["seeds"].numel())
     s0, s1 = shard_range(G, world, rank)
     # (seeds / enc_index / knobs / timesteps rode in the header at N > 1: CPU tensors, no device read here)
@@ -369,10 +400,22 @@ def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[D
         if mine_h is not None:
             ctx_l = torch.cat([mine_h.to(ctx_l.dtype), ctx_l[..., ctx_l.shape[-1] // 2:]], -1).contiguous()
         null = b.get("null")
+        def rows_of(t):   # this rank's songs of an optional [G | 1, ...] item (None when the request has none)
+            if t is None or t.numel() == 0:
+                return None
+            return (t[s0:s1] if t.shape[0] > 1 else t.expand(s1 - s0, *t.shape[1:])).contiguous()
+
+        enc_nc = None
+        rows_nc, idx_nc = b.get("enc_rows_non_cover"), b.get("enc_index_non_cover")
+        if rows_nc is not None and rows_nc.numel():
+            idx_nc_all = [int(x) for x in idx_nc.tolist()]
+            enc_nc = rows_nc[[idx_nc_all[i] for i in range(s0, s1)]]
         local = {"encoder_hidden_states": b["enc_rows"][[idx_all[i] for i in range(s0, s1)]], "context_latents": ctx_l,
                  "null_condition_emb": None if null is None or null.numel() == 0 else null, "seeds": seeds_all[s0:s1], "knobs": knobs,
                  "timesteps": timesteps,
-                 "range": (s0, s1), "global_batch": G, "enc_rows": b["enc_rows"], "enc_index": idx_all[s0:s1]}
+                 "range": (s0, s1), "global_batch": G, "enc_rows": b["enc_rows"], "enc_index": idx_all[s0:s1],
+                 "src_latents": rows_of(b.get("src")), "context_latents_non_cover": rows_of(b.get("ctx_non_cover")),
+                 "encoder_hidden_states_non_cover": enc_nc}
         result = execute(local)
     out = {"local": result, "range": (s0, s1), "global_batch": G}
     if gather:

@@ -84,6 +84,31 @@ def _worker(rank, world, port, q):
         ok = ok and torch.equal(allw, expect)
     else:
         ok = ok and res["gathered"] is None
+    # a cover request (round 5, advisor r4): strengths as knobs, src_latents in fp32 bit for bit, the non-cover conditions as distinct
+    # rows + index like the cover ones, a shared non-cover context collapsed to one row and expanded again on arrival
+    src5 = torch.randn(G5, 6, 64, generator=g)
+    enc_nc5 = torch.randn(1, 4, 16, generator=g).expand(G5, -1, -1).clone()
+    enc_nc5[1] -= 2.0
+    ctx_nc5 = torch.randn(1, 6, 128, generator=g)
+    req = a_dist.pack_request(enc5, ctx5, seeds5, None, audio_cover_strength=0.5, cover_noise_strength=0.25, src_latents=src5,
+                              encoder_hidden_states_non_cover=enc_nc5, context_latents_non_cover=ctx_nc5.expand(G5, -1, -1)) if rank == 0 else None
+    if rank == 0:
+        ok = ok and tuple(req["enc_rows_non_cover"].shape) == (2, 4, 16) and req["enc_index_non_cover"].tolist() == [0, 1, 0, 0, 0] and req["ctx_non_cover"].shape[0] == 1
+    calls.clear()
+    a_dist.run_request(req, lambda local: calls.append(local), src=0, device=torch.device("cpu"))
+    loc = calls[0]
+    ok = ok and loc["knobs"]["audio_cover_strength"] == 0.5 and loc["knobs"]["cover_noise_strength"] == 0.25 and loc["knobs"]["inference_steps"] == 27.0
+    ok = ok and loc["src_latents"].dtype == torch.float32 and torch.equal(loc["src_latents"], src5[s5:e5])
+    ok = ok and torch.equal(loc["encoder_hidden_states_non_cover"].float(), enc_nc5[s5:e5].to(torch.bfloat16).float())
+    ok = ok and torch.equal(loc["context_latents_non_cover"].float(), ctx_nc5.to(torch.bfloat16).float().expand(e5 - s5, -1, -1))
+    ok = ok and loc["null_condition_emb"] is None and loc["timesteps"] is None
+    # ... and a request without them leaves all three None on every rank
+    req = a_dist.pack_request(enc5, ctx5, seeds5) if rank == 0 else None
+    calls.clear()
+    a_dist.run_request(req, lambda local: calls.append(local), src=0, device=torch.device("cpu"))
+    loc = calls[0]
+    ok = ok and loc["src_latents"] is None and loc["encoder_hidden_states_non_cover"] is None and loc["context_latents_non_cover"] is None
+    ok = ok and loc["knobs"]["audio_cover_strength"] == 1.0 and loc["knobs"]["cover_noise_strength"] == 0.0
     # NativeHandler.generate_music(data_parallel=True) on handlers that were never initialised: the failure of every rank's share
     # becomes the reference's error payload on EVERY rank (agreed by one all-reduce), nobody hangs in a collective
     from ace355.backend import NativeHandler
@@ -93,6 +118,9 @@ def _worker(rank, world, port, q):
     ok = ok and pay["success"] is False and pay["audios"] == [] and isinstance(pay["error"], str)
     pay = hd.generate_music(enc5 if rank == 0 else None, ctx5 if rank == 0 else None, seed=7, data_parallel=True)   # scalar seed: refused on rank 0, error everywhere
     ok = ok and pay["success"] is False and ("seed" in pay["error"] or "another rank" in pay["error"])
+    pay = hd.generate_music(enc5 if rank == 0 else None, ctx5.expand(G5, -1, -1) if rank == 0 else None, seed=seeds5 if rank == 0 else None,
+                            data_parallel=True, infer_method_typo="ode")   # a keyword that does not travel: refused, error everywhere
+    ok = ok and pay["success"] is False and ("not part of the broadcast request" in pay["error"] or "another rank" in pay["error"])
     # per-item LM hints [G, T, 64] scattered by song ownership (G = 11 over 2 ranks: 6 + 5 rows)
     G, T = 11, 9
     hints = torch.arange(G * T * 64, dtype=torch.float32).view(G, T, 64) if rank == 0 else None

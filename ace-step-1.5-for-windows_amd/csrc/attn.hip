@@ -1172,7 +1172,10 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
         // ACE355_ATTN_ROT=2 also where the 192- / 128-row kernels would (A/B of the self-attention launches), =0 never
         static int rot_env = -1;
         if (rot_env < 0) { const char* e = getenv("ACE355_ATTN_ROT"); rot_env = e ? atoi(e) : 1; }
-        if (nwh && !a.out_q && (rot_env >= 2 || (rot_env == 1 && nwh == 3))) {
+        // (the key-split kernel merges two partial softmaxes per row: another fp32 summation order than the one-walk kernels.  Which kernel
+        //  a sequence gets depends on how many sequences share the launch, so with ace355_gemm_set_k_rotation(0) - "one summation order
+        //  whatever the launch shape" - it stays off: a song alone and inside a batch then take the same per-row arithmetic again)
+        if (nwh && !a.out_q && gemm_k_rotation_mode() != 0 && (rot_env >= 2 || (rot_env == 1 && nwh == 3))) {
             AttnArgs ap = a;
             ap.clk_probe = clk;
             const long total = units(3);

@@ -163,6 +163,7 @@ struct GemmEpilogue {
     int cu_slots;
 };
 int gemm_set_k_rotation(int mode);   // ace355_gemm_set_k_rotation; returns the previous mode
+int gemm_k_rotation_mode();          // the current mode (0: launch-shape-independent summation orders, also honoured by launch_attention)
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
 // MXFP8 operands: Aq / Wq fp8 e4m3 [M, K] / [N, K] (row stride = K bytes), scales as GemmEpilogue::mx_sa / mx_sw describe; same

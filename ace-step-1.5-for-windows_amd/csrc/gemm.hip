@@ -27,6 +27,11 @@
 #define ACE355_ABL_NODMA 0   // 1 (diagnostic build, WRONG results): the bf16 K loop issues no DMA pieces - what the pieces cost a K step
 #endif
 
+#ifndef ACE355_EPI_NT
+#define ACE355_EPI_NT 0      // cache policy of the residual (mode 2) epilogue's single-use traffic, bit mask: 1 = old-H loads non-temporal, 2 = new-H
+                             // stores non-temporal, 4 = the folded norm's bf16(h * g) stores non-temporal (A/B builds: tools/r05_epi_nt.sh)
+#endif
+
 #include <stdio.h>
 #include <type_traits>
 #include <stdlib.h>
@@ -109,6 +114,20 @@ __device__ __forceinline__ int stage_off(int row, int slot) {
 }
 
 __device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+typedef float f32x4nt __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldf4_h(const float* p) {   // an old-H row segment of the residual epilogue (read once)
+    if constexpr ((ACE355_EPI_NT & 1) != 0) { const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(p)); return float4{v[0], v[1], v[2], v[3]}; }
+    else return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void stf4_h(float* p, const float4& o) {   // the new-H row segment (next read: the next residual GEMM, ~200 MB of traffic later)
+    if constexpr ((ACE355_EPI_NT & 2) != 0) __builtin_nontemporal_store(f32x4nt{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4nt*>(p));
+    else *reinterpret_cast<float4*>(p) = o;
+}
+__device__ __forceinline__ void stu2_xg(bf16_t* p, const uint2& v) {   // bf16(h * g): read by the next GEMM's DMA through every XCD's L2
+    if constexpr ((ACE355_EPI_NT & 4) != 0) __builtin_nontemporal_store(u32x2nt{v.x, v.y}, reinterpret_cast<u32x2nt*>(p));
+    else *reinterpret_cast<uint2*>(p) = v;
+}
 // v + (v of the lane a DPP control selects): cross-lane adds on the VALU, no LDS round trip
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -420,7 +439,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int m = mw0 + t * 8 + rsub;
-                        hvp[j][t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
+                        hvp[j][t] = ldf4_h(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
                     }
                 }
             }
@@ -485,7 +504,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int m = mw0 + t * 8 + rsub;
-                        hv[t] = ldf4(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
+                        hv[t] = ldf4_h(hp + (long)(ROWS_FULL ? m : min(m, M - 1)) * ldc);
                     }
                 }
                 if (ep.cvec && (ep.ksplit <= 1 || blockIdx.y == 0)) cv = ldf4(ep.cvec + n);  // (the first K part adds the constant term)
@@ -549,7 +568,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
                     uint2 pk;
                     pk.x = pack_bf2(o.x * gq.x, o.y * gq.y);
                     pk.y = pack_bf2(o.z * gq.z, o.w * gq.w);
-                    if (ROWS_FULL || m < M) *reinterpret_cast<uint2*>(ep.nf_xg + (long)m * ep.nf_ldx + n) = pk;
+                    if (ROWS_FULL || m < M) stu2_xg(ep.nf_xg + (long)m * ep.nf_ldx + n, pk);
                     float sq = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
                     sq = dpp_add<0xB1>(sq);    // quad_perm [1,0,3,2]
                     sq = dpp_add<0x4E>(sq);    // quad_perm [2,3,0,1]
@@ -565,7 +584,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
                         const float4 gt = (remA + row >= rps) ? gB : gA;
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
-                        if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
+                        if (ROWS_FULL || m < M) stf4_h(hp + (long)m * ldc, o);
                         if (nf_on) nf_emit(t, m, o);
                     }
                 } else {  // short sequences (tiny configs): a wave's rows touch more than two sequences
@@ -578,7 +597,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
                         const float4 gt = {g1.x + r2.x, g1.y + r2.y, g1.z + r2.z, g1.w + r2.w};
                         float4 o = {hv[t].x + gt.x * a.x, hv[t].y + gt.y * a.y, hv[t].z + gt.z * a.z, hv[t].w + gt.w * a.w};
                         if (ep.cvec && m >= ep.cvec_row0) { o.x += cv.x; o.y += cv.y; o.z += cv.z; o.w += cv.w; }
-                        if (ROWS_FULL || m < M) *reinterpret_cast<float4*>(hp + (long)m * ldc) = o;
+                        if (ROWS_FULL || m < M) stf4_h(hp + (long)m * ldc, o);
                         if (nf_on) nf_emit(t, m, o);
                     }
                 }
@@ -1401,6 +1420,7 @@ static int k_rotation_mode() {
     if (g_k_rotation < 0) g_k_rotation = env_int("ACE355_GEMM_KROT", 1);
     return g_k_rotation;
 }
+int gemm_k_rotation_mode() { return k_rotation_mode(); }
 int gemm_set_k_rotation(int mode) {
     const int prev = k_rotation_mode();
     g_k_rotation = mode < 0 ? 0 : (mode > 2 ? 2 : mode);

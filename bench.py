@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="DiT-only (BASELINE configs 0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gc-on", action="store_true", help="leave Python's cyclic collector enabled inside the timed passes (default: collected "
+                    "once, then disabled for the timed region; config.gc_disabled_in_timed_region records which)")
     ap.add_argument("--tiny", action="store_true", help="tiny architecture (smoke/debug only; result is not a benchmark)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE configs[4] precision: the four big projections on MXFP8 MFMA (not the headline metric, whose dtype is bf16)")
@@ -457,7 +459,8 @@ def main():
         # prepare_noise / set_condition at random: profiles/r04_pass_trace.txt) - the interpreter's housekeeping, not work of the request.
         gc.collect()
         gc_was = gc.isenabled()
-        gc.disable()
+        if not args.gc_on:
+            gc.disable()
         t0 = time.perf_counter()
         for i in range(steps):
             marks[i].record()
@@ -506,7 +509,7 @@ def main():
                                f"(T={T}), {args.infer_steps} steps, CFG {args.guidance:g} (2x{B} sequences/forward on rank 0), L={L}, "
                                f"{G} songs per request over {world} GPU(s)" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
                    "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "batch_rank0": B, "global_batch": G,
-                   "parallelism": f"dp{world}", "tiny": bool(args.tiny),
+                   "parallelism": f"dp{world}", "tiny": bool(args.tiny), "gc_disabled_in_timed_region": not args.gc_on,
                    "sampler_chains_per_gpu": (dit.dual_count() > 0) + 1 if hasattr(dit, "dual_count") else 1},
     }
     if other is not None:

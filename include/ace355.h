@@ -55,7 +55,11 @@ int ace355_box_probe_mfma(int iters, double* tflops_out);
  * ORDER of an output element then depends on the XCD region its tile falls in, i.e. on the launch shape: the same request still gives the
  * same bits, but a song's bits depend on the batch it is part of (3e-3 rel L2 apart, both at the same distance from the reference).
  * mode 0: off (one K order whatever the shape; what the bit-identity tests of the CFG fork pin), 1 (default; env ACE355_GEMM_KROT):
- * launches with N <= 2048, 2: every one-round launch.  Not a per-handle setting: call it before the first request. */
+ * launches with N <= 2048, 2: every one-round launch.  Not a per-handle setting: call it before the first request.
+ * Mode 0 is the library's "launch-shape-independent arithmetic" switch as a whole: the attention launcher then also keeps to its one-walk
+ * kernels (the 12-wave key-split kernel of the 96-row launches merges two partial softmaxes per row, and which launches are 96-row ones
+ * depends on how many sequences share them), so a song computed alone and inside a larger batch agree bit for bit wherever both runs take
+ * the GQA kernels (tests/test_metric_shapes_gpu.py::test_120s_forward_vs_reference_golden_and_batch16). */
 int ace355_gemm_set_k_rotation(int mode);
 
 /* ------------------------------------------------------------------------------------------

@@ -27,6 +27,10 @@
 #define ACE355_ABL_NODMA 0   // 1 (diagnostic build, WRONG results): the bf16 K loop issues no DMA pieces - what the pieces cost a K step
 #endif
 
+#ifndef ACE355_EPI_VEC
+#define ACE355_EPI_VEC 1     // 0 (A/B build): the folded-norm consumers of the 8-wave kernels load their row sums / bias / head-norm weights from global
+                             // memory at the top of the epilogue, as until round 5, instead of from the LDS vector area a DMA filled under the K loop
+#endif
 #ifndef ACE355_EPI_NT
 #define ACE355_EPI_NT 0      // cache policy of the residual (mode 2) epilogue's single-use traffic, bit mask: 1 = old-H loads non-temporal, 2 = new-H
                              // stores non-temporal, 4 = the folded norm's bf16(h * g) stores non-temporal (A/B builds: tools/r05_epi_nt.sh)
@@ -137,7 +141,12 @@ __device__ __forceinline__ float dpp_add(float v) {
 template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true, bool L16 = false>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
 __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW], char* __restrict__ stg, void* __restrict__ Cv, int ldc,
                                                    int M, const GemmEpilogue& ep, int mw0, int nw0, int lane, float* xw = nullptr,
-                                                   int wave = 0, int wnw = 1) {
+                                                   int wave = 0, int wnw = 1, const char* vec = nullptr, int mt0 = 0, int nt0 = 0) {
+    // vec (8-wave bf16 kernels, folded-norm consumers): the workgroup's LDS vector area, filled by DMA pieces issued ahead of the tile's
+    // first operand tile (gemm_sp_kernel: vec_issue): [0, 2048) the u64 row sums of squares of the tile's rows, [2048, 3072) nc_bias of its
+    // columns, [3072, 3584) the head's norm weights (mode 4).  mt0 / nt0 = this wave's first row / column inside the tile.  The row sums
+    // were written by memory-side atomics of the producer GEMM: as global loads they opened the epilogue with a fabric round trip, and the
+    // per-column vectors cost an L2 round trip per phase; from LDS they are ~64-cycle reads (in registers they spilled: profiles/r05_presq_*).
     constexpr int RPB = L16 ? 2 : 1;   // rows of a 32x32 block one lane holds (AccTile)
     const int lrow = L16 ? (lane & 15) : (lane & 31);   // the lane's row inside its 16- / 32-row group
     const bool eprobe = ep.clk_probe && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0;   // ACE355_GEMM_CLK: phases of this epilogue
@@ -160,12 +169,17 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
 #pragma unroll
                 for (int rr = 0; rr < RPB; ++rr) {
                     const int m = mw0 + i * 32 + rr * 16 + lrow;
-                    rs_in[i][rr] = rsqrtf((float)(long long)ep.nc_rowsq[ROWS_FULL ? m : min(m, M - 1)] * (1.f / 16777216.f) * ep.nc_inv_d + ep.nc_eps);
+                    const unsigned long long sq = vec ? *reinterpret_cast<const unsigned long long*>(vec + (mt0 + i * 32 + rr * 16 + lrow) * 8)
+                                                      : ep.nc_rowsq[ROWS_FULL ? m : min(m, M - 1)];
+                    rs_in[i][rr] = rsqrtf((float)(long long)sq * (1.f / 16777216.f) * ep.nc_inv_d + ep.nc_eps);
                 }
         }
         auto fold_bias = [&](int j, int g) -> float4 {   // nc_bias of this lane's 4 columns of quad g of block column j; zeros with the hooks off
             float4 bq = {0.f, 0.f, 0.f, 0.f};
-            if (FOLD && ep.nc_bias) bq = ldf4(ep.nc_bias + nw0 + j * 32 + q_col<L16>(g, lane));
+            if (FOLD && ep.nc_bias) {
+                if (vec) bq = *reinterpret_cast<const float4*>(vec + 2048 + (nt0 + j * 32 + q_col<L16>(g, lane)) * 4);
+                else bq = ldf4(ep.nc_bias + nw0 + j * 32 + q_col<L16>(g, lane));
+            }
             return bq;
         };
         // mode 4, q / k tiles (workgroup-uniform): per-row sum of squares over the head's 128 columns = this wave's 64 (two
@@ -207,7 +221,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
         if constexpr (MODE == 4) {
             constexpr int HW = 4 / NTW;  // waves per 128-column head: a pair (64 columns each) or all four N-waves of a 128-wide tile
             if (hn) {
-                hw = (nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk;
+                hw = vec ? reinterpret_cast<const float*>(vec + 3072) : ((nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk);
                 float ss[MT][RPB];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -670,7 +684,7 @@ __device__ __forceinline__ void gemm_epilogue_scalar(AccTile<L16> (&acc)[MT][NTW
 template <int MODE, int MT, int NTW = 2, bool FOLD = true, bool L16 = false>
 __device__ __forceinline__ void gemm_epilogue(AccTile<L16> (&acc)[MT][NTW], char* smem, void* __restrict__ Cv, int ldc, int M, int N,
                                               const GemmEpilogue& ep, int m0, int n0, int wm, int wn, int wave, int lane,
-                                              int bm = MT * 64, int bn = 128) {
+                                              int bm = MT * 64, int bn = 128, const char* vec = nullptr) {
     const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NTW * 32);
     if (ep.wide_ok && n0 + bn <= N) {  // workgroup-uniform
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -678,8 +692,9 @@ __device__ __forceinline__ void gemm_epilogue(AccTile<L16> (&acc)[MT][NTW], char
         char* stg = smem + wave * (MT * 32 * 128);
         float* xw = reinterpret_cast<float*>(smem + (bn / (NTW * 32)) * (bm / (MT * 32)) * (MT * 32 * 128));  // behind the last staging slice
         const int wnw = bn / (NTW * 32);
-        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD, L16>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
-        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD, L16>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw);
+        const int mt0 = wm * (MT * 32), nt0 = wn * (NTW * 32);
+        if (m0 + bm <= M) gemm_epilogue_wide<MODE, MT, NTW, true, FOLD, L16>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw, vec, mt0, nt0);
+        else gemm_epilogue_wide<MODE, MT, NTW, false, FOLD, L16>(acc, stg, Cv, ldc, M, ep, mw0, nw0, lane, xw, wave, wnw, vec, mt0, nt0);
     } else {
         gemm_epilogue_scalar<MODE, MT, NTW, L16>(acc, Cv, ldc, M, N, ep, mw0, nw0, lane);
     }
@@ -861,7 +876,10 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
     constexpr int EPI_BYTES = NW * MT * 32 * 128 + NW * MT * 32 * 4;  // epilogue staging: MT*32 rows x 128 B per wave (+ mode 4's row sums)
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES];
+    // Vector area (8-wave bf16 kernels whose epilogue consumes a folded norm; one workgroup per CU, so the 4 KB are free): see gemm_epilogue_wide
+    constexpr bool VEC = (ACE355_EPI_VEC != 0) && !FP8 && WNW == 4 && (MODE == 0 || MODE == 3 || MODE == 4);
+    constexpr int VOFF = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[VOFF + (VEC ? 4096 : 0)];
 
     // Workgroup -> tile map.  Block b runs on XCD b % 8 (observed, speed only).  The 8 XCDs (private L2s) form an
     // xcd_m x xcd_n grid of rectangular tile regions, chosen per GEMM to minimise the bytes each L2 must pull from
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // workgroups resident on one XCD share both A row-panels and W column-panels.
     for (int idx = blockIdx.x >> 3;; idx += (int)(gridDim.x >> 3)) {
     const unsigned long long t_entry = ep.clk_probe ? clock64() : 0ull;
-    int tm, tn;
+    int tm, tn, trow;   // trow: the tile's row inside its XCD region
     {
         const int tiles_m = nwg / tiles_n;
         const int xcd = blockIdx.x & 7;
@@ -883,7 +901,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         const int grp = idx / gsz, rem = idx - grp * gsz;
         const int first_m = grp * group_m;
         const int gm = min(hm - first_m, group_m);
-        tm = m_lo + first_m + rem % gm;
+        trow = first_m + rem % gm;
+        tm = m_lo + trow;
         tn = n_lo + rem / gm;
     }
     const int m0 = tm * BMv, n0 = tn * BNv;
@@ -921,7 +940,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // K rotation (ep.krot; one-round launches): the workgroups of XCD x start at K step x * nk / 8 and wrap, so the eight L2s do not miss the
     // same K slice at the same moment: a slice's first reader pays the HBM latency, the other seven find it in the memory-side cache
     // (launches that leave a quarter of the CUs without a tile have no common miss to spread: batch 1 measured + 0.3 % with the rotation on)
-    const int krot = (!PERS && !FP8 && ep.krot && ep.kparts == 1 && nwg >= 192) ? (int)(blockIdx.x & 7) * (nk >> 3) : 0;
+    // Row stagger (ep.krot >> 4 = d > 0): inside an XCD the workgroups of region row r start another r * d K steps ahead.  All 32 workgroups
+    // of an XCD used to reach every new K slice together - 32 "first readers" waiting for the same fabric fetch - where in the persistent
+    // launches they drift apart and all but one find the slice in their L2; the workgroups of one region row (which share the A slice) stay
+    // in step, the rows that share a W slice follow each other d steps apart (a few 100 KB of traffic later: still in the 4 MB L2).
+    const int krot = (!PERS && !FP8 && ep.krot && ep.kparts == 1 && nwg >= 192) ? ((int)(blockIdx.x & 7) * (nk >> 3) + (ep.krot >> 4) * trow) % nk : 0;
     auto kmap = [&](int kt) -> int { const int k = kt + krot; return k >= nk ? k - nk : k; };
     const int frow = L16 ? (lane & 15) : (lane & 31), fhalf = L16 ? (lane >> 4) : (lane >> 5);   // fragment row inside its 16- / 32-row group, K group of the lane
     // MX scales: wave 0 stages the A rows' words of K step kt (rows m0 .. m0+255 of scale row kt, 16 bytes per lane), wave 1 the W rows'
@@ -981,9 +1004,36 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     };
 
     bf16x8 pa[2][MT], pw[2][NTW], qa[2][MT], qw[2][NTW];
+    // Epilogue vectors of this tile -> LDS vector area, one DMA piece per wave 0-3 BEHIND the prologue's operand tiles (ahead of them
+    // they held tile 0 back: loads retire in order and the row sums are a fabric round trip - prologue + 500 cycles, the epilogues' gain
+    // gone; profiles/r05_epi_vec_first_ab.txt).  As the youngest request a piece only makes the counted waits of its wave conservative by
+    // one, the first K step's wait covers it and that step's barrier publishes it.  Waves 0 / 1: the row sums of squares (two rows per
+    // lane; M even, so a pair never straddles the end of the array: rows >= M take the last pair's values and are never stored), wave 2
+    // the bias of the tile's columns, wave 3 the head's norm weights.  Only whole tiles on the wide path (workgroup-uniform).
+    bool vec_on = false;
+    auto vec_issue = [&]() {
+    if constexpr (VEC) {
+        vec_on = ep.nc_rowsq && ep.wide_ok && (M & 1) == 0 && n0 + BNv <= N && ((uintptr_t)ep.nc_rowsq & 15) == 0 &&
+                 (MODE != 4 || (((uintptr_t)ep.hn_wq | (uintptr_t)ep.hn_wk) & 15) == 0);
+        if (vec_on) {
+            const unsigned vl = (unsigned)(uintptr_t)smem + VOFF;
+            if (wave < 2) {
+                const unsigned ro = (unsigned)min(m0 + wave * 128 + 2 * lane, M - 2) * 8u;
+                glds16_sv(ro, ep.nc_rowsq, (unsigned)__builtin_amdgcn_readfirstlane((int)(vl + (unsigned)wave * 1024u)));
+            } else if (wave == 2) {
+                if (ep.nc_bias) glds16_sv((unsigned)min(n0 + 4 * lane, N - 4) * 4u, ep.nc_bias, (unsigned)__builtin_amdgcn_readfirstlane((int)(vl + 2048u)));
+            } else if (wave == 3) {
+                if constexpr (MODE == 4) {
+                    if (n0 < ep.hn_qk_cols) glds16_sv((unsigned)((4 * lane) & 127) * 4u, n0 < ep.hn_q_cols ? ep.hn_wq : ep.hn_wk, (unsigned)__builtin_amdgcn_readfirstlane((int)(vl + 3072u)));
+                }
+            }
+        }
+    }
+    };
     issue(0);
     if (NS == 2) {
         if (nk > 1) issue(1);
+        vec_issue();
         if (nk > 1) {
             if (FP8 && wave < 2) wait_vmcnt<AJ + WJ + 1>(); else wait_vmcnt<AJ + WJ>();  // (waves 0 / 1 carry one scale piece per K step)
         } else wait_vmcnt<0>();
@@ -992,9 +1042,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         if (nk >= NS) {
 #pragma unroll
             for (int t = 1; t < NS; ++t) issue(t);
+            vec_issue();
             wait_vmcnt<(NS - 1) * (AJ + WJ)>();
         } else {
             for (int t = 1; t < nk; ++t) issue(t);
+            vec_issue();
             wait_vmcnt<0>();
         }
     }
@@ -1248,7 +1300,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 asm volatile("" ::: "memory");
             }
         }
-        gemm_epilogue<MODE, MT, NTW, !FP8, L16>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv);
+        gemm_epilogue<MODE, MT, NTW, !FP8, L16>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv, (VEC && vec_on) ? smem + VOFF : nullptr);
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's H rows are in L2
@@ -1441,6 +1493,9 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         ep.clk_probe = clk;
         const int krot = k_rotation_mode();   // 1: launches with N <= 2048, 2: every launch (the kernel applies it to one-round bf16 launches)
         ep.krot = (krot == 2 || (krot == 1 && N <= 2048)) && (K / 64) % 8 == 0;
+        static int rowst = -1;
+        if (rowst < 0) rowst = std::min(std::max(env_int("ACE355_GEMM_KROT_ROW", 0), 0), 15);   // row stagger in K steps (with the rotation only)
+        if (ep.krot) ep.krot |= rowst << 4;
     }
     ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");

@@ -161,6 +161,10 @@ struct GemmEpilogue {
     // dual-chain sampler (dit.hip) runs two independent launch sequences on two hardware queues and shapes every launch of both for 128
     // CUs, so that the chains run side by side instead of interleaving workgroups over all 256 (round 4: 512 -> 473 ms per 8-song pass)
     int cu_slots;
+    // a_zero_idx > 0: row a_zero_idx of A (counted from the A pointer, >= M) exists and is all zeros: the rows a tile pads beyond M read IT
+    // instead of repeating row M - 1.  The padded rows' MFMAs are wasted either way (M = 6000 on 192-row tiles: 2.4 % of all of them); on
+    // zeros the matrix pipe switches next to nothing for them, and under the power cap that energy comes back as clock.
+    int a_zero_idx;
 };
 int gemm_set_k_rotation(int mode);   // ace355_gemm_set_k_rotation; returns the previous mode
 int gemm_k_rotation_mode();          // the current mode (0: launch-shape-independent summation orders, also honoured by launch_attention)

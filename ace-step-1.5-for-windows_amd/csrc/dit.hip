@@ -62,6 +62,8 @@ struct ace355_dit {
     // workspace
     int ws_N = 0, ws_T = 0;
     int vt_key_N = -1, vt_key_S = -1;   // (N, S) the pad columns of vt were last zeroed for
+    bool zr_on = false; int fwd_M = 0;  // (set by forward_core for its gemm() calls)
+    int zr_M = -1;                      // row zr_M of xn / ao / act is zero: the row the GEMM tiles' pad rows read (GemmEpilogue::a_zero_idx)
     std::vector<void*> ws_allocs;
     bf16_t *xin = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr;
     float *h = nullptr, *vpad = nullptr, *tfreq = nullptr, *ta1 = nullptr, *temb = nullptr, *tsilu = nullptr, *tproj = nullptr;
@@ -297,6 +299,15 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
     e2.sk_cnt = side ? h->fk.sk_cnt : h->sk_cnt;
     e2.sk_slab = side ? nullptr : h->sk_slab; e2.sk_slab_cap = SK_SLAB_FLOATS;
     e2.cu_slots = h->cu_slots;
+    // pad rows of the last row tile read the workspace's zero row (forward_core keeps row fwd_M of xn / ao / act zero)
+    if (h->zr_on && h->zr_M == h->fwd_M && h->fwd_M >= M) {
+        const struct { const bf16_t* base; int ld; } ops[3] = {{h->xn, h->D}, {h->ao, h->QD}, {h->act, h->F}};
+        for (const auto& o : ops) {
+            if (lda != o.ld || A < o.base || A >= o.base + (size_t)h->fwd_M * o.ld) continue;
+            const size_t off = (size_t)(A - o.base);
+            if (off % o.ld == 0 && (long)(off / o.ld) + M <= h->fwd_M) e2.a_zero_idx = h->fwd_M - (int)(off / o.ld);
+        }
+    }
     return launch_gemm(A, lda, W, ldw, C, ldc, M, N, K, e2, s);
 }
 
@@ -366,10 +377,10 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
     const long D = h->D, QKV = h->QD + 2 * h->KVD;
     ALLOC(h->ws_allocs, h->xin, (size_t)capN * cTp * 192);
     ALLOC(h->ws_allocs, h->h, (size_t)M * D);
-    ALLOC(h->ws_allocs, h->xn, (size_t)M * D);
+    ALLOC(h->ws_allocs, h->xn, (size_t)(M + 1) * D);      // (+ 1: the zero row behind the rows of the call in progress, forward_core)
     ALLOC(h->ws_allocs, h->qkv, (size_t)M * QKV);
-    ALLOC(h->ws_allocs, h->ao, (size_t)M * h->QD);
-    ALLOC(h->ws_allocs, h->act, (size_t)M * h->F);
+    ALLOC(h->ws_allocs, h->ao, (size_t)(M + 1) * h->QD);
+    ALLOC(h->ws_allocs, h->act, (size_t)(M + 1) * h->F);
     ALLOC(h->ws_allocs, h->vt, (size_t)capN * h->KVH * 128 * Sp);
     ALLOC(h->ws_allocs, h->vpad, (size_t)M * 2 * h->OUTC);
     ALLOC(h->ws_allocs, h->tfreq, (size_t)2 * capN * 256);
@@ -393,6 +404,7 @@ int ensure_workspace(ace355_dit* h, int N, int T, hipStream_t s) {
     h->ws_N = capN;
     h->ws_T = capT;
     h->vt_key_N = h->vt_key_S = -1;
+    h->zr_M = -1;
     h->ws_epoch++;
     return 0;
 }
@@ -546,6 +558,18 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ACE_HIP(hipMemsetAsync(h->vt, 0, (size_t)N * h->KVH * 128 * Sp * sizeof(bf16_t), s));
         h->vt_key_N = N; h->vt_key_S = S;
     }
+    // Zero row behind the M rows of the three bf16 GEMM operands (GemmEpilogue::a_zero_idx): written here whenever M changes - a larger
+    // call since then used that row as data - and by nothing else (every producer stores rows < M only).
+    static int zr_env = -1;
+    if (zr_env < 0) { const char* e = getenv("ACE355_GEMM_ZROW"); zr_env = e ? atoi(e) : 1; }
+    if (zr_env && h->zr_M != M) {
+        ACE_HIP(hipMemsetAsync(h->xn + (size_t)M * D, 0, (size_t)D * sizeof(bf16_t), s));
+        ACE_HIP(hipMemsetAsync(h->ao + (size_t)M * QD, 0, (size_t)QD * sizeof(bf16_t), s));
+        ACE_HIP(hipMemsetAsync(h->act + (size_t)M * F, 0, (size_t)F * sizeof(bf16_t), s));
+        h->zr_M = M;
+    }
+    h->zr_on = zr_env != 0;
+    h->fwd_M = M;
     const long gs_stride = temb_rows == 1 ? 0 : (long)h->NL * 4 * D;
     // folded RMSNorm (sampler path): row sums of squares of the 3 NL norm inputs accumulate during this forward
     const bool fold = h->nf.on && temb_rows == 1 && M <= h->nf.cap_M;

@@ -917,7 +917,10 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     // the L2 whatever the tile, which separates what the fabric costs a K step from what the CU-side path (DMA, LDS, MFMA) costs it
     const int lm0 = (ep.clk_probe & 2) ? 0 : m0, ln0 = (ep.clk_probe & 4) ? 0 : n0;
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) a_voff[j] = ((unsigned)min(lm0 + 8 * (wave + NW * j) + lrow, M - 1) * (unsigned)lda + sslot * 8) * 2u;
+    for (int j = 0; j < AJ; ++j) {
+        const int ar = lm0 + 8 * (wave + NW * j) + lrow;
+        a_voff[j] = ((unsigned)(ar < M ? ar : (ep.a_zero_idx > 0 ? ep.a_zero_idx : M - 1)) * (unsigned)lda + sslot * 8) * 2u;   // (pad rows: the zero row, else row M - 1)
+    }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) w_voff[j] = ((unsigned)min(ln0 + 8 * (wave + NW * j) + lrow, N - 1) * (unsigned)ldw + sslot * 8) * 2u;
     const unsigned lds0 = (unsigned)(uintptr_t)smem + (unsigned)wave * 1024u;
@@ -1377,6 +1380,7 @@ static int gemm_variant() {
     return v;
 }
 bool gemm_fold_supported() { return gemm_variant() != 1; }
+static bool variant_is_v1() { return gemm_variant() == 1; }
 bool gemm_slab_wanted() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("ACE355_GEMM_SLAB"); v = (e && atoi(e) != 0) ? 1 : 0; }
@@ -1499,7 +1503,9 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     }
     ACE_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem");
     ACE_CHECK(K % BK == 0, "gemm: K must be a multiple of 64");
-    ACE_CHECK((long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31), "gemm: A and W must each be smaller than 4 GB (32-bit DMA offsets)");
+    ACE_CHECK((long)std::max(M, ep.a_zero_idx + 1) * lda < (1L << 31) && (long)N * ldw < (1L << 31), "gemm: A and W must each be smaller than 4 GB (32-bit DMA offsets)");
+    ACE_CHECK(ep.a_zero_idx == 0 || ep.a_zero_idx >= M, "gemm: the zero row of A lies behind its M rows");
+    if (variant_is_v1()) ep.a_zero_idx = 0;
     ACE_CHECK((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-B rows)");
     ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");

@@ -165,6 +165,9 @@ struct GemmEpilogue {
     // instead of repeating row M - 1.  The padded rows' MFMAs are wasted either way (M = 6000 on 192-row tiles: 2.4 % of all of them); on
     // zeros the matrix pipe switches next to nothing for them, and under the power cap that energy comes back as clock.
     int a_zero_idx;
+    // a_wrap > 0: rows >= a_wrap of A read row (m - a_wrap): the operand of the second half of the rows IS the first half's (layer 0 of a
+    // CFG forward: both halves carry the same latents up to the first cross-attention, dit.hip: forward_core).
+    int a_wrap;
 };
 int gemm_set_k_rotation(int mode);   // ace355_gemm_set_k_rotation; returns the previous mode
 int gemm_k_rotation_mode();          // the current mode (0: launch-shape-independent summation orders, also honoured by launch_attention)

@@ -63,6 +63,9 @@ struct ace355_dit {
     int ws_N = 0, ws_T = 0;
     int vt_key_N = -1, vt_key_S = -1;   // (N, S) the pad columns of vt were last zeroed for
     bool zr_on = false; int fwd_M = 0;  // (set by forward_core for its gemm() calls)
+    bool dup_half = false;              // set by the sampler around forward_core: sequences [N/2, N) carry the same latents / context / timestep as [0, N/2) (CFG)
+    bool dedup_on = true;               // ace355_dit_set_dedup / ACE355_DEDUP0
+    int64_t dedup_forwards = 0;         // forwards whose layer 0 ran its QKV projection + self-attention on one half (ace355_dit_dedup_count)
     int zr_M = -1;                      // row zr_M of xn / ao / act is zero: the row the GEMM tiles' pad rows read (GemmEpilogue::a_zero_idx)
     std::vector<void*> ws_allocs;
     bf16_t *xin = nullptr, *xn = nullptr, *qkv = nullptr, *ao = nullptr, *act = nullptr, *vt = nullptr;
@@ -629,6 +632,15 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         const LayerW& W = h->layers[li];
         const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
         // ---- self attention (base.py:499-511)
+        // Layer 0 of a CFG forward: the conditional and the null sequence of a song enter the decoder with the same latents, context and
+        // timestep (x = cat([xt, xt]), base.py:1929) and differ only from the first cross-attention on - the reference computes the same
+        // numbers twice.  Here the first norm, the QKV projection and the self-attention of layer 0 run on the conditional half only, and
+        // the o_proj GEMM reads that half's attention output for both (GemmEpilogue::a_wrap); its epilogue (gate, constant term of the
+        // null rows, the two folded norms) is per row as always.  ace355_dit_set_dedup(h, 0) / ACE355_DEDUP0=0 switch it off (A/B, tests).
+        const bool dedup0 = li == 0 && h->dup_half && h->dedup_on && temb_rows == 1 && Nc > 0 && N == 2 * Nc && h->precision != ACE355_PRECISION_MXFP8 &&
+                            !h->tap_dst[0] && gemm_fold_supported();
+        const int Mq = dedup0 ? Mc : M, Nq = dedup0 ? Nc : N;   // rows / sequences the self-attention half of this layer computes
+        if (dedup0) h->dedup_forwards++;
         const bool mx_qkv = mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD) && D == 2048;
         const bool fold_sa = fold && li > 0;   // layer 0's input comes from the patchify GEMM: its norm stays a kernel
         if (fold_sa) rc = 0;                   // xn = bf16(h * g) and the row sums were written by the previous layer's down projection
@@ -636,7 +648,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             rc = launch_rmsnorm_gs_mx(h->h, gs_p + (size_t)(li * 2 + 0) * 2 * D, gs_p + (size_t)(li * 2 + 0) * 2 * D + D, h->xq, h->xs, h->xs_pad,
                                       M, D, eps, gs_stride, S, s);
         else
-        rc = launch_rmsnorm_gs(h->h, gs_p + (size_t)(li * 2 + 0) * 2 * D, gs_p + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, M, D, eps,
+        rc = launch_rmsnorm_gs(h->h, gs_p + (size_t)(li * 2 + 0) * 2 * D, gs_p + (size_t)(li * 2 + 0) * 2 * D + D, h->xn, Mq, D, eps,
                                gs_stride, S, s);
         if (rc) return rc;
         // QKV projection with q / k head-norm + RoPE in its epilogue (mode 4; launch_gemm falls back to two kernels)
@@ -651,10 +663,10 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep.vt_out = h->vt; ep.vt_ld = Sp; ep.vt_heads = h->KVH; ep.vt_done = &vt_done;
         if (mx_qkv) rc = gemm_mx(h, nullptr, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
-        else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, M, QKV, D, ep, s);
+        else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, Mq, QKV, D, ep, s);
         if (rc) return rc;
         if (!vt_done) {
-            rc = launch_transpose_v(h->qkv, QKV, QD + KVD, N, S, h->KVH, h->vt, Sp, s);
+            rc = launch_transpose_v(h->qkv, QKV, QD + KVD, Nq, S, h->KVH, h->vt, Sp, s);
             if (rc) return rc;
         }
         bool ao_is_mx = false;
@@ -665,7 +677,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             a.vt = h->vt; a.vt_seq_stride = (long)h->KVH * 128 * Sp; a.vt_head_stride = 128L * Sp; a.vt_ld = Sp;
             a.use_tab = 0;
             a.out = h->ao; a.o_seq_stride = (long)S * QD; a.o_row_stride = QD;
-            a.N = N; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
+            a.N = Nq; a.Sq = S; a.Skv = S; a.Hq = h->HQ; a.Hkv = h->KVH;
             a.window = sliding ? h->cfg.sliding_window : -1;
             a.scale = scale;
             a.part = h->attn_part; a.part_floats = h->attn_part_floats;
@@ -682,7 +694,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
                     for (int i = 0; i < S; ++i) tot += (double)(std::min(S - 1, i + a.window) - std::max(0, i - a.window) + 1);
                     keys = tot / S;
                 }
-                h->attn_flops += 4.0 * N * h->HQ * (double)S * keys * 128.0;
+                h->attn_flops += 4.0 * Nq * h->HQ * (double)S * keys * 128.0;
             }
             rc = launch_attention(a, s);
             if (rc) return rc;
@@ -694,6 +706,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             ep.nf_gA = W.n_ca; ep.nf_sqA = rowsq(li, 1);
             ep.nf_gB = g_mlp; ep.nf_sqB = rowsq(li, 2);
         }
+        if (dedup0) ep.a_wrap = Mc;   // rows of the null half read the conditional half's attention output
         if (ao_is_mx) rc = gemm_mx(h, nullptr, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else if (mx_usable(h, W.mx_o, M, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
@@ -865,7 +878,10 @@ int sampler_step(SamplerChain& c, int i, hipEvent_t ev) {
         rc = time_embed(h, &t_curr, &t_curr, 1, s);
         if (rc) return rc;
     }
+    // (both copies of a song were filled from the same latents and the same context rows: launch_set_xin_latent / launch_set_xin_ctx)
+    h->dup_half = do_cfg;
     rc = forward_core(h, N, T, slots, 1, s);
+    h->dup_half = false;
     if (rc) return rc;
     const int apply = (t_curr >= p->cfg_interval_start && t_curr <= p->cfg_interval_end) ? 1 : 0;
     const float dt = t_curr - t_prev;
@@ -943,6 +959,7 @@ int chain_ctx_sync(ace355_dit* h) {
     c->precision = h->precision; c->weights_fp8wo = h->weights_fp8wo; c->mx_min_rows = h->mx_min_rows;
     c->nf.enabled = h->nf.enabled; c->nf.min_rows = h->nf.min_rows;
     c->profile = h->profile;
+    c->dedup_on = h->dedup_on;
     return 0;
 }
 void chain_ctx_destroy(ace355_dit* c) {
@@ -1069,6 +1086,7 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     if (int prc = gemm_verify_splitk_placement()) return prc;
     h->expected_tensors = (size_t)h->NL * 19 + 4 + 12 + 4;
     if (const char* e = getenv("ACE355_SAMPLE_GRAPH")) h->graph_mode = atoi(e) != 0;
+    if (const char* e = getenv("ACE355_DEDUP0")) h->dedup_on = atoi(e) != 0;
     if (const char* e = getenv("ACE355_DUAL")) h->dual.mode = atoi(e);
     if (const char* e = getenv("ACE355_DUAL_SLOTS_MIN_ROWS")) h->dual.slots_min_rows = atoi(e);
     if (const char* e = getenv("ACE355_DUAL_MAX_ROWS")) h->dual.max_rows = atoi(e);
@@ -1625,6 +1643,20 @@ int ace355_dit_set_cfg_fork(ace355_dit* h, int mode) {
 int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks) {
     ACE_CHECK(h && forks, "cfg_fork_count: null argument");
     *forks = h->fk.forks;
+    return ACE355_OK;
+}
+
+int ace355_dit_set_dedup(ace355_dit* h, int enable) {
+    ACE_CHECK(h, "set_dedup: null handle");
+    h->dedup_on = enable != 0;
+    if (h->dual.ctx) h->dual.ctx->dedup_on = h->dedup_on;
+    h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
+    return ACE355_OK;
+}
+
+int ace355_dit_dedup_count(ace355_dit* h, int64_t* forwards) {
+    ACE_CHECK(h && forwards, "dedup_count: null argument");
+    *forwards = h->dedup_forwards + (h->dual.ctx ? h->dual.ctx->dedup_forwards : 0);
     return ACE355_OK;
 }
 

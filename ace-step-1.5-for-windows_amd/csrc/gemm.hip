@@ -919,7 +919,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
         const int ar = lm0 + 8 * (wave + NW * j) + lrow;
-        a_voff[j] = ((unsigned)(ar < M ? ar : (ep.a_zero_idx > 0 ? ep.a_zero_idx : M - 1)) * (unsigned)lda + sslot * 8) * 2u;   // (pad rows: the zero row, else row M - 1)
+        const int arw = (ep.a_wrap > 0 && ar >= ep.a_wrap) ? ar - ep.a_wrap : ar;   // (second half of the rows = the first half's operand)
+        a_voff[j] = ((unsigned)(ar < M ? arw : (ep.a_zero_idx > 0 ? ep.a_zero_idx : M - 1 - (ep.a_wrap > 0 ? ep.a_wrap : 0))) * (unsigned)lda + sslot * 8) * 2u;   // (pad rows: the zero row, else the last row)
     }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) w_voff[j] = ((unsigned)min(ln0 + 8 * (wave + NW * j) + lrow, N - 1) * (unsigned)ldw + sslot * 8) * 2u;
@@ -1506,6 +1507,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ACE_CHECK((long)std::max(M, ep.a_zero_idx + 1) * lda < (1L << 31) && (long)N * ldw < (1L << 31), "gemm: A and W must each be smaller than 4 GB (32-bit DMA offsets)");
     ACE_CHECK(ep.a_zero_idx == 0 || ep.a_zero_idx >= M, "gemm: the zero row of A lies behind its M rows");
     if (variant_is_v1()) ep.a_zero_idx = 0;
+    ACE_CHECK(ep.a_wrap == 0 || (!variant_is_v1() && ep.a_wrap > 0 && 2 * ep.a_wrap >= M), "gemm: a_wrap needs the DMA kernels and at most two copies of the rows");
     ACE_CHECK((lda % 8) == 0 && (ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 (16-B rows)");
     ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");

@@ -222,6 +222,16 @@ class NativeDit:
         native.check(self._lib.ace355_dit_cfg_fork_count(self._h, C.byref(n)), "dit_cfg_fork_count")
         return n.value
 
+    def set_dedup(self, enable: bool) -> None:
+        """Layer-0 de-duplication of the two CFG copies of a song (include/ace355.h: `ace355_dit_set_dedup`); on by default."""
+        native.check(self._lib.ace355_dit_set_dedup(self._h, 1 if enable else 0), "dit_set_dedup")
+
+    def dedup_count(self) -> int:
+        """Forwards whose layer 0 ran its QKV projection + self-attention on the conditional half only (`ace355_dit_dedup_count`)."""
+        n = C.c_int64()
+        native.check(self._lib.ace355_dit_dedup_count(self._h, C.byref(n)), "dit_dedup_count")
+        return n.value
+
     # ------------------------------------------------------------------ hipGraph replay of the sampler loop
     def set_graph(self, enable: bool) -> None:
         """Capture the sampler's launch sequence once per (shapes, schedule, knobs, slots, stream) and replay it afterwards."""

@@ -88,6 +88,8 @@ SIGNATURES = {
     "ace355_dit_dual_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ace355_dit_set_cfg_fork": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_cfg_fork_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ace355_dit_set_dedup": (C.c_int, [C.c_void_p, C.c_int]),
+    "ace355_dit_dedup_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ace355_dit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ace355_dit_poll_errors": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ace355_dit_trim_slots": (C.c_int, [C.c_void_p, C.c_int]),

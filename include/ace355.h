@@ -201,6 +201,14 @@ int ace355_dit_dual_count(ace355_dit* h, int64_t* calls);
 int ace355_dit_set_cfg_fork(ace355_dit* h, int mode);
 int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks);
 
+/* Layer-0 de-duplication under classifier-free guidance (on by default; ace355_dit_set_dedup(h, 0) or ACE355_DEDUP0=0 in the environment switch it off).  The
+ * reference feeds the decoder x = cat([xt, xt]) with the same context latents and timestep for both copies (base.py:1905-1911, 1929): up to
+ * the first cross-attention (base.py:499-511 of layer 0) the conditional and the null copy of a song are the same numbers.
+ * ace355_dit_sample therefore runs layer 0's first norm, QKV projection and self-attention on the conditional half only and lets the
+ * o_proj GEMM read that half's attention output for both halves.  dedup_count: forwards that took the shortcut so far. */
+int ace355_dit_set_dedup(ace355_dit* h, int enable);
+int ace355_dit_dedup_count(ace355_dit* h, int64_t* forwards);
+
 /* Test / debug hook: after decoder layer `layer` (0-based) of every following forward, copy the fp32 residual stream
  * hidden_states [N*S, hidden] (the layer's output, base.py:539) to dst_dev; dst_dev NULL clears the tap.  Lets the parity
  * tests compare the per-layer activations the golden fixtures hold, not only the final velocity. */

@@ -162,6 +162,53 @@ def test_tiny_sampler_with_cfg_fork_forced(gpu_device, golden_dir):
     assert res[0][0] < 5e-3 and res[2][0] < 5e-3 and res[0][1] < 2e-3 and res[2][1] < 2e-3, res
 
 
+def test_tiny_sampler_layer0_dedup_on_off(gpu_device, golden_dir):
+    """Layer-0 de-duplication under CFG (ace355_dit_set_dedup): the conditional and the null copy of a song are the same numbers up to the
+    first cross-attention (x = cat([xt, xt]), base.py:1929), so layer 0's first norm, QKV projection and self-attention run on one half
+    and the o_proj GEMM reads that half's rows for both (GemmEpilogue::a_wrap).  Against the reference's golden with the shortcut on and
+    off, norms folded and as kernels; the two agree to the summation-order level (other tile shapes for the half-size launches), and the
+    counter says the shortcut was taken once per forward; a guidance-free call (one copy per song) never takes it."""
+    from ace355 import weightgen
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
+    name = "cfg7_shift1"
+    cfg, w, dit = _make(TINY, int(G["seed"]), gpu_device)
+    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=int(G["seed"]))
+    enc = torch.from_numpy(G[f"{name}_enc"])
+    ctx = torch.from_numpy(G[f"{name}_ctx"])
+    B = ctx.shape[0]
+    lo, hi = G[f"{name}_interval"].tolist()
+    steps = int(G[f"{name}_steps"])
+    kw = dict(seed=G[f"{name}_seeds"].tolist(), infer_steps=steps, diffusion_guidance_sale=float(G[f"{name}_guidance"]),
+              cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=G[f"{name}_timesteps"].tolist() or None)
+    ref = torch.from_numpy(G[f"{name}_out"])
+    dit.set_dual(False)
+    res = {}
+    try:
+        for fold in (0, 2):
+            dit.set_norm_fold(fold)
+            dit.set_dedup(False)
+            n0 = dit.dedup_count()
+            off = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+            assert dit.dedup_count() == n0
+            dit.set_dedup(True)
+            on = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+            assert dit.dedup_count() == n0 + steps, (dit.dedup_count(), n0, steps)
+            again = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
+            assert torch.equal(on, again)
+            res[fold] = (_rel(on, ref), _rel(off, ref), _rel(on, off))
+        n1 = dit.dedup_count()
+        kw1 = dict(kw, diffusion_guidance_sale=1.0)
+        generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw1)
+        assert dit.dedup_count() == n1   # no second copy, nothing to share
+    finally:
+        dit.set_dedup(True)
+    print(f"tiny sampler, layer-0 dedup: on vs reference {res[0][0]:.3e} / {res[2][0]:.3e} (norm kernels / folded), off {res[0][1]:.3e} / {res[2][1]:.3e}, "
+          f"on vs off {res[0][2]:.3e} / {res[2][2]:.3e}")
+    for fold in (0, 2):
+        assert res[fold][0] < 5e-3 and res[fold][1] < 5e-3 and res[fold][2] < 2e-3, res
+
+
 def test_folded_norms_with_unordered_split_k_switch(gpu_device):
     """ACE355_GEMM_SKORD=0 (the fp32-atomics split-K the split-K timeout message recommends) together with the folded RMSNorm of
     the small-M launches (advisor r3): a folded-norm producer cannot be split into unordered parts - launch_gemm keeps such a launch's

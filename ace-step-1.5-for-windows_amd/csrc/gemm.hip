@@ -1449,6 +1449,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
         } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+        else if (mt == 1) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 1, 2, 2, 0, 4>), 256);
         else if (deep && mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 2, 0, 3>), 256);
         else if (deep) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 4>), 256);
         else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
@@ -1465,6 +1466,9 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
     } else if (big) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4>), 512);
+    else if (mt == 1) {
+        if constexpr (MODE != 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 1, 2, 2, 0, 4>), 256);  // 64 x 128, 4 x 24 KB stages
+    }
     else if (deep && mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2, 2, 0, 3>), 256);   // 3 x 40 KB stages
     else if (deep) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 2, 2, 2, 0, 4>), 256);              // 4 x 32 KB stages
     else if (mt == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 2>), 256);
@@ -1531,6 +1535,16 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
         if (bigenv == 2 || (bigenv == 1 && tbig >= 180 * cus / 256 && (N % 256 == 0 || N >= 1024)) || (ep.tile_hint == 1 && bigenv != 0 && N % 256 == 0)) { mt = 3; bn = 256; big = 1; }
         else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 * cus / 256 && t192 <= 320 * cus / 256))) { mt = 3; bn = 128; big = 2; }
+    }
+    // One sequence's worth of rows (the conditional rows' cross-attention projections of a one-song request: M = 375 -> 48 workgroups of
+    // 128 x 128, each pulling 32 KB per K step through ONE CU's DMA path while 200 CUs idle): 64-row tiles double the workgroups and cut a
+    // K step to 24 KB (ACE355_GEMM_MT1=0 for A/B).  Only where the 128-row form leaves more than half of the chip without a workgroup.
+    if (variant != 1 && big == 0 && ep.mode != 3) {
+        static int mt1_env = -1;
+        if (mt1_env < 0) mt1_env = env_int("ACE355_GEMM_MT1", 1);
+        const long cus = gemm_cu_slots(ep.cu_slots);
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        if (mt1_env && t128 * 2 <= cus && M > 64) mt = 1;
     }
     // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every
     // workgroup alone on its CU with a long serial K loop.  Slab split-K (ACE355_GEMM_SLAB=1, OFF by default): the 8-wave 192x128 tile, K

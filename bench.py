@@ -184,8 +184,11 @@ def pmc_traffic_bytes_per_launch():
     -> dict(bytes, file, commit, lib_src_sha, current)."""
     try:
         import glob
-        # newest by the round / version in the name (r04_final sorts after r04_v1 ... after r03_*)
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")))[-1]
+        # the profile taken on THIS library if there is one (source sha stamped into the summary), else the last by name (reported as stale)
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")))
+        cur = library_source_sha()
+        same = [c for c in cands if json.load(open(c)).get("_meta", {}).get("lib_src_sha") == cur]
+        f = (same or cands)[-1]
         w = f.replace("FETCH_SIZE", "WRITE_SIZE")
         jf, jw = json.load(open(f)), json.load(open(w))
         b = (2.0 * jf["gemm"]["FETCH_SIZE"]["per_launch"] + jw["gemm"]["WRITE_SIZE"]["per_launch"]) * 1024.0

@@ -209,6 +209,48 @@ def test_tiny_sampler_layer0_dedup_on_off(gpu_device, golden_dir):
         assert res[fold][0] < 5e-3 and res[fold][1] < 5e-3 and res[fold][2] < 2e-3, res
 
 
+def test_zero_row_and_tile64_switches_keep_the_bits(gpu_device):
+    """ACE355_GEMM_ZROW (pad rows of a GEMM tile read a zero row instead of repeating row M - 1) changes no stored value: the same request
+    in fresh processes with the switch on and off gives the same bits; ACE355_GEMM_MT1 (64 x 128 tiles for the launches of small requests)
+    changes tile shapes, i.e. at most the fp32 summation order of the two-wave head-norm sums: the results agree to 2e-3.  A mid-size
+    configuration whose launches pad (M = 2 x 100 rows on 128- / 64-row tiles) and take the 64-row tiles by default."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import ace355\n"
+        "from ace355 import weightgen\n"
+        "from ace355.dit import NativeDit, generate_latents\n"
+        "dev = torch.device('cuda:0')\n"
+        "cfg = ace355.DitConfig(hidden_size=1024, intermediate_size=3072, num_hidden_layers=2, num_attention_heads=8, num_key_value_heads=4)\n"
+        "w = weightgen.make_dit_weights(cfg.weight_shapes(), cfg.hidden_size, seed=3, mode='test')\n"
+        "null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=3)\n"
+        "dit = NativeDit(cfg, dev); dit.load_state_dict(w)\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "B, T, L = 1, 200, 33\n"
+        "enc = torch.randn(B, L, cfg.hidden_size, generator=g)\n"
+        "ctx = torch.cat([0.5 * torch.randn(B, T, 64, generator=g), torch.ones(B, T, 64)], -1)\n"
+        "out = generate_latents(dit, null, enc, ctx, seed=[7], infer_steps=4, diffusion_guidance_sale=7.0)['target_latents'].cpu()\n"
+        "dit.poll_errors()\n"
+        "assert torch.isfinite(out).all()\n"
+        "torch.save(out, sys.argv[1])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, env in (("base", {}), ("zrow0", {"ACE355_GEMM_ZROW": "0"}), ("mt1_0", {"ACE355_GEMM_MT1": "0"})):
+            path = os.path.join(d, name + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (name, r.stderr[-3000:])
+            outs[name] = torch.load(path)
+    r_m = _rel(outs["mt1_0"], outs["base"])
+    print(f"zero row on vs off: equal = {torch.equal(outs['zrow0'], outs['base'])}; 64-row tiles on vs off: {r_m:.3e}")
+    assert torch.equal(outs["zrow0"], outs["base"])
+    assert r_m < 2e-3, r_m
+
+
 def test_folded_norms_with_unordered_split_k_switch(gpu_device):
     """ACE355_GEMM_SKORD=0 (the fp32-atomics split-K the split-K timeout message recommends) together with the folded RMSNorm of
     the small-M launches (advisor r3): a folded-norm producer cannot be split into unordered parts - launch_gemm keeps such a launch's

@@ -20,6 +20,10 @@
 
 #include "common.h"
 
+#ifndef ACE355_CONV_V2
+#define ACE355_CONV_V2 1   // 0: the round-3 chunk / tap loop (A/B builds: tools/build_variant.sh old conv.hip -DACE355_CONV_V2=0)
+#endif
+
 namespace ace355 {
 
 namespace {
@@ -131,8 +135,42 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     // registers - and, for the next chunk, before the tap loop of the current one - so a workgroup pays one memory latency
     // per chunk instead of one per load (the loads used to sit in a load -> Snake -> ds_write loop).
     constexpr int WLD = (WIN_MAX * 8 + NTHR - 1) / NTHR;
+    // the 4-wave form keeps the next chunk's window loads in flight across the tap loop; with 4 waves per SIMD the 8-wave
+    // form has no registers to spare for that (128-VGPR budget) and other waves to cover the latency instead
+    constexpr bool PREFETCH = (TM == 128);
     u32x4 wv[WLD];
     const bool snake = a.alpha != nullptr;
+#if ACE355_CONV_V2
+    // V2 addressing: one loop-invariant 32-bit byte offset per thread (its row within a block of NTHR / 8 window rows, its 16-byte slot)
+    // on top of a UNIFORM 64-bit base per (chunk, row block) - the `global_load_dwordx4 v, v_off, s[base]` form - and the bounds as
+    // two uniform 32-bit limits per row block.  Version 1 kept a 64-bit address and a lane mask per load alive across the chunk
+    // loop: in the 8-wave form (128 VGPRs) they were spilled, and every reload's `s_waitcnt vmcnt(0)` (scratch loads count in vmcnt)
+    // sat between two window loads - five serialised memory round trips per chunk instead of one.
+    const int wrow_t = tid >> 3;                                        // row within a row block
+    const unsigned x_voff = (unsigned)((wrow_t * Cin + sslot * 8) * 2);  // bytes; <= 64 rows x 2048 channels x 2 B
+    auto win_load = [&](int ci0) {
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int r0 = i * (NTHR / 8);                // first window row of this block (uniform)
+            const long u = (long)(x_row0 + r0) * Cin + ci0 + a.x_shift;   // flat element index of (row r0, channel ci0): uniform
+            int lo, hi;   // the thread's element is read iff lo <= key < hi
+            int key;
+            if (a.x_valid) {  // strided-conv view: 0 <= u + wrow_t * Cin + sslot * 8 < x_valid, rows < win_rows
+                key = wrow_t * Cin + sslot * 8;
+                const long l = -u, h = a.x_valid - u, hr = (long)(win_rows - r0) * Cin;
+                lo = (int)max(0L, min(l, 0x7fffffffL));
+                hi = (int)max(0L, min(min(h, hr), 0x7fffffffL));
+            } else {          // plain rows: 0 <= x_row0 + r0 + wrow_t < L_in, r0 + wrow_t < win_rows
+                key = wrow_t;
+                lo = max(0, -(x_row0 + r0));
+                hi = max(0, min(a.L_in - (x_row0 + r0), win_rows - r0));
+            }
+            const char* sb = reinterpret_cast<const char*>(xb + u);   // uniform (may point below the tensor: only `inside` lanes load)
+            wv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (key >= lo && key < hi) wv[i] = ld_u32x4(sb + (size_t)x_voff);
+        }
+    };
+#else
     auto win_load = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
@@ -144,14 +182,79 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             if (inside) wv[i] = ld_u32x4(xb + flat);
         }
     };
+#endif
+    // Snake parameters of this thread's 8 channels of a chunk (exp(alpha), 1 / (exp(beta) + 1e-9): fp32 bits).  V2 requests them with
+    // the window rows (ahead of the barrier that opens the chunk); they used to be loaded at the top of win_store, behind that
+    // barrier, and waited for on the spot: one exposed L2 round trip per chunk
+    u32x4 spa[2], spb[2];
+    auto par_load = [&](int ci0) {
+        if (snake) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                spa[q] = ld_u32x4(a.alpha + ci0 + sslot * 8 + 4 * q);
+                spb[q] = ld_u32x4(a.beta + ci0 + sslot * 8 + 4 * q);
+            }
+        }
+    };
+    const int st0 = lds_off(tid >> 3, sslot);
+#if ACE355_CONV_V2
+    // Snake of one bf16 pair: x + 1/(e^beta + 1e-9) * sin^2(e^alpha x) (fp32; Snake(0) = 0, so zero rows - outside the signal or
+    // beyond the window - pass through unchanged and the arithmetic needs no row predicate, only the store does)
+    auto snake_pair = [&](unsigned p, unsigned a0, unsigned b0, unsigned a1, unsigned b1) -> unsigned {
+        const float x0 = bf_lo(p), x1 = bf_hi(p);
+        const float s0 = __sinf(__uint_as_float(a0) * x0), s1 = __sinf(__uint_as_float(a1) * x1);
+        return pack_bf2(x0 + __uint_as_float(b0) * s0 * s0, x1 + __uint_as_float(b1) * s1 * s1);
+    };
+    auto win_store = [&](int ci0) {
+        if (snake) {
+            if constexpr (PREFETCH) {   // parameters requested with the rows (spa / spb)
+#pragma unroll
+                for (int i = 0; i < WLD; ++i)
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2)
+                        wv[i][e2] = snake_pair(wv[i][e2], spa[e2 >> 1][2 * (e2 & 1)], spb[e2 >> 1][2 * (e2 & 1)],
+                                               spa[e2 >> 1][2 * (e2 & 1) + 1], spb[e2 >> 1][2 * (e2 & 1) + 1]);
+            } else {
+                // 8-wave form (128 VGPRs): the parameters of four channels at a time; with all sixteen values requested at once hipcc
+                // spilled them as they arrived (load, vmcnt(0), scratch store, next load)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 pa = ld_u32x4(a.alpha + ci0 + sslot * 8 + 4 * h);
+                    const u32x4 pb = ld_u32x4(a.beta + ci0 + sslot * 8 + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < WLD; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+                            wv[i][2 * h + q] = snake_pair(wv[i][2 * h + q], pa[2 * q], pb[2 * q], pa[2 * q + 1], pb[2 * q + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WLD; ++i) {
+            const int c = tid + i * NTHR;
+            // row block i is NTHR / 8 = 32 or 64 rows further down: (row >> 1) & 7 - the swizzle key - does not change, so the
+            // address is the thread's block-0 address plus an immediate (hipcc kept one address VGPR per block)
+            if (c < win_rows * 8) *reinterpret_cast<u32x4*>(As + st0 + i * (NTHR / 8) * 128) = wv[i];
+        }
+    };
+#else
     auto win_store = [&](int ci0) {
         float sa[8], sib[8];
         if (snake) {
+#if ACE355_CONV_V2
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sa[e] = __uint_as_float(spa[e >> 2][e & 3]);
+                sib[e] = __uint_as_float(spb[e >> 2][e & 3]);
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 sa[e] = a.alpha[ci0 + sslot * 8 + e];   // already exp(alpha)
                 sib[e] = a.beta[ci0 + sslot * 8 + e];   // already 1/(exp(beta)+1e-9)
             }
+#endif
         }
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
@@ -166,17 +269,101 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                         v[e2] = pack_bf2(x0 + sib[2 * e2] * s0 * s0, x1 + sib[2 * e2 + 1] * s1 * s1);
                     }
                 }
+#if ACE355_CONV_V2
+                // row block i is NTHR / 8 = 32 or 64 rows further down: (row >> 1) & 7 - the swizzle key - does not change, so the
+                // address is the thread's block-0 address plus an immediate (hipcc kept one address VGPR per block)
+                *reinterpret_cast<u32x4*>(As + st0 + i * (NTHR / 8) * 128) = v;
+#else
                 *reinterpret_cast<u32x4*>(As + lds_off(c >> 3, sslot)) = v;
+#endif
             }
         }
     };
 
-    const bool probe = a.clk_probe && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+#endif
+    // (wave-uniform condition: the clock values stay in SGPRs; with a per-thread `tid == 0` they lived in ten VGPRs of every wave)
+    const bool probe = a.clk_probe && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     unsigned long long p_t0 = 0, p_w0 = 0, p_stage = 0, p_taps = 0, p_mark = 0;
     if (probe) p_t0 = clock64(), p_w0 = wall_clock64();
-    // the 4-wave form keeps the next chunk's window loads in flight across the tap loop; with 4 waves per SIMD the 8-wave
-    // form has no registers to spare for that (128-VGPR budget) and other waves to cover the latency instead
-    constexpr bool PREFETCH = (TM == 128);
+#if ACE355_CONV_V2
+    // Version 2 of the chunk / tap loop (round 5; same MFMA order per output element: results are bit-identical to version 1).
+    // What the ISA of version 1 showed (hipcc --save-temps): (a) the Snake parameter loads of a chunk sat behind the chunk's first
+    // barrier and were waited for at once; their destination registers were then reused for the tap loop's fragments, and because
+    // win_store - wait included - is skipped by waves without window rows, hipcc guarded those registers with `s_waitcnt vmcnt(2)` /
+    // `vmcnt(0)` at the top of EVERY tap: right behind the asm-issued DMA of the next tap's weight tile (invisible to hipcc), i.e.
+    // every tap waited for the tile it had just requested and the DMA never ran under the MFMAs (a tap cost ~1530 cycles for 512
+    // cycles of MFMA issue, and a deeper ring changed nothing); (b) the next chunk's window rows were requested ahead of that same
+    // wait; (c) every fragment read was followed by `lgkmcnt(0)` and its MFMAs.  Here: parameters travel with the window rows, a
+    // BUILTIN vmcnt(0) (visible to hipcc's counter model) closes the staging on every path, the tap-0 tile is requested ahead of the
+    // Snake arithmetic, the next chunk's window rows behind the staging barrier (they land under tap 0), and the fragments of K
+    // group kk + 1 are requested ahead of the MFMAs of group kk (4-wave form: registers to spare).
+    constexpr bool FPIPE = (TM == 128);
+    if (PREFETCH) { win_load(0); par_load(0); }
+    for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
+        if (probe) p_mark = clock64();
+        if (!PREFETCH) win_load(ci0);
+        __syncthreads();  // previous chunk fully consumed (window rows and both weight buffers)
+        // vmcnt(0) as a BUILTIN: hipcc's counter model sees it, so win_store carries no waits of its own (they would also wait for the
+        // DMA below, which hipcc does not track) and no register is guarded against these loads later.  The rows and parameters were
+        // requested a tap loop ago (4-wave form) / ahead of the barrier (8-wave form).
+        if (PREFETCH) __builtin_amdgcn_s_waitcnt(0x0F70);
+        w_issue(0, ci0, 0);   // the tap-0 tile lands under the Snake arithmetic (8-wave form: with the parameters, one round trip for both)
+        win_store(ci0);       // Snake in fp32 registers, parked in LDS once per chunk
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA
+        __syncthreads();
+        if (PREFETCH && ci0 + 64 < Cin) { win_load(ci0 + 64); par_load(ci0 + 64); }
+        if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
+
+        for (int tap = 0; tap < taps; ++tap) {
+            const bool more = (tap + 1) < taps;
+            if (more) w_issue(tap + 1, ci0, (tap + 1) & 1);
+            const char* Ws = Wbase + (tap & 1) * (BN * 128);
+            const int arow = wm * (MT * 32) + tap * dil + lq;
+            if constexpr (FPIPE) {
+                bf16x8 fa[2][MT], fw[2][NT];
+                auto frag = [&](int kk, int sl) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        fa[sl][i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(arow + i * 32, kk * 2 + half)));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        fw[sl][j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
+                };
+                frag(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk < 3) frag(kk + 1, (kk + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[kk & 1][j], fa[kk & 1][i], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    bf16x8 fa[MT], fw[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(arow + i * 32, kk * 2 + half)));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);
+                }
+            }
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        if (probe) p_taps += clock64() - p_mark;
+    }
+#else
     if (PREFETCH) win_load(0);
     for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
         if (probe) p_mark = clock64();
@@ -221,6 +408,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         }
         if (probe) p_taps += clock64() - p_mark;
     }
+#endif
     // ---------------------------------------------------------------- fused k = 1 stage of a residual unit (C = 128)
     // The k = 7 result t = acc + bias never leaves the workgroup: snake2(t) is written to LDS as the A operand of a
     // 128 x 128 x 128 GEMM with w2 (two 64-channel planes over the dead window / first weight buffer, w2 chunks through the
@@ -329,7 +517,8 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         const int row_l = lane >> 2, c4 = lane & 3;
         u32x4 bl[NT], bh[NT];   // bias of this lane's 8 columns per half (fp32 bits)
         u32x4 rv[2][MT * 2];    // residual rows, double-buffered over the halves
-        const bool has_res = a.res != nullptr;
+        // (the 8-wave form is never launched with a residual: launch_conv; its 128-VGPR budget has no room for the residual rows)
+        const bool has_res = (TM == 128) && a.res != nullptr;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             bl[j] = u32x4{0u, 0u, 0u, 0u};
@@ -495,7 +684,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         // plain-row transposed convs with Cin >= 1024 gain from ~ 900 four-wave tiles up (one song, 2048 -> 1024, 480 tiles: 149 -> 170 us).
         const bool tall_k = a.Cin >= 256 && a.taps >= 3 && wgs128 >= 448;
         const bool tall_t = a.taps == 2 && a.Cin >= 1024 && !a.alpha && !a.x_valid && wgs128 >= 900;
-        const bool tall = !a.w2 && (tm_env ? tm_env == 256 : (tall_k || tall_t));
+        const bool tall = !a.w2 && !a.res && (tm_env ? tm_env == 256 : (tall_k || tall_t));
         const int tm_rows = tall ? 256 : 128;
         dim3 grid((a.M + tm_rows - 1) / tm_rows, (a.N + 127) / 128, a.B);
         aw.ras_tm = aw.ras_tn = 0;

@@ -23,6 +23,10 @@
 #ifndef ACE355_CONV_V2
 #define ACE355_CONV_V2 1   // 0: the round-3 chunk / tap loop (A/B builds: tools/build_variant.sh old conv.hip -DACE355_CONV_V2=0)
 #endif
+#ifndef ACE355_CONV_FUSE2
+#define ACE355_CONV_FUSE2 1   // 0: the fused k = 1 stage with register-staged w2 chunks and parameter loads behind its first barrier
+#endif
+#define ACE355_CONV_F2 (ACE355_CONV_V2 && ACE355_CONV_FUSE2)
 
 namespace ace355 {
 
@@ -39,6 +43,15 @@ __device__ unsigned long long g_conv_probe[8];
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 ld_u32x4(const void* p) {
     return *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<uintptr_t>(p));
+}
+
+// the same with a per-lane 64-bit address (the fused stage's parameter table: three separate vectors in one piece)
+__device__ __forceinline__ void conv_glds16_v(const void* vptr, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(vptr), "s"(lds_addr)
+                 : "memory");
 }
 
 constexpr int HALO_MAX = 64;  // (taps-1)*dil <= 6*9 = 54 rows of halo at most
@@ -65,7 +78,10 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     constexpr int MT = (BN == 128) ? 2 : 1;
     constexpr int NT = (BN == 128) ? 2 : 1;
     constexpr int WCH = BN * 8 / NTHR;  // 16-B weight chunks per thread per tile
-    __shared__ __attribute__((aligned(16))) char smem[WIN_MAX * 128 + 2 * BN * 128];
+    // (4-wave 128 x 128 form: + a third 16 KB weight buffer and a 2 KB parameter table for the fused k = 1 stage: 74 KB, still two
+    //  workgroups per CU like the 8-wave form's 72 KB)
+    constexpr int FUSE_LDS = (ACE355_CONV_F2 && BN == 128 && TM == 128) ? (BN * 128 + 2048) : 0;
+    __shared__ __attribute__((aligned(16))) char smem[WIN_MAX * 128 + 2 * BN * 128 + FUSE_LDS];
     char* As = smem;
     char* Wbase = smem + WIN_MAX * 128;
 
@@ -129,6 +145,12 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     auto w_issue = [&](int tap, int ci0, int buf) {
 #pragma unroll
         for (int i = 0; i < WCH; ++i) w_piece(i, tap, ci0, buf);
+    };
+    // piece i of the 64-channel chunk c2 of w2 [128][128] (fused stage) -> the weight-tile image at `lbase` (this wave's first piece)
+    auto w2_piece = [&](int i, int c2, unsigned lbase) {
+        const int prow = 8 * (wave + NWV * i) + (lane >> 3);
+        const int ls = (lane & 7) ^ ((prow >> 1) & 7);
+        conv_glds16((unsigned)((prow * 128 + ls * 8) * 2), a.w2 + c2 * 64, (unsigned)__builtin_amdgcn_readfirstlane((int)lbase) + (unsigned)i * (NWV * 1024));
     };
 
     // Input window of one 64-channel chunk: all of a thread's (up to 6) 16-byte loads are issued back to back into
@@ -317,6 +339,24 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         for (int tap = 0; tap < taps; ++tap) {
             const bool more = (tap + 1) < taps;
             if (more) w_issue(tap + 1, ci0, (tap + 1) & 1);
+            if constexpr (FUSE_LDS != 0) {
+                // fused residual unit, last chunk: the k = 1 stage's operands arrive under the taps - w2's first 64-channel chunk one
+                // piece per wave per tap (taps 1-4) into the third buffer, the parameter table (bias, snake2 alpha / beta: 3 x 512 B)
+                // at tap 5, w2's second chunk at the last tap into the ring buffer that tap leaves free (launch_conv: taps == 7)
+                if (a.w2 && ci0 + 64 >= Cin) {   // workgroup-uniform
+                    const unsigned w2b = (unsigned)(uintptr_t)(Wbase + 2 * BN * 128) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+                    if (tap >= 1 && tap <= WCH) w2_piece(tap - 1, 0, w2b);
+                    if (tap == WCH + 1 && __builtin_amdgcn_readfirstlane(wave) < 2) {
+                        const float* src = (wave == 0) ? (lane < 32 ? (a.bias ? a.bias : a.alpha2) : a.alpha2) : a.beta2;
+                        conv_glds16_v(src + 4 * (lane & 31), (unsigned)(uintptr_t)(Wbase + 3 * BN * 128) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u);
+                    }
+                    if (!more) {
+                        const unsigned ring = wlds0 + (unsigned)((tap + 1) & 1) * (BN * 128);
+#pragma unroll
+                        for (int i = 0; i < WCH; ++i) w2_piece(i, 1, ring);
+                    }
+                }
+            }
             const char* Ws = Wbase + (tap & 1) * (BN * 128);
             const int arow = wm * (MT * 32) + tap * dil + lq;
             if constexpr (FPIPE) {
@@ -409,6 +449,37 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         if (probe) p_taps += clock64() - p_mark;
     }
 #endif
+    // ---- epilogue operands (declared ahead of the fused stage, which requests them under its MFMAs)
+    const bool full = (m0 + TM <= a.M) && (n0 + BN <= a.N) &&
+                      ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + TM - 1) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
+    const bool wide = BN == 128 && a.out_mode == 0 && full && a.wide_ok;   // the LDS-staged 16-byte epilogue
+    const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NT * 32);
+    const int row_l = lane >> 2, c4 = lane & 3;
+    u32x4 bl[NT], bh[NT];   // bias of this lane's 8 columns per half (fp32 bits)
+    u32x4 rv[2][MT * 2];    // residual rows, double-buffered over the halves
+    // (the 8-wave form is never launched with a residual: launch_conv; its 128-VGPR budget has no room for the residual rows)
+    const bool has_res = (TM == 128) && a.res != nullptr;
+    auto res_load = [&](int j, u32x4 (&r)[MT * 2]) {
+        const long rcol = (long)b * a.res_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
+#pragma unroll
+        for (int t = 0; t < MT * 2; ++t) r[t] = ld_u32x4(a.res + rcol + (long)(mw0 + t * 16 + row_l) * a.N);
+    };
+    auto epi_pre = [&](const float* eb) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bl[j] = u32x4{0u, 0u, 0u, 0u};
+            bh[j] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (eb) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bl[j] = ld_u32x4(eb + nw0 + j * 32 + c4 * 8);
+                bh[j] = ld_u32x4(eb + nw0 + j * 32 + c4 * 8 + 4);
+            }
+        }
+        if (has_res) res_load(0, rv[0]);
+    };
+    bool epi_pre_done = false;
     // ---------------------------------------------------------------- fused k = 1 stage of a residual unit (C = 128)
     // The k = 7 result t = acc + bias never leaves the workgroup: snake2(t) is written to LDS as the A operand of a
     // 128 x 128 x 128 GEMM with w2 (two 64-channel planes over the dead window / first weight buffer, w2 chunks through the
@@ -420,6 +491,75 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             epi_bias = a.bias2;
             const float* b7p = a.bias ? a.bias : a.alpha2;  // (unconditional loads: a branch per element would fence them)
             const float b7s = a.bias ? 1.f : 0.f;
+#if ACE355_CONV_F2
+            __syncthreads();  // every wave is done with the window and the weight tiles
+            char* A2 = smem;                      // 2 planes x 128 rows x 128 B (over the window and the head of ring buffer 0)
+            const char* W2c0 = Wbase + 2 * BN * 128;             // w2 channels 0-63: the third buffer (landed under taps 1-4)
+            const char* W2c1 = Wbase + (taps & 1) * (BN * 128);  // w2 channels 64-127: ring buffer 1 (requested at the last tap)
+            const char* Pt = Wbase + 3 * BN * 128;               // bias | alpha2 | beta2, 128 floats each (landed under tap 5)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u32x4 b4[4], e4[4], i4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = n0 + wn * (NT * 32) + j * 32 + 8 * g + 4 * half;
+                    b4[g] = *reinterpret_cast<const u32x4*>(Pt + c * 4);
+                    e4[g] = *reinterpret_cast<const u32x4*>(Pt + 512 + c * 4);
+                    i4[g] = *reinterpret_cast<const u32x4*>(Pt + 1024 + c * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[i][j][4 * g + e] + b7s * __uint_as_float(b4[g][e]);
+                            const float sn = __sinf(__uint_as_float(e4[g][e]) * v);
+                            t[e] = v + __uint_as_float(i4[g][e]) * sn * sn;
+                        }
+                        const int row = wm * (MT * 32) + i * 32 + lq;
+                        uint2 pk = make_uint2(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]));
+                        *reinterpret_cast<uint2*>(A2 + wn * 16384 + lds_off(row, j * 4 + g) + 8 * half) = pk;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of w2's second chunk
+            __syncthreads();
+            if (wide) { epi_pre(a.bias2); epi_pre_done = true; }   // bias2 + the residual rows arrive under the 32 MFMAs below
+            {   // 128 x 128 x 128: 8 K groups straight through, fragments one group ahead
+                bf16x8 fa[2][MT], fw[2][NT];
+                auto frag2 = [&](int k8, int sl) {
+                    const char* Ap = A2 + (k8 >> 2) * 16384;
+                    const char* Wp = (k8 >> 2) ? W2c1 : W2c0;
+                    const int kk = k8 & 3;
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        fa[sl][i] = as_bf16x8(*reinterpret_cast<const uint4*>(Ap + lds_off(wm * (MT * 32) + i * 32 + lq, kk * 2 + half)));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        fw[sl][j] = as_bf16x8(*reinterpret_cast<const uint4*>(Wp + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
+                };
+                frag2(0, 0);
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) {
+                    if (k8 < 7) frag2(k8 + 1, (k8 + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[k8 & 1][j], fa[k8 & 1][i], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+#else
             __syncthreads();  // every wave is done with the window and the weight tiles
             char* A2 = smem;                      // 2 planes x 128 rows x 128 B
             char* W2s = Wbase + BN * 128;         // second weight buffer (16 KB), beyond the planes
@@ -492,6 +632,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             }
         }
     }
+#endif
     const unsigned long long p_e0 = probe ? clock64() : 0ull;
     auto probe_done = [&]() {
         if (!probe) return;
@@ -506,37 +647,12 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     // g = r>>2, four consecutive channels n = .. + 8g + 4*half + (r&3).  Stores (and the residual loads) of an MFMA epilogue
     // are issue-bound per instruction: interior bf16 tiles go through a wave-private fp32 LDS staging image, one 32-channel
     // half at a time, and leave as 16-byte row-major accesses (8 loads + 8 stores per lane instead of 64 + 64 two-byte ones).
-    const bool full = (m0 + TM <= a.M) && (n0 + BN <= a.N) &&
-                      ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + TM - 1) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
-    const int mw0 = m0 + wm * (MT * 32), nw0 = n0 + wn * (NT * 32);
-    if (BN == 128 && a.out_mode == 0 && full && a.wide_ok) {  // workgroup-uniform
+    if (wide) {  // workgroup-uniform
         // Every global load of the epilogue is requested before it is needed: the bias of both column halves and the first
-        // half's residual rows before the staging, the second half's residual rows before the first half is written.  (They
-        // used to be issued per half, each behind its own wait - eight scalar bias loads behind eight branches, then the
-        // residual rows: four L2 round trips per workgroup, most of the 5.5-7 k cycle epilogue.)
-        const int row_l = lane >> 2, c4 = lane & 3;
-        u32x4 bl[NT], bh[NT];   // bias of this lane's 8 columns per half (fp32 bits)
-        u32x4 rv[2][MT * 2];    // residual rows, double-buffered over the halves
-        // (the 8-wave form is never launched with a residual: launch_conv; its 128-VGPR budget has no room for the residual rows)
-        const bool has_res = (TM == 128) && a.res != nullptr;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bl[j] = u32x4{0u, 0u, 0u, 0u};
-            bh[j] = u32x4{0u, 0u, 0u, 0u};
-        }
-        if (epi_bias) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                bl[j] = ld_u32x4(epi_bias + nw0 + j * 32 + c4 * 8);
-                bh[j] = ld_u32x4(epi_bias + nw0 + j * 32 + c4 * 8 + 4);
-            }
-        }
-        auto res_load = [&](int j, u32x4 (&r)[MT * 2]) {
-            const long rcol = (long)b * a.res_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
-#pragma unroll
-            for (int t = 0; t < MT * 2; ++t) r[t] = ld_u32x4(a.res + rcol + (long)(mw0 + t * 16 + row_l) * a.N);
-        };
-        if (has_res) res_load(0, rv[0]);
+        // half's residual rows before the staging (fused unit, V2: before the k = 1 stage's MFMAs), the second half's residual rows
+        // before the first half is written.  (They used to be issued per half, each behind its own wait - eight scalar bias loads
+        // behind eight branches, then the residual rows: four L2 round trips per workgroup, most of the 5.5-7 k cycle epilogue.)
+        if (!epi_pre_done) epi_pre(epi_bias);
         __syncthreads();  // every wave is done with the operand tiles: the LDS may be overwritten
         char* stg = smem + wave * (MT * 32 * 128);  // MT*32 rows x 128 B (32 floats)
 #pragma unroll
@@ -640,7 +756,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     ACE_CHECK((long)a.N * a.taps * a.Cin * 2 < (1L << 32) && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0,
               "conv: the weight tensor must be 16-byte aligned and smaller than 4 GB (32-bit DMA offsets)");
     ACE_CHECK(a.x_valid ? (a.x_shift % 8 == 0 && a.x_valid % 8 == 0) : a.x_shift == 0, "conv: x_shift / x_valid must be multiples of 8 (and x_shift needs x_valid)");
-    ACE_CHECK(!a.w2 || (a.Cin == 128 && a.N == 128 && !a.x_valid && a.out_mode == 0 && a.alpha2 && a.beta2 &&
+    ACE_CHECK(!a.w2 || (a.Cin == 128 && a.N == 128 && a.taps == 7 && !a.x_valid && a.out_mode == 0 && a.alpha2 && a.beta2 &&
                         (reinterpret_cast<uintptr_t>(a.alpha2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.beta2) & 15) == 0 &&
                         (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.w2) & 15) == 0),
               "conv: the fused k = 1 stage needs Cin = N = 128, a plain conv and 16-byte aligned vectors");
@@ -682,8 +798,14 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         // wrong for the k = 7 convs: the tall tile wins at every batch (one song: 205 -> 190, 259 -> 221, 240 -> 197 us at C = 1024 / 512 /
         // 256; two songs: 328 -> 254, 450 -> 376 us), down to the 472 four-wave tiles of one 30 s song at C = 1024: threshold 448.  The
         // plain-row transposed convs with Cin >= 1024 gain from ~ 900 four-wave tiles up (one song, 2048 -> 1024, 480 tiles: 149 -> 170 us).
-        const bool tall_k = a.Cin >= 256 && a.taps >= 3 && wgs128 >= 448;
-        const bool tall_t = a.taps == 2 && a.Cin >= 1024 && !a.alpha && !a.x_valid && wgs128 >= 900;
+        // Round 5, after version 2 of the chunk / tap loop (the 8-wave form no longer spills, its window loads are no longer serialised
+        // by scratch reloads): re-swept at 1 / 2 / 4 / 8 songs (profiles/r05_conv_tile_height_sweep.txt).  The 8-wave tile now wins on
+        // EVERY k >= 2 launch that fills the chip about one and a half times (512 tall workgroups are resident at once = 1024 four-wave
+        // tiles): the transposed convs at every Cin (8 songs: 1645 -> 1388, 1256 -> 1069, 1020 -> 845 us for Cin = 128 / 256 / 512), the k = 7
+        // convs from ~1400 four-wave tiles (one song: C = 256 204 -> 175 us, C = 512 224 -> 221, C = 1024 (472 tiles) 177 -> 197: stays 4-wave;
+        // two songs: all three win), the unfused k = 7 at C = 128 too (3.38 -> 2.98 ms).  Below that the tail of half-empty rounds costs more.
+        const bool tall_k = a.Cin >= 128 && a.taps >= 3 && wgs128 >= 1400;
+        const bool tall_t = a.taps == 2 && a.Cin >= 128 && !a.alpha && !a.x_valid && wgs128 >= 1500;
         const bool tall = !a.w2 && !a.res && (tm_env ? tm_env == 256 : (tall_k || tall_t));
         const int tm_rows = tall ? 256 : 128;
         dim3 grid((a.M + tm_rows - 1) / tm_rows, (a.N + 127) / 128, a.B);

@@ -67,28 +67,43 @@ __device__ __forceinline__ void conv_glds16(unsigned voff, const void* sbase, un
                  : "memory");
 }
 
+// K slots of the fused k = 1 stage.  The 8-wave form feeds snake2(t) to the MFMA straight from the k = 7 accumulators, and an accumulator
+// lane (row, half h) holds channels 8 g + 4 h + (0..3) of every 32-channel tile: the eight values it can supply to K group q (16
+// channels) are 16 q + 4 h + (0..3) and 16 q + 8 + 4 h + (0..3) - not the 8 h + (0..7) of a plain fragment.  Both forms of the stage
+// therefore use THAT slot order for both operands (two 8-byte reads 16 bytes apart instead of one 16-byte read), so that a unit is the same
+// bits whichever form launch_conv picks for its size (window decodes must equal whole-sequence decodes).
+__device__ __forceinline__ bf16x8 frag_kperm(const char* base, int row, int q, int h) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(base + lds_off(row, 2 * q) + 8 * h);
+    const uint2 hi = *reinterpret_cast<const uint2*>(base + lds_off(row, 2 * q + 1) + 8 * h);
+    return as_bf16x8(make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
 // TM = positions per workgroup, one wave per 64 x 64 (BN = 128) sub-tile: 128 -> 4 waves, 256 -> 8 waves.  The 8-wave
 // form shares each weight tile between twice as many MFMAs, shrinks the Snake halo from 1.42x to 1.21x of the tile and puts
 // 4 waves on every SIMD (2 workgroups per CU either way), which is what hides the per-tap barrier and the staging phases.
-template <int BN, int TM>
+// WS = 1 (TM = 256, BN = 128; the fused residual unit at C = 128 on the 8-wave tile, round 5): a wave owns 32 rows x ALL 128 output
+// channels (MT = 1, NT = 4) instead of a 64 x 64 sub-tile, so the k = 7 result of its rows never has to meet another wave's: snake2(t)
+// goes from the accumulators straight into the B operand of the k = 1 stage's MFMAs (no LDS image, no barrier between the stages).
+template <int BN, int TM, int WS = 0>
 __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     static_assert(TM == 128 || (TM == 256 && BN == 128), "tile shapes");
+    static_assert(WS == 0 || (TM == 256 && BN == 128 && ACE355_CONV_F2), "the 32 x 128 wave shape belongs to the fused 8-wave form");
     constexpr int NTHR = TM * 2;
     constexpr int WIN_MAX = TM + HALO_MAX;
-    constexpr int MT = (BN == 128) ? 2 : 1;
-    constexpr int NT = (BN == 128) ? 2 : 1;
+    constexpr int MT = WS ? 1 : ((BN == 128) ? 2 : 1);
+    constexpr int NT = WS ? 4 : ((BN == 128) ? 2 : 1);
     constexpr int WCH = BN * 8 / NTHR;  // 16-B weight chunks per thread per tile
     // (4-wave 128 x 128 form: + a third 16 KB weight buffer and a 2 KB parameter table for the fused k = 1 stage: 74 KB, still two
-    //  workgroups per CU like the 8-wave form's 72 KB)
-    constexpr int FUSE_LDS = (ACE355_CONV_F2 && BN == 128 && TM == 128) ? (BN * 128 + 2048) : 0;
+    //  workgroups per CU like the 8-wave form's 72 KB; WS = 1: the table only, w2 goes through the ring)
+    constexpr int FUSE_LDS = (ACE355_CONV_F2 && BN == 128 && TM == 128) ? (BN * 128 + 2048) : (WS ? 2048 : 0);
     __shared__ __attribute__((aligned(16))) char smem[WIN_MAX * 128 + 2 * BN * 128 + FUSE_LDS];
     char* As = smem;
     char* Wbase = smem + WIN_MAX * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, half = lane >> 5;
-    const int wm = (BN == 128) ? (wave >> 1) : wave;
-    const int wn = (BN == 128) ? (wave & 1) : 0;
+    const int wm = WS ? wave : ((BN == 128) ? (wave >> 1) : wave);
+    const int wn = WS ? 0 : ((BN == 128) ? (wave & 1) : 0);
     // Rasterisation.  Workgroups are handed to the 8 XCDs round-robin by linear id, each XCD has its own L2, and with the plain (m, n, b)
     // grid the column tiles of one row block are tiles_m launches-slots apart: every one of them pulled the same input window from HBM
     // (2x at C = 256 ... 8x at C = 1024 for the k = 1 convs, s * Cout / 128 times for the transposed ones).  With ras_tn > 1 the grid is
@@ -159,37 +174,38 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     constexpr int WLD = (WIN_MAX * 8 + NTHR - 1) / NTHR;
     // the 4-wave form keeps the next chunk's window loads in flight across the tap loop; with 4 waves per SIMD the 8-wave
     // form has no registers to spare for that (128-VGPR budget) and other waves to cover the latency instead
-    constexpr bool PREFETCH = (TM == 128);
+    constexpr bool PREFETCH = (TM == 128) || (WS == 1);   // (WS = 1: two chunks only, and the rows' registers are idle across the taps)
+    constexpr bool PARPRE = (TM == 128);                  // Snake parameters requested with the rows (16 more registers across the taps)
     u32x4 wv[WLD];
     const bool snake = a.alpha != nullptr;
 #if ACE355_CONV_V2
-    // V2 addressing: one loop-invariant 32-bit byte offset per thread (its row within a block of NTHR / 8 window rows, its 16-byte slot)
-    // on top of a UNIFORM 64-bit base per (chunk, row block) - the `global_load_dwordx4 v, v_off, s[base]` form - and the bounds as
-    // two uniform 32-bit limits per row block.  Version 1 kept a 64-bit address and a lane mask per load alive across the chunk
-    // loop: in the 8-wave form (128 VGPRs) they were spilled, and every reload's `s_waitcnt vmcnt(0)` (scratch loads count in vmcnt)
-    // sat between two window loads - five serialised memory round trips per chunk instead of one.
+    // V2 addressing: a buffer descriptor per workgroup and one loop-invariant 32-bit byte offset per thread (its row within a block of
+    // NTHR / 8 window rows, its 16-byte slot) plus a uniform offset per (chunk, row block).  The hardware's range check replaces the
+    // predicates: the descriptor covers [max(first window element, 0), end of the valid flat range) of this batch item, an offset
+    // below it wraps to > 2^31 and one past it exceeds num_records - both read zeros, which is what rows outside the signal are
+    // (rows beyond the window but inside the tensor are loaded and never stored).  Version 1 kept a 64-bit address and a lane mask
+    // per load alive across the chunk loop: in the 8-wave form (128 VGPRs) they were spilled, and every reload's `s_waitcnt vmcnt(0)`
+    // (scratch loads count in vmcnt) sat between two window loads - five serialised memory round trips per chunk instead of one.
     const int wrow_t = tid >> 3;                                        // row within a row block
     const unsigned x_voff = (unsigned)((wrow_t * Cin + sslot * 8) * 2);  // bytes; <= 64 rows x 2048 channels x 2 B
+    const long xw_f0 = (long)x_row0 * Cin + a.x_shift;                   // flat index of (window row 0, channel 0); may be negative
+    const long xw_end = a.x_valid ? a.x_valid : (long)a.L_in * Cin;      // the valid flat range of this item is [0, xw_end)
+    const long xw_fb = max(xw_f0, 0L);
+    const int xw_neg = (int)((xw_f0 - xw_fb) * 2);                        // <= 0: bytes from the descriptor's base back to window row 0
+    const uintptr_t xw_bp = reinterpret_cast<uintptr_t>(xb + xw_fb);
+    const unsigned xw_lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xw_bp);
+    const unsigned xw_hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xw_bp >> 32));
+    const unsigned xw_nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)max(0L, min((xw_end - xw_fb) * 2, 0x7fffffffL)));
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)xw_hi32 << 32) | xw_lo32), (short)0, (int)xw_nrec, 0x00020000);
     auto win_load = [&](int ci0) {
 #pragma unroll
         for (int i = 0; i < WLD; ++i) {
-            const int r0 = i * (NTHR / 8);                // first window row of this block (uniform)
-            const long u = (long)(x_row0 + r0) * Cin + ci0 + a.x_shift;   // flat element index of (row r0, channel ci0): uniform
-            int lo, hi;   // the thread's element is read iff lo <= key < hi
-            int key;
-            if (a.x_valid) {  // strided-conv view: 0 <= u + wrow_t * Cin + sslot * 8 < x_valid, rows < win_rows
-                key = wrow_t * Cin + sslot * 8;
-                const long l = -u, h = a.x_valid - u, hr = (long)(win_rows - r0) * Cin;
-                lo = (int)max(0L, min(l, 0x7fffffffL));
-                hi = (int)max(0L, min(min(h, hr), 0x7fffffffL));
-            } else {          // plain rows: 0 <= x_row0 + r0 + wrow_t < L_in, r0 + wrow_t < win_rows
-                key = wrow_t;
-                lo = max(0, -(x_row0 + r0));
-                hi = max(0, min(a.L_in - (x_row0 + r0), win_rows - r0));
-            }
-            const char* sb = reinterpret_cast<const char*>(xb + u);   // uniform (may point below the tensor: only `inside` lanes load)
-            wv[i] = u32x4{0u, 0u, 0u, 0u};
-            if (key >= lo && key < hi) wv[i] = ld_u32x4(sb + (size_t)x_voff);
+            // uniform part in the scalar offset (one address VGPR for all row blocks); where it is negative - row block 0 of a tile at the
+            // start of the signal - it goes into the lane's offset instead, so that the range check sees the wrapped value
+            const int uoff = xw_neg + (i * (NTHR / 8) * Cin + ci0) * 2;   // uniform
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)x_voff + min(uoff, 0), max(uoff, 0), 0);
+            wv[i] = __builtin_bit_cast(u32x4, v);
         }
     };
 #else
@@ -220,6 +236,12 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     };
     const int st0 = lds_off(tid >> 3, sslot);
 #if ACE355_CONV_V2
+    auto vec_rsrc = [&](const float* p, int n) {
+        const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uintptr_t)hi << 32) | lo), (short)0, p ? n * 4 : 0, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t sa_rsrc = vec_rsrc(a.alpha, Cin), sb_rsrc = vec_rsrc(a.beta, Cin);
     // Snake of one bf16 pair: x + 1/(e^beta + 1e-9) * sin^2(e^alpha x) (fp32; Snake(0) = 0, so zero rows - outside the signal or
     // beyond the window - pass through unchanged and the arithmetic needs no row predicate, only the store does)
     auto snake_pair = [&](unsigned p, unsigned a0, unsigned b0, unsigned a1, unsigned b1) -> unsigned {
@@ -229,7 +251,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     };
     auto win_store = [&](int ci0) {
         if (snake) {
-            if constexpr (PREFETCH) {   // parameters requested with the rows (spa / spb)
+            if constexpr (PARPRE) {   // parameters requested with the rows (spa / spb)
 #pragma unroll
                 for (int i = 0; i < WLD; ++i)
 #pragma unroll
@@ -241,8 +263,9 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                 // spilled them as they arrived (load, vmcnt(0), scratch store, next load)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const u32x4 pa = ld_u32x4(a.alpha + ci0 + sslot * 8 + 4 * h);
-                    const u32x4 pb = ld_u32x4(a.beta + ci0 + sslot * 8 + 4 * h);
+                    // (descriptor + 32-bit lane offset + scalar offset: no 64-bit address VGPRs to keep - or spill - across the chunk loop)
+                    const u32x4 pa = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sa_rsrc, sslot * 32, (ci0 + 4 * h) * 4, 0));
+                    const u32x4 pb = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sb_rsrc, sslot * 32, (ci0 + 4 * h) * 4, 0));
 #pragma unroll
                     for (int i = 0; i < WLD; ++i)
 #pragma unroll
@@ -320,7 +343,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     // Snake arithmetic, the next chunk's window rows behind the staging barrier (they land under tap 0), and the fragments of K
     // group kk + 1 are requested ahead of the MFMAs of group kk (4-wave form: registers to spare).
     constexpr bool FPIPE = (TM == 128);
-    if (PREFETCH) { win_load(0); par_load(0); }
+    if (PREFETCH) { win_load(0); if (PARPRE) par_load(0); }
     for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
         if (probe) p_mark = clock64();
         if (!PREFETCH) win_load(ci0);
@@ -333,27 +356,34 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         win_store(ci0);       // Snake in fp32 registers, parked in LDS once per chunk
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA
         __syncthreads();
-        if (PREFETCH && ci0 + 64 < Cin) { win_load(ci0 + 64); par_load(ci0 + 64); }
+        if (PREFETCH && ci0 + 64 < Cin) { win_load(ci0 + 64); if (PARPRE) par_load(ci0 + 64); }
         if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
 
+#pragma unroll 1   // (hipcc unrolled the WS = 1 form's tap loop by its trip-count guess and hoisted every tap's fragment addresses: 169 VGPRs)
         for (int tap = 0; tap < taps; ++tap) {
             const bool more = (tap + 1) < taps;
             if (more) w_issue(tap + 1, ci0, (tap + 1) & 1);
             if constexpr (FUSE_LDS != 0) {
-                // fused residual unit, last chunk: the k = 1 stage's operands arrive under the taps - w2's first 64-channel chunk one
-                // piece per wave per tap (taps 1-4) into the third buffer, the parameter table (bias, snake2 alpha / beta: 3 x 512 B)
-                // at tap 5, w2's second chunk at the last tap into the ring buffer that tap leaves free (launch_conv: taps == 7)
+                // fused residual unit, last chunk: the k = 1 stage's operands arrive under the taps.  4-wave form: w2's first 64-channel
+                // chunk one piece per wave per tap (taps 1-4) into the third buffer, w2's second chunk at the last tap into the ring buffer
+                // that tap leaves free; 8-wave form (no third buffer): the FIRST chunk at the last tap into the free ring buffer, the second
+                // behind the barrier that closes the taps.  The parameter table (bias | snake2 alpha | snake2 beta | bias2: 4 x 512 B) at tap
+                // 5, one piece from each of waves 0 and 1 (launch_conv: taps == 7)
                 if (a.w2 && ci0 + 64 >= Cin) {   // workgroup-uniform
-                    const unsigned w2b = (unsigned)(uintptr_t)(Wbase + 2 * BN * 128) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
-                    if (tap >= 1 && tap <= WCH) w2_piece(tap - 1, 0, w2b);
-                    if (tap == WCH + 1 && __builtin_amdgcn_readfirstlane(wave) < 2) {
-                        const float* src = (wave == 0) ? (lane < 32 ? (a.bias ? a.bias : a.alpha2) : a.alpha2) : a.beta2;
-                        conv_glds16_v(src + 4 * (lane & 31), (unsigned)(uintptr_t)(Wbase + 3 * BN * 128) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u);
+                    constexpr int PT_OFF = (WS ? 2 : 3) * BN * 128;
+                    if constexpr (WS == 0) {
+                        const unsigned w2b = (unsigned)(uintptr_t)(Wbase + 2 * BN * 128) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+                        if (tap >= 1 && tap <= WCH) w2_piece(tap - 1, 0, w2b);
+                    }
+                    if (tap == 5 && __builtin_amdgcn_readfirstlane(wave) < 2) {
+                        const float* src = (wave == 0) ? (lane < 32 ? (a.bias ? a.bias : a.alpha2) : a.alpha2)
+                                                       : (lane < 32 ? a.beta2 : (a.bias2 ? a.bias2 : a.beta2));
+                        conv_glds16_v(src + 4 * (lane & 31), (unsigned)(uintptr_t)(Wbase + PT_OFF) + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u);
                     }
                     if (!more) {
                         const unsigned ring = wlds0 + (unsigned)((tap + 1) & 1) * (BN * 128);
 #pragma unroll
-                        for (int i = 0; i < WCH; ++i) w2_piece(i, 1, ring);
+                        for (int i = 0; i < WCH; ++i) w2_piece(i, WS ? 0 : 1, ring);
                     }
                 }
             }
@@ -458,7 +488,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     u32x4 bl[NT], bh[NT];   // bias of this lane's 8 columns per half (fp32 bits)
     u32x4 rv[2][MT * 2];    // residual rows, double-buffered over the halves
     // (the 8-wave form is never launched with a residual: launch_conv; its 128-VGPR budget has no room for the residual rows)
-    const bool has_res = (TM == 128) && a.res != nullptr;
+    const bool has_res = (TM == 128 || WS == 1) && a.res != nullptr;
     auto res_load = [&](int j, u32x4 (&r)[MT * 2]) {
         const long rcol = (long)b * a.res_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
 #pragma unroll
@@ -470,7 +500,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             bl[j] = u32x4{0u, 0u, 0u, 0u};
             bh[j] = u32x4{0u, 0u, 0u, 0u};
         }
-        if (eb) {
+        if (eb && WS == 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 bl[j] = ld_u32x4(eb + nw0 + j * 32 + c4 * 8);
@@ -486,6 +516,62 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     // second weight buffer), and the epilogue below then adds bias2 and the residual.  Two of the unit's five tensor passes
     // (write t, read t) and one launch disappear.
     const float* epi_bias = a.bias;
+    bool bias_in_lds = false;   // WS = 1 fused: bias2 is read from the parameter table (no registers for it across the epilogue)
+    if constexpr (WS == 1) {
+        if (a.w2) {  // workgroup-uniform
+            epi_bias = a.bias2;
+            bias_in_lds = a.bias2 != nullptr;
+            const float b7s = a.bias ? 1.f : 0.f;
+            const char* W2c0 = Wbase + (taps & 1) * (BN * 128);        // w2 channels 0-63: the ring buffer the last tap left free
+            const char* W2c1 = Wbase + ((taps + 1) & 1) * (BN * 128);  // w2 channels 64-127: the last tap's own buffer, requested below
+            const char* Pt = Wbase + 2 * BN * 128;                     // bias | alpha2 | beta2 | bias2 (landed under tap 5)
+            __syncthreads();  // every wave is done with the window and the last tap's weight tile
+            {
+                const unsigned ring = wlds0 + (unsigned)(taps & 1 ? 0 : 1) * (BN * 128);
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) w2_piece(i, 1, ring);   // lands under the Snake arithmetic
+            }
+            // snake2(k7 + bias) of this wave's 32 rows x 128 channels, packed to bf16 in MFMA B-operand order: sp[j][g] = channels
+            // 32 j + 8 g + 4 half + (0..3) of row lq
+            uint2 sp[NT][4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {   // one register quad at a time: 12 parameter registers live, 4 accumulators become 2 packed ones
+                    const int c = j * 32 + 8 * g + 4 * half;
+                    const u32x4 b4 = *reinterpret_cast<const u32x4*>(Pt + c * 4);
+                    const u32x4 e4 = *reinterpret_cast<const u32x4*>(Pt + 512 + c * 4);
+                    const u32x4 i4 = *reinterpret_cast<const u32x4*>(Pt + 1024 + c * 4);
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[0][j][4 * g + e] + b7s * __uint_as_float(b4[e]);
+                        const float sn = __sinf(__uint_as_float(e4[e]) * v);
+                        t[e] = v + __uint_as_float(i4[e]) * sn * sn;
+                    }
+                    sp[j][g] = make_uint2(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of both w2 chunks
+            __syncthreads();
+            // 128 x 128 K per wave row block: K group kg = channels 16 kg .. 16 kg + 15 (slot order: frag_kperm), B operand from sp
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const char* Wp = (kg >> 2) ? W2c1 : W2c0;
+                const uint2 s0 = sp[kg >> 1][2 * (kg & 1)], s1 = sp[kg >> 1][2 * (kg & 1) + 1];
+                const bf16x8 fb = as_bf16x8(make_uint4(s0.x, s0.y, s1.x, s1.y));
+                bf16x8 fw[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fw[j] = frag_kperm(Wp, j * 32 + lq, kg & 3, half);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[0][j] = mfma32(fw[j], fb, acc[0][j]);
+            }
+        }
+    }
     if constexpr (BN == 128 && TM == 128) {
         if (a.w2) {  // workgroup-uniform
             epi_bias = a.bias2;
@@ -496,7 +582,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             char* A2 = smem;                      // 2 planes x 128 rows x 128 B (over the window and the head of ring buffer 0)
             const char* W2c0 = Wbase + 2 * BN * 128;             // w2 channels 0-63: the third buffer (landed under taps 1-4)
             const char* W2c1 = Wbase + (taps & 1) * (BN * 128);  // w2 channels 64-127: ring buffer 1 (requested at the last tap)
-            const char* Pt = Wbase + 3 * BN * 128;               // bias | alpha2 | beta2, 128 floats each (landed under tap 5)
+            const char* Pt = Wbase + 3 * BN * 128;               // bias | alpha2 | beta2 | bias2, 128 floats each (landed under tap 5)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 u32x4 b4[4], e4[4], i4[4];
@@ -539,11 +625,9 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     const char* Wp = (k8 >> 2) ? W2c1 : W2c0;
                     const int kk = k8 & 3;
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        fa[sl][i] = as_bf16x8(*reinterpret_cast<const uint4*>(Ap + lds_off(wm * (MT * 32) + i * 32 + lq, kk * 2 + half)));
+                    for (int i = 0; i < MT; ++i) fa[sl][i] = frag_kperm(Ap, wm * (MT * 32) + i * 32 + lq, kk, half);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        fw[sl][j] = as_bf16x8(*reinterpret_cast<const uint4*>(Wp + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
+                    for (int j = 0; j < NT; ++j) fw[sl][j] = frag_kperm(Wp, wn * (NT * 32) + j * 32 + lq, kk, half);
                 };
                 frag2(0, 0);
 #pragma unroll
@@ -676,6 +760,16 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                 }
             }
             const long col = (long)b * a.y_batch_stride + nw0 + j * 32 + c4 * 8 + a.y_shift;
+            if constexpr (WS == 1) {   // 128-VGPR form: this half's bias from the parameter table in LDS (fused unit), else from memory
+                if (bias_in_lds) {
+                    const char* pb = Wbase + 2 * BN * 128 + 1536 + (nw0 + j * 32 + c4 * 8) * 4;
+                    bl[j] = *reinterpret_cast<const u32x4*>(pb);
+                    bh[j] = *reinterpret_cast<const u32x4*>(pb + 16);
+                } else if (epi_bias) {
+                    bl[j] = ld_u32x4(epi_bias + nw0 + j * 32 + c4 * 8);
+                    bh[j] = ld_u32x4(epi_bias + nw0 + j * 32 + c4 * 8 + 4);
+                }
+            }
             const float bias[8] = {__uint_as_float(bl[j][0]), __uint_as_float(bl[j][1]), __uint_as_float(bl[j][2]), __uint_as_float(bl[j][3]),
                                    __uint_as_float(bh[j][0]), __uint_as_float(bh[j][1]), __uint_as_float(bh[j][2]), __uint_as_float(bh[j][3])};
 #pragma unroll
@@ -814,6 +908,21 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
             aw.ras_tm = (int)grid.x, aw.ras_tn = (int)grid.y;
             grid = dim3(grid.x * grid.y, 1, a.B);
         }
+#if ACE355_CONV_F2
+        // fused residual unit (C = 128): the 8-wave form with 32 x 128 wave tiles from the same size threshold as the other k = 7 convs
+        // (ACE355_CONV_F8=0 / 1: never / always, A/B runs); both forms give the same bits (frag_kperm)
+        static int f8_env = -2;
+        if (f8_env == -2) {
+            const char* e = getenv("ACE355_CONV_F8");
+            f8_env = e ? atoi(e) : -1;
+        }
+        const bool f8 = a.w2 && (f8_env >= 0 ? f8_env != 0 : wgs128 >= 1400);
+        if (f8) {
+            dim3 g8((a.M + 255) / 256, 1, a.B);
+            aw.ras_tm = aw.ras_tn = 0;
+            hipLaunchKernelGGL((conv_kernel<128, 256, 1>), g8, dim3(512), 0, s, aw);
+        } else
+#endif
         if (tall) hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);
         else hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(256), 0, s, aw);
     } else {

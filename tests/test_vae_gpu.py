@@ -251,3 +251,32 @@ def test_snake_placement_switch_agrees(gpu_device):
         print(f"Snake placement 1 vs 0, {k}: {snr:.1f} dB")
         assert snr > 35.0, (k, snr)
         assert not torch.equal(outs["1"][k], outs["0"][k])
+
+
+def test_fused_unit_forms_agree_bit_for_bit(gpu_device):
+    """conv.hip runs the fused residual unit (C = 128) on a 4-wave 128-row tile (snake2(k7) through an LDS image) or, from ~1400 tiles up,
+    on an 8-wave 256-row tile whose waves own 32 rows x all 128 channels (snake2(k7) from the accumulators straight into the k = 1
+    stage's MFMAs).  `launch_conv` picks by problem size, and a windowed decode must equal a whole-sequence decode, so the two forms
+    present the same K-slot order to the matrix unit (frag_kperm) and must give the SAME BITS.  ACE355_CONV_F8 = 0 / 1 forces one form at
+    every size (read once per process: child processes); the full-width config so that the C = 128 units exist."""
+    import subprocess, sys, os, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import ace355\nfrom ace355 import weightgen\nfrom ace355.vae import NativeVae\n"
+        "cfg = ace355.VaeConfig()\n"
+        "w = weightgen.make_vae_weights({**cfg.weight_shapes(), **cfg.encoder_weight_shapes()}, seed=2, mode='test')\n"
+        "vae = NativeVae(cfg, 'cuda:0'); vae.load_state_dict(w)\n"
+        "z = torch.randn(2, 64, 41, generator=torch.Generator().manual_seed(5))\n"
+        "a = 0.3 * torch.randn(1, 2, cfg.hop * 12, generator=torch.Generator().manual_seed(6))\n"
+        "torch.save({'wav': vae.decode(z).cpu(), 'mean': vae.encode(a, sample=False).cpu()}, sys.argv[1])\n" % (root,))
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for v in ("0", "1"):
+            path = os.path.join(d, f"o{v}.pt")
+            env = dict(os.environ, ACE355_CONV_F8=v)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+            outs[v] = torch.load(path)
+    for k in ("wav", "mean"):
+        assert torch.isfinite(outs["1"][k]).all()
+        assert torch.equal(outs["1"][k], outs["0"][k]), (k, float((outs["1"][k] - outs["0"][k]).abs().max()))

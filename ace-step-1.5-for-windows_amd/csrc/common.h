@@ -327,6 +327,8 @@ struct ConvArgs {
     // set by launch_conv: XCD-aware rasterisation of the (row block, column tile) grid (ras_tn > 1: a 1-D grid of ras_tm * ras_tn
     // workgroups per batch item, the column tiles of one row block on consecutive slots of ONE XCD); 0: the plain (m, n, b) grid
     int ras_tm; int ras_tn;
+    // set by launch_conv (ACE355_CONV_DEPHASE): the first `dephase_n` workgroups' second residents sleep `dephase` x 4096 cycles once
+    int dephase; int dephase_n;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s);

@@ -122,6 +122,19 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             bx = full + l2 / tn;
         }
     }
+    // De-phasing (ACE355_CONV_DEPHASE, round 5).  The two workgroups of a CU start together and run the same sequence of phases - Snake
+    // staging (VALU), taps (MFMA), epilogue (memory) - in lock step: the matrix pipe is contended in the taps and idle in the stagings.
+    // The first generation's second workgroup per CU (wave slots beyond the first workgroup's: HW_ID.WAVE_ID) sleeps once at the start;
+    // later generations start when a slot frees and inherit the offset.
+    if (a.dephase > 0) {   // workgroup-uniform
+        const long lin = (long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+        if (lin < a.dephase_n) {
+            const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_REG_HW_ID, WAVE_ID[3:0]: the wave's slot on its SIMD
+            if ((int)slot >= NTHR / 256) {
+                for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles per unit
+            }
+        }
+    }
     const int m0 = bx * TM, n0 = by * BN, b = blockIdx.z;
     const int Cin = a.Cin, taps = a.taps, dil = a.dil;
     const int win_rows = TM + (taps - 1) * dil;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     constexpr int WLD = (WIN_MAX * 8 + NTHR - 1) / NTHR;
     // the 4-wave form keeps the next chunk's window loads in flight across the tap loop; with 4 waves per SIMD the 8-wave
     // form has no registers to spare for that (128-VGPR budget) and other waves to cover the latency instead
-    constexpr bool PREFETCH = (TM == 128) || (WS == 1);   // (WS = 1: two chunks only, and the rows' registers are idle across the taps)
+    constexpr bool PREFETCH = true;   // (round 5: the 8-wave forms too - with descriptor loads the rows fit their 128 VGPRs across the taps)
     constexpr bool PARPRE = (TM == 128);                  // Snake parameters requested with the rows (16 more registers across the taps)
     u32x4 wv[WLD];
     const bool snake = a.alpha != nullptr;
@@ -862,7 +875,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
                      (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
                      (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
     }
-    static int tm_env = -1, clk_env = -1, ras_env = -1;
+    static int tm_env = -1, clk_env = -1, ras_env = -1, deph_env = -1;
+    if (deph_env < 0) {
+        const char* e = getenv("ACE355_CONV_DEPHASE");   // units of 4096 cycles the second workgroup of a CU sleeps at the start (0: off)
+        deph_env = e ? atoi(e) : 0;
+    }
+    aw.dephase = deph_env; aw.dephase_n = 512;   // 256 CUs x 2 resident workgroups
     if (ras_env < 0) {
         const char* e = getenv("ACE355_CONV_RAS");  // 0: the plain (m, n, b) grid (A/B runs); default 1: XCD-aware rasterisation
         ras_env = e ? atoi(e) : 1;

@@ -257,20 +257,28 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t sa_rsrc = vec_rsrc(a.alpha, Cin), sb_rsrc = vec_rsrc(a.beta, Cin);
     // Snake of one bf16 pair: x + 1/(e^beta + 1e-9) * sin^2(e^alpha x) (fp32; Snake(0) = 0, so zero rows - outside the signal or
     // beyond the window - pass through unchanged and the arithmetic needs no row predicate, only the store does)
-    auto snake_pair = [&](unsigned p, unsigned a0, unsigned b0, unsigned a1, unsigned b1) -> unsigned {
+    // (a0 / a1 arrive in REVOLUTIONS - exp(alpha) / 2 pi, folded once per thread and chunk by rev4 below: v_sin_f32 takes its argument
+    //  in revolutions, and `__sinf(a * x)` spent a second multiply per element on the conversion)
+    auto snake_pair = [&](unsigned p, float a0, unsigned b0, float a1, unsigned b1) -> unsigned {
         const float x0 = bf_lo(p), x1 = bf_hi(p);
-        const float s0 = __sinf(__uint_as_float(a0) * x0), s1 = __sinf(__uint_as_float(a1) * x1);
+        const float s0 = __builtin_amdgcn_sinf(a0 * x0), s1 = __builtin_amdgcn_sinf(a1 * x1);
         return pack_bf2(x0 + __uint_as_float(b0) * s0 * s0, x1 + __uint_as_float(b1) * s1 * s1);
+    };
+    auto rev4 = [&](const u32x4& v, float (&o)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __uint_as_float(v[e]) * 0.15915494309189535f;
     };
     auto win_store = [&](int ci0) {
         if (snake) {
             if constexpr (PARPRE) {   // parameters requested with the rows (spa / spb)
+                float ra[2][4];
+                rev4(spa[0], ra[0]); rev4(spa[1], ra[1]);
 #pragma unroll
                 for (int i = 0; i < WLD; ++i)
 #pragma unroll
                     for (int e2 = 0; e2 < 4; ++e2)
-                        wv[i][e2] = snake_pair(wv[i][e2], spa[e2 >> 1][2 * (e2 & 1)], spb[e2 >> 1][2 * (e2 & 1)],
-                                               spa[e2 >> 1][2 * (e2 & 1) + 1], spb[e2 >> 1][2 * (e2 & 1) + 1]);
+                        wv[i][e2] = snake_pair(wv[i][e2], ra[e2 >> 1][2 * (e2 & 1)], spb[e2 >> 1][2 * (e2 & 1)],
+                                               ra[e2 >> 1][2 * (e2 & 1) + 1], spb[e2 >> 1][2 * (e2 & 1) + 1]);
             } else {
                 // 8-wave form (128 VGPRs): the parameters of four channels at a time; with all sixteen values requested at once hipcc
                 // spilled them as they arrived (load, vmcnt(0), scratch store, next load)
@@ -279,11 +287,13 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                     // (descriptor + 32-bit lane offset + scalar offset: no 64-bit address VGPRs to keep - or spill - across the chunk loop)
                     const u32x4 pa = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sa_rsrc, sslot * 32, (ci0 + 4 * h) * 4, 0));
                     const u32x4 pb = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(sb_rsrc, sslot * 32, (ci0 + 4 * h) * 4, 0));
+                    float ra[4];
+                    rev4(pa, ra);
 #pragma unroll
                     for (int i = 0; i < WLD; ++i)
 #pragma unroll
                         for (int q = 0; q < 2; ++q)
-                            wv[i][2 * h + q] = snake_pair(wv[i][2 * h + q], pa[2 * q], pb[2 * q], pa[2 * q + 1], pb[2 * q + 1]);
+                            wv[i][2 * h + q] = snake_pair(wv[i][2 * h + q], ra[2 * q], pb[2 * q], ra[2 * q + 1], pb[2 * q + 1]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

@@ -27,6 +27,9 @@
 #define ACE355_CONV_FUSE2 1   // 0: the fused k = 1 stage with register-staged w2 chunks and parameter loads behind its first barrier
 #endif
 #define ACE355_CONV_F2 (ACE355_CONV_V2 && ACE355_CONV_FUSE2)
+#ifndef ACE355_CONV_PRIO
+#define ACE355_CONV_PRIO 0   // 1-3: s_setprio of a wave inside its tap loops (A/B builds)
+#endif
 
 namespace ace355 {
 
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     // BUILTIN vmcnt(0) (visible to hipcc's counter model) closes the staging on every path, the tap-0 tile is requested ahead of the
     // Snake arithmetic, the next chunk's window rows behind the staging barrier (they land under tap 0), and the fragments of K
     // group kk + 1 are requested ahead of the MFMAs of group kk (4-wave form: registers to spare).
-    constexpr bool FPIPE = (TM == 128);
+    constexpr bool FPIPE = (TM == 128);   // (8-wave forms: no registers for a second fragment set - the fused form tried it and spilled 17)
     if (PREFETCH) { win_load(0); if (PARPRE) par_load(0); }
     for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
         if (probe) p_mark = clock64();
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         if (PREFETCH && ci0 + 64 < Cin) { win_load(ci0 + 64); if (PARPRE) par_load(ci0 + 64); }
         if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
 
+#if ACE355_CONV_PRIO
+        __builtin_amdgcn_s_setprio(ACE355_CONV_PRIO);   // the taps' MFMA issue ahead of the other waves' Snake / epilogue VALU streams
+#endif
 #pragma unroll 1   // (hipcc unrolled the WS = 1 form's tap loop by its trip-count guess and hoisted every tap's fragment addresses: 169 VGPRs)
         for (int tap = 0; tap < taps; ++tap) {
             const bool more = (tap + 1) < taps;
@@ -454,6 +460,9 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                 __syncthreads();
             }
         }
+#if ACE355_CONV_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (probe) p_taps += clock64() - p_mark;
     }
 #else

@@ -31,6 +31,14 @@
 #define ACE355_EPI_VEC 1     // 0 (A/B build): the folded-norm consumers of the 8-wave kernels load their row sums / bias / head-norm weights from global
                              // memory at the top of the epilogue, as until round 5, instead of from the LDS vector area a DMA filled under the K loop
 #endif
+#ifndef ACE355_MFMA_ORDER
+#define ACE355_MFMA_ORDER 2  // order of the 16x16x32 MFMAs of a half K step (same accumulators, same sums; A/B builds: tools/r05_mfma_order.sh).  2 (default,
+                             // round 5): row-major over the wave's (2 MT) x (2 NTW) grid of 16x16 blocks walked as a SERPENTINE - exactly one operand register
+                             // set changes from one instruction to the next (the A-row fragment stays for 2 NTW instructions, the W fragment across the
+                             // turn).  0 = the plain row-major order (both operands change at every row turn); 1 / 3 = column-major, plain / serpentine
+                             // (the W fragment held).  The K loops sit at the power cap, where what pays is energy: same-box ABAB per 8-song pass, order 0 ->
+                             // 2: -0.45 % (6 of 6 pairs on two boxes), 0 -> 1: +0.3 %, 0 -> 3: +0.3 % (profiles/r05_mfma_order_ab.txt)
+#endif
 #ifndef ACE355_EPI_NT
 #define ACE355_EPI_NT 0      // cache policy of the residual (mode 2) epilogue's single-use traffic, bit mask: 1 = old-H loads non-temporal, 2 = new-H
                              // stores non-temporal, 4 = the folded norm's bf16(h * g) stores non-temporal (A/B builds: tools/r05_epi_nt.sh)
@@ -1074,7 +1082,15 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         // 16x16x32 form: (i, hr, j, hc) - quad (hr, hc) of block (i, j), row half from fa[hr][i], column half from fw[hc][j]
         auto mfma_m = [&](int m, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
             if constexpr (L16) {
-                const int i = m / (4 * NTW), hr = (m / (2 * NTW)) & 1, j = (m >> 1) % NTW, hc = m & 1;
+                int i = m / (4 * NTW), hr = (m / (2 * NTW)) & 1, j = (m >> 1) % NTW, hc = m & 1;
+                if constexpr (ACE355_MFMA_ORDER == 1) { j = m / (4 * MT), hc = (m / (2 * MT)) & 1, i = (m >> 1) % MT, hr = m & 1; }
+                if constexpr (ACE355_MFMA_ORDER == 2) {   // odd (i, hr) rows walk their 2 NTW column halves backwards
+                    if ((m / (2 * NTW)) & 1) { const int c = 2 * NTW - 1 - (m % (2 * NTW)); j = c >> 1, hc = c & 1; }
+                }
+                if constexpr (ACE355_MFMA_ORDER == 3) {   // order 1 as a serpentine: odd (j, hc) columns walk their 2 MT row halves backwards
+                    const int col = m / (2 * MT), r0 = m % (2 * MT), r = (col & 1) ? 2 * MT - 1 - r0 : r0;
+                    j = col >> 1, hc = col & 1, i = r >> 1, hr = r & 1;
+                }
                 acc[i][j].q[hr * 2 + hc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[hc][j], fa[hr][i], acc[i][j].q[hr * 2 + hc], 0, 0, 0);
             } else {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;

@@ -39,6 +39,9 @@
                              // (the W fragment held).  The K loops sit at the power cap, where what pays is energy: same-box ABAB per 8-song pass, order 0 ->
                              // 2: -0.45 % (6 of 6 pairs on two boxes), 0 -> 1: +0.3 %, 0 -> 3: +0.3 % (profiles/r05_mfma_order_ab.txt)
 #endif
+#ifndef ACE355_WAVE_PAIR
+#define ACE355_WAVE_PAIR 0   // 1 (A/B build): the two waves of a SIMD in the 8-wave tiles share their A rows instead of their W columns (gemm_sp_kernel)
+#endif
 #ifndef ACE355_EPI_NT
 #define ACE355_EPI_NT 0      // cache policy of the residual (mode 2) epilogue's single-use traffic, bit mask: 1 = old-H loads non-temporal, 2 = new-H
                              // stores non-temporal, 4 = the folded norm's bf16(h * g) stores non-temporal (A/B builds: tools/r05_epi_nt.sh)
@@ -916,7 +919,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     const int m0 = tm * BMv, n0 = tn * BNv;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WNW, wn = wave % WNW;
+    // Which two waves share a SIMD (waves are dealt round-robin: wave w runs on SIMD w & 3, so the 8-wave tiles put waves w and w + 4 together):
+    // ACE355_WAVE_PAIR 0 = the pair shares its W columns (wn) and differs in its A rows; 1 (A/B build) = the pair shares its A rows.  `vw` is the
+    // wave's index in (wm, wn) order, which is what the epilogue's staging slices and row-sum exchange are laid out by.
+    const int wm = (ACE355_WAVE_PAIR && NW == 8) ? (wave & 1) : wave / WNW, wn = (ACE355_WAVE_PAIR && NW == 8) ? (wave >> 1) : wave % WNW;
+    const int vw = wm * WNW + wn;
 
     const int lrow = lane >> 3, pslot = lane & 7;
     const int sslot = pslot ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);
@@ -1173,7 +1180,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             // first half: k 0..63 of the step = the P fragments (both slots of each operand), k-blocks 0 | 1 -> op_sel 0
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
-                const int i = m / NTW, j = m % NTW;
+                const int i = m / NTW, j = (ACE355_MFMA_ORDER == 2 && ((m / NTW) & 1)) ? NTW - 1 - m % NTW : m % NTW;   // (serpentine: see ACE355_MFMA_ORDER)
                 if constexpr (!L16) acc[i][j].v = mfma_mx<0>(pw[0][j], pw[1][j], pa[0][i], pa[1][i], acc[i][j].v, scw[j], sca[i]);
 #pragma unroll
                 for (int f = 2 * m; f < 2 * m + 2; ++f)
@@ -1200,7 +1207,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             constexpr int PER = (NF + RS - 1) / RS;
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
-                const int i = m / NTW, j = m % NTW;
+                const int i = m / NTW, j = (ACE355_MFMA_ORDER == 2 && ((m / NTW) & 1)) ? NTW - 1 - m % NTW : m % NTW;
                 if constexpr (!L16) acc[i][j].v = mfma_mx<2>(qw[0][j], qw[1][j], qa[0][i], qa[1][i], acc[i][j].v, scw[j], sca[i]);
                 if (dma) {
 #pragma unroll
@@ -1320,7 +1327,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 asm volatile("" ::: "memory");
             }
         }
-        gemm_epilogue<MODE, MT, NTW, !FP8, L16>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, wave, lane, BMv, BNv, (VEC && vec_on) ? smem + VOFF : nullptr);
+        gemm_epilogue<MODE, MT, NTW, !FP8, L16>(acc, smem, Cv, ldc, M, N, ep, m0, n0, wm, wn, vw, lane, BMv, BNv, (VEC && vec_on) ? smem + VOFF : nullptr);
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's H rows are in L2

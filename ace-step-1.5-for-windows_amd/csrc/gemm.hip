@@ -39,6 +39,12 @@
                              // (the W fragment held).  The K loops sit at the power cap, where what pays is energy: same-box ABAB per 8-song pass, order 0 ->
                              // 2: -0.45 % (6 of 6 pairs on two boxes), 0 -> 1: +0.3 %, 0 -> 3: +0.3 % (profiles/r05_mfma_order_ab.txt)
 #endif
+#ifndef ACE355_MFMA_PAIR
+#define ACE355_MFMA_PAIR 1   // 1: the K loop of the 8-wave 192x256 bf16 tile issues the two MFMAs a 16x16 block gets per K step (its K halves P and Q) BACK TO BACK on
+                             // the block's accumulator (gemm_sp_kernel: kstep_pair) instead of all P MFMAs, then all Q MFMAs.  Same instructions, same sums in the
+                             // same order per accumulator - the second MFMA takes its accumulator from the first without a trip through the register file, which
+                             // under the power cap is worth + 4.7 % on a pure-MFMA loop (tools/probe/mfma_acc_probe.hip).  0: the half-by-half loop (A/B builds)
+#endif
 #ifndef ACE355_WAVE_PAIR
 #define ACE355_WAVE_PAIR 0   // 1 (A/B build): the two waves of a SIMD in the 8-wave tiles share their A rows instead of their W columns (gemm_sp_kernel)
 #endif
@@ -147,6 +153,12 @@ __device__ __forceinline__ void stu2_xg(bf16_t* p, const uint2& v) {   // bf16(h
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// c += a0 b0; c += a1 b1 as two v_mfma_f32_16x16x32_bf16 BACK TO BACK with D == C on both (gemm_sp_kernel: kstep_pair).  asm, because hipcc gives the first
+// of two chained builtins a scratch destination whenever that suits its register allocation, and only the in-place form is chained by the matrix pipe.
+__device__ __forceinline__ void mfma16_pair(f32x4v& c, const bf16x8& a0, const bf16x8& b0, const bf16x8& a1, const bf16x8& b1) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %3, %4, %0" : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
 }
 
 template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true, bool L16 = false>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
@@ -1071,6 +1083,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     }
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, pa, pw);
+    constexpr bool PAIRK = (ACE355_MFMA_PAIR != 0) && L16 && NTW == 2 && NW == 8 && MT == 3 && (AJ + WJ) == 7;   // (kstep_pair below)
+    if constexpr (PAIRK) load_frags(smem, 2, qa, qw);   // the pair loop starts a K step with both K halves of its A rows and of column block 0 in registers
     load_scales(smem);
 
     // ---- ILV: explicit instruction interleave.  An LDS-DMA piece costs 60-185 cycles to ISSUE (TA queue); seven of them
@@ -1173,6 +1187,81 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // ---- kstep_pair (PAIRK: the 8-wave bf16 tiles with two column blocks per wave).  A 16x16 block's two MFMAs of a K step - K half P (k 0..31) and K half
+        // Q (k 32..63) - are issued back to back on its accumulator, P first (the summation order per accumulator is the half-by-half loop's: same bits).
+        // What makes that possible in the SAME 20 fragment registers, with the same single barrier and the same DMA timing per step:
+        //   phase A = the blocks of column block 0 (rows in order, (hc 0: P, Q), (hc 1: P, Q)): 8 MT MFMAs on pa / qa (A rows, both K halves) and pw / qw[.][0];
+        //             behind its first MFMAs the four fragments of column block 1 of THIS step are read (their registers died with the previous step's phase B);
+        //   barrier   (tile kt + 1 landed; every wave has read everything it needs of stage kt: A rows and column block 0 during the previous step's phase B,
+        //             column block 1 just now - so the stage is free for tile kt + NS, exactly as in the half-by-half loop);
+        //   phase B = the blocks of column block 1: row r's A-row fragments die with its MFMAs (P after slot 4 r + 2, Q after 4 r + 3) and are re-read for step
+        //             kt + 1 right there; the other two slots of a row carry the DMA pieces of tile kt + NS (spread over the phase) and the four fragments of
+        //             column block 0 of step kt + 1.
+        auto frag_at = [&](const char* stg, int kk0, int h, int e) -> const uint4* {   // fragment half h of A block e (e < MT) or W block e - MT, K half kk0 / 2
+            const int slot = frag_slot(kk0, h);
+            return reinterpret_cast<const uint4*>(e < MT ? stg + a_off[e] + h * HROW + ((slot ^ swz) << 4) : stg + w_off[e - MT] + h * HROW + ((slot ^ swzw) << 4));
+        };
+        auto kstep_pair = [&](int kt, auto more_c, auto dma_c) {
+            constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
+            if constexpr (PAIRK) {
+            constexpr int NPR = 4 * MT;         // pairs per phase: (2 MT row halves) x (2 column halves of the phase's column block)
+            constexpr int ND = AJ + WJ;         // DMA pieces of this wave per tile
+            constexpr int NE = 2 * MT;          // phase-B pair slots in mid-row (the row-end ones carry the A-row re-reads)
+            const char* st = smem + (kt % NS) * STAGE;
+            // One asm statement per pair: hipcc would otherwise give the first MFMA a scratch destination (D != C) whenever that suits its allocation,
+            // and only D == C on both instructions is the form the matrix pipe chains without the register file.  The compiler does not see an MFMA here:
+            // the wait states a VALU read of the accumulators needs are inserted by hand behind the K loop.
+            auto pair_mfma = [&](int pi, int j) {
+                const int r = pi >> 1, i = r >> 1, hr = r & 1, hc = pi & 1;
+                mfma16_pair(acc[i][j].q[hr * 2 + hc], pw[hc][j], pa[hr][i], qw[hc][j], qa[hr][i]);
+            };
+#pragma unroll
+            for (int pi = 0; pi < NPR; ++pi) {
+                pair_mfma(pi, 0);
+                if (pi < 2) pw[pi][1] = as_bf16x8(*frag_at(st, 0, pi, MT + 1));
+                else if (pi < 4) qw[pi - 2][1] = as_bf16x8(*frag_at(st, 2, pi - 2, MT + 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (more) {
+                if (dma) wait_vmcnt<(NS - 2) * (AJ + WJ)>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
+            const char* stn = smem + ((kt + 1) % NS) * STAGE;
+            const int kt2 = kmap((ACE355_ABL_HOTK ? (kt & 1) : kt) + NS);
+            const bf16_t* a_k2 = A + kt2 * BK;
+            const bf16_t* w_k2 = W + kt2 * BK;
+            auto piece = [&](int pc) {
+                if (dma && !ACE355_ABL_NODMA && pc < ND) {
+                    if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
+                    else glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
+                }
+            };
+            auto wread = [&](int f) {   // fragment f of column block 0 of step kt + 1
+                if (more && f >= 0 && f < 4) {
+                    if (f < 2) pw[f][0] = as_bf16x8(*frag_at(stn, 0, f, MT));
+                    else qw[f - 2][0] = as_bf16x8(*frag_at(stn, 2, f - 2, MT));
+                }
+            };
+            // Phase-B schedule (MT = 3, 7 pieces): at most ONE DMA piece per pair slot (a piece takes 60-185 cycles to issue: two in a row hold the wave
+            // longer than its partner on the SIMD can cover), the re-read of row r's fragments anywhere from its last pair (slot 2 r + 1) on
+            constexpr int PC[12] = {0, 1, -1, 2, -1, 3, 4, -1, 5, -1, 6, -1};          // piece of the slot
+            constexpr int WR[12] = {0, -1, 1, -1, 2, -1, -1, 3, -1, -1, -1, -1};       // column-block-0 fragment of the slot
+            constexpr int AP[12] = {-1, 0, -1, 1, -1, 2, -1, 3, -1, 4, -1, 5};         // row whose P-half A fragment is re-read in the slot
+            constexpr int AQ[12] = {-1, -1, 0, -1, 1, -1, 2, -1, 3, 4, -1, 5};         // ... Q half
+            static_assert(NPR == 12 && ND == 7, "kstep_pair: the phase-B schedule is written for the 192x256 tile");
+#pragma unroll
+            for (int pi = 0; pi < NPR; ++pi) {
+                pair_mfma(pi, 1);
+                if (PC[pi] >= 0) piece(PC[pi]);
+                if (WR[pi] >= 0) wread(WR[pi]);
+                if (more && AP[pi] >= 0) pa[AP[pi] & 1][AP[pi] >> 1] = as_bf16x8(*frag_at(stn, 0, AP[pi] & 1, AP[pi] >> 1));
+                if (more && AQ[pi] >= 0) qa[AQ[pi] & 1][AQ[pi] >> 1] = as_bf16x8(*frag_at(stn, 2, AQ[pi] & 1, AQ[pi] >> 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            }
+        };
         auto kstep_mx = [&](int kt, auto more_c, auto dma_c) {
             constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
             constexpr int NX = MT * NTW;  // scaled MFMAs per half K-step (64 cycles each: the same pipe time as the 2 NX bf16 ones)
@@ -1250,9 +1339,17 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 for (; kt + 1 < nk; ++kt) kstep_mx(kt, T{}, F{});
                 kstep_mx(kt, F{}, F{});
             } else {
+            if constexpr (PAIRK) {
+                for (; kt + NS < nk; ++kt) kstep_pair(kt, T{}, T{});
+                for (; kt + 1 < nk; ++kt) kstep_pair(kt, T{}, F{});
+                kstep_pair(kt, F{}, F{});
+                // (the accumulators were last written by asm-issued MFMAs hipcc does not know as such: the wait states a VALU read of a 8-pass XDL result needs)
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+            } else {
             for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{});     // steady state: branch-free
             for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{});       // the last NS-1 K steps but one: nothing left to prefetch
             kstep(kt, F{}, F{});                                 // last K step
+            }
             }
         }
         if (probe && (int)blockIdx.y == ep.kparts - 1) {

@@ -40,7 +40,7 @@
                              // 2: -0.45 % (6 of 6 pairs on two boxes), 0 -> 1: +0.3 %, 0 -> 3: +0.3 % (profiles/r05_mfma_order_ab.txt)
 #endif
 #ifndef ACE355_MFMA_PAIR
-#define ACE355_MFMA_PAIR 1   // 1: the K loop of the 8-wave 192x256 bf16 tile issues the two MFMAs a 16x16 block gets per K step (its K halves P and Q) BACK TO BACK on
+#define ACE355_MFMA_PAIR 1   // 1 / 2: the K loop of the 8-wave 192x256 bf16 tile issues the two MFMAs a 16x16 block gets per K step (its K halves P and Q) BACK TO BACK on
                              // the block's accumulator (gemm_sp_kernel: kstep_pair) instead of all P MFMAs, then all Q MFMAs.  Same instructions, same sums in the
                              // same order per accumulator - the second MFMA takes its accumulator from the first without a trip through the register file, which
                              // under the power cap is worth + 4.7 % on a pure-MFMA loop (tools/probe/mfma_acc_probe.hip).  0: the half-by-half loop (A/B builds)
@@ -1220,6 +1220,13 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 pair_mfma(pi, 0);
                 if (pi < 2) pw[pi][1] = as_bf16x8(*frag_at(st, 0, pi, MT + 1));
                 else if (pi < 4) qw[pi - 2][1] = as_bf16x8(*frag_at(st, 2, pi - 2, MT + 1));
+                if constexpr (ACE355_MFMA_PAIR == 1) {   // the rows of the second half of the grid (3 .. 5) are read HERE, in the step that uses them (their
+                    if (pi < 6) {                         // registers died with the previous step's last pairs): phase B carries 17 items instead of 23
+                        const int r = 3 + (pi >> 1);
+                        if (pi & 1) qa[r & 1][r >> 1] = as_bf16x8(*frag_at(st, 2, r & 1, r >> 1));
+                        else pa[r & 1][r >> 1] = as_bf16x8(*frag_at(st, 0, r & 1, r >> 1));
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1246,10 +1253,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             };
             // Phase-B schedule (MT = 3, 7 pieces): at most ONE DMA piece per pair slot (a piece takes 60-185 cycles to issue: two in a row hold the wave
             // longer than its partner on the SIMD can cover), the re-read of row r's fragments anywhere from its last pair (slot 2 r + 1) on
+            constexpr bool SPLIT = (ACE355_MFMA_PAIR == 1);   // (2: all six rows re-read in phase B, the first form measured)
             constexpr int PC[12] = {0, 1, -1, 2, -1, 3, 4, -1, 5, -1, 6, -1};          // piece of the slot
             constexpr int WR[12] = {0, -1, 1, -1, 2, -1, -1, 3, -1, -1, -1, -1};       // column-block-0 fragment of the slot
-            constexpr int AP[12] = {-1, 0, -1, 1, -1, 2, -1, 3, -1, 4, -1, 5};         // row whose P-half A fragment is re-read in the slot
-            constexpr int AQ[12] = {-1, -1, 0, -1, 1, -1, 2, -1, 3, 4, -1, 5};         // ... Q half
+            constexpr int AP[12] = {-1, 0, -1, 1, -1, 2, -1, SPLIT ? -1 : 3, -1, SPLIT ? -1 : 4, -1, SPLIT ? -1 : 5};   // row whose P-half A fragment is re-read in the slot
+            constexpr int AQ[12] = {-1, -1, 0, -1, 1, -1, 2, -1, SPLIT ? -1 : 3, SPLIT ? -1 : 4, -1, SPLIT ? -1 : 5};   // ... Q half
             static_assert(NPR == 12 && ND == 7, "kstep_pair: the phase-B schedule is written for the 192x256 tile");
 #pragma unroll
             for (int pi = 0; pi < NPR; ++pi) {

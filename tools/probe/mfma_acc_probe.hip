@@ -106,22 +106,25 @@ __global__ __launch_bounds__(512) void probe32(float* sink, int iters) {
     if (t == 12345.678f) sink[0] = t;
 }
 
+static int g_threads = 512;
 template <int MODE>
 static double run(float* sink, int cus, int iters) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
-    if constexpr (MODE >= 4) hipLaunchKernelGGL(probe32<MODE>, dim3(cus), dim3(512), 0, 0, sink, iters);
-    else hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(512), 0, 0, sink, iters);
+    if constexpr (MODE >= 4) hipLaunchKernelGGL(probe32<MODE>, dim3(cus), dim3(g_threads), 0, 0, sink, iters);
+    else hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(g_threads), 0, 0, sink, iters);
     (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return (double)cus * 8.0 * iters * 48.0 * 16384.0 / (ms * 1e-3) / 1e12;
+    return (double)cus * (g_threads / 64.0) * iters * 48.0 * 16384.0 / (ms * 1e-3) / 1e12;
 }
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 60000;   // ~0.25 s per launch
     const int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    g_threads = argc > 3 ? atoi(argv[3]) : 512;   // 256: one wave per SIMD (nobody to cover a dependent pair)
+    printf("%d threads per workgroup (%d waves per SIMD)\n", g_threads, g_threads / 256);
     float* sink; (void)hipMalloc(&sink, 64);
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;

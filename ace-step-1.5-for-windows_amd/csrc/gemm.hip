@@ -45,6 +45,9 @@
                              // same order per accumulator - the second MFMA takes its accumulator from the first without a trip through the register file, which
                              // under the power cap is worth + 4.7 % on a pure-MFMA loop (tools/probe/mfma_acc_probe.hip).  0: the half-by-half loop (A/B builds)
 #endif
+#ifndef ACE355_PAIR_PCS
+#define ACE355_PAIR_PCS 0    // placement of the seven DMA pieces over the twelve pair slots of kstep_pair's phase B (A/B builds)
+#endif
 #ifndef ACE355_WAVE_PAIR
 #define ACE355_WAVE_PAIR 0   // 1 (A/B build): the two waves of a SIMD in the 8-wave tiles share their A rows instead of their W columns (gemm_sp_kernel)
 #endif
@@ -1254,8 +1257,20 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             // Phase-B schedule (MT = 3, 7 pieces): at most ONE DMA piece per pair slot (a piece takes 60-185 cycles to issue: two in a row hold the wave
             // longer than its partner on the SIMD can cover), the re-read of row r's fragments anywhere from its last pair (slot 2 r + 1) on
             constexpr bool SPLIT = (ACE355_MFMA_PAIR == 1);   // (2: all six rows re-read in phase B, the first form measured)
+#if ACE355_PAIR_PCS == 1
+            constexpr int PC[12] = {0, 1, 2, 3, 4, 5, 6, -1, -1, -1, -1, -1};          // (A/B: pieces up front)
+#elif ACE355_PAIR_PCS == 2
+            constexpr int PC[12] = {0, -1, 1, -1, 2, -1, 3, -1, 4, 5, 6, -1};          // (A/B: every other slot)
+#elif ACE355_PAIR_PCS == 3
+            constexpr int PC[12] = {0, -1, 1, -1, 2, -1, 3, -1, 4, 5, 6, -1};          // (A/B: every other slot, the reads re-balanced around them)
+#else
             constexpr int PC[12] = {0, 1, -1, 2, -1, 3, 4, -1, 5, -1, 6, -1};          // piece of the slot
+#endif
+#if ACE355_PAIR_PCS == 3
+            constexpr int WR[12] = {0, 1, -1, 2, -1, 3, -1, -1, -1, -1, -1, -1};
+#else
             constexpr int WR[12] = {0, -1, 1, -1, 2, -1, -1, 3, -1, -1, -1, -1};       // column-block-0 fragment of the slot
+#endif
             constexpr int AP[12] = {-1, 0, -1, 1, -1, 2, -1, SPLIT ? -1 : 3, -1, SPLIT ? -1 : 4, -1, SPLIT ? -1 : 5};   // row whose P-half A fragment is re-read in the slot
             constexpr int AQ[12] = {-1, -1, 0, -1, 1, -1, 2, -1, SPLIT ? -1 : 3, SPLIT ? -1 : 4, -1, SPLIT ? -1 : 5};   // ... Q half
             static_assert(NPR == 12 && ND == 7, "kstep_pair: the phase-B schedule is written for the 192x256 tile");

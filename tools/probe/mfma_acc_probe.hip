@@ -49,7 +49,7 @@ __global__ __launch_bounds__(512) void probe(float* sink, int iters) {
 #pragma unroll
                 for (int c = 3; c >= 0; --c) { acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][c], fa[1][r], acc[r][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
             }
-        } else {
+        } else if constexpr (MODE == 3) {
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
@@ -59,6 +59,22 @@ __global__ __launch_bounds__(512) void probe(float* sink, int iters) {
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][c], fa[1][r], acc[r][c], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+        } else {   // MODE 6: chains of four (a K step of 128 would give a block four MFMAs): half the blocks per loop iteration, same instruction count
+            if (it & 1) {
+#pragma unroll
+                for (int r = 3; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[k & 1][c], fa[k & 1][r], acc[r][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[k & 1][c], fa[k & 1][r], acc[r][c], 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         // (keeps the loop from being re-ordered or hoisted across iterations; costs nothing)
         asm volatile("" ::: "memory");
@@ -111,7 +127,7 @@ template <int MODE>
 static double run(float* sink, int cus, int iters) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
-    if constexpr (MODE >= 4) hipLaunchKernelGGL(probe32<MODE>, dim3(cus), dim3(g_threads), 0, 0, sink, iters);
+    if constexpr (MODE == 4 || MODE == 5) hipLaunchKernelGGL(probe32<MODE>, dim3(cus), dim3(g_threads), 0, 0, sink, iters);
     else hipLaunchKernelGGL(probe<MODE>, dim3(cus), dim3(g_threads), 0, 0, sink, iters);
     (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
@@ -129,15 +145,15 @@ int main(int argc, char** argv) {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     run<0>(sink, cus, iters);   // warm-up: the board reaches its power-capped state
-    double sum[6] = {0, 0, 0, 0, 0, 0};
+    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < rounds; ++r) {
-        const double t[6] = {run<0>(sink, cus, iters), run<1>(sink, cus, iters), run<2>(sink, cus, iters), run<3>(sink, cus, iters), run<4>(sink, cus, iters), run<5>(sink, cus, iters)};
-        printf("round %d: 16x16x32 row-major %7.1f  serpentine %7.1f  row: P then Q reversed %7.1f  block: P, Q back to back %7.1f | 32x32x16 sub-step outermost %7.1f  sub-steps back to back %7.1f TFLOP/s\n",
-               r, t[0], t[1], t[2], t[3], t[4], t[5]);
-        for (int m = 0; m < 6; ++m) sum[m] += t[m];
+        const double t[7] = {run<0>(sink, cus, iters), run<1>(sink, cus, iters), run<2>(sink, cus, iters), run<3>(sink, cus, iters), run<4>(sink, cus, iters), run<5>(sink, cus, iters), run<6>(sink, cus, iters)};
+        printf("round %d: 16x16x32 row-major %7.1f  serpentine %7.1f  row: P then Q reversed %7.1f  block: P, Q back to back %7.1f | 32x32x16 sub-step outermost %7.1f  sub-steps back to back %7.1f | 16x16x32 chains of four %7.1f TFLOP/s\n",
+               r, t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
+        for (int m = 0; m < 7; ++m) sum[m] += t[m];
     }
     printf("mean   :");
-    for (int m = 0; m < 6; ++m) printf("  mode %d %7.1f (%+.2f %%)", m, sum[m] / rounds, 100.0 * (sum[m] / sum[0] - 1));
+    for (int m = 0; m < 7; ++m) printf("  mode %d %7.1f (%+.2f %%)", m, sum[m] / rounds, 100.0 * (sum[m] / sum[0] - 1));
     printf("\n");
     return 0;
 }

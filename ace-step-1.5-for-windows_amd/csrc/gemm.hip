@@ -45,6 +45,9 @@
                              // same order per accumulator - the second MFMA takes its accumulator from the first without a trip through the register file, which
                              // under the power cap is worth + 4.7 % on a pure-MFMA loop (tools/probe/mfma_acc_probe.hip).  0: the half-by-half loop (A/B builds)
 #endif
+#ifndef ACE355_MFMA_PAIR1
+#define ACE355_MFMA_PAIR1 1  // the pair K loop on the 8-wave 192x128 tile too (kstep_pair1: phases by column HALF of the wave's one column block); 0: A/B builds
+#endif
 #ifndef ACE355_PAIR_PCS
 #define ACE355_PAIR_PCS 0    // placement of the seven DMA pieces over the twelve pair slots of kstep_pair's phase B (A/B builds)
 #endif
@@ -1087,7 +1090,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, pa, pw);
     constexpr bool PAIRK = (ACE355_MFMA_PAIR != 0) && L16 && NTW == 2 && NW == 8 && MT == 3 && (AJ + WJ) == 7;   // (kstep_pair below)
-    if constexpr (PAIRK) load_frags(smem, 2, qa, qw);   // the pair loop starts a K step with both K halves of its A rows and of column block 0 in registers
+    constexpr bool PAIRK1 = (ACE355_MFMA_PAIR != 0) && (ACE355_MFMA_PAIR1 != 0) && L16 && NTW == 1 && NW == 8 && MT == 3 && (AJ + WJ) == 5;   // (kstep_pair1: the 192x128 tile)
+    if constexpr (PAIRK || PAIRK1) load_frags(smem, 2, qa, qw);   // the pair loop starts a K step with both K halves of its A rows and of column block 0 in registers
     load_scales(smem);
 
     // ---- ILV: explicit instruction interleave.  An LDS-DMA piece costs 60-185 cycles to ISSUE (TA queue); seven of them
@@ -1285,6 +1289,57 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             }
             }
         };
+        // kstep_pair1 (PAIRK1: the 8-wave 192x128 tile, one 32-column block per wave): the same turn of the double buffer with the two 16-column HALVES of
+        // the block as the phases - phase A = the six pairs of column half 0, phase B = those of half 1.  Six pairs per phase are too few to read rows 3-5
+        // in the phase that uses them first: rows 4 and 5 are (four and two pairs ahead), row 3 is re-read in phase B with rows 0-2.
+        auto kstep_pair1 = [&](int kt, auto more_c, auto dma_c) {
+            constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
+            if constexpr (PAIRK1) {
+            constexpr int ND = AJ + WJ;
+            const char* st = smem + (kt % NS) * STAGE;
+            auto pair1 = [&](int r, int hc) {
+                const int i = r >> 1, hr = r & 1;
+                mfma16_pair(acc[i][0].q[hr * 2 + hc], pw[hc][0], pa[hr][i], qw[hc][0], qa[hr][i]);
+            };
+            auto aread = [&](const char* stg, int r, int q) {   // K half q of row r's A fragment
+                if (q) qa[r & 1][r >> 1] = as_bf16x8(*frag_at(stg, 2, r & 1, r >> 1));
+                else pa[r & 1][r >> 1] = as_bf16x8(*frag_at(stg, 0, r & 1, r >> 1));
+            };
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                pair1(r, 0);
+                if (r == 0) { pw[1][0] = as_bf16x8(*frag_at(st, 0, 1, MT)); aread(st, 4, 0); }
+                if (r == 1) { qw[1][0] = as_bf16x8(*frag_at(st, 2, 1, MT)); aread(st, 4, 1); }
+                if (r == 2) aread(st, 5, 0);
+                if (r == 3) aread(st, 5, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (more) {
+                if (dma) wait_vmcnt<(NS - 2) * (AJ + WJ)>(); else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
+            const char* stn = smem + ((kt + 1) % NS) * STAGE;
+            const int kt2 = kmap((ACE355_ABL_HOTK ? (kt & 1) : kt) + NS);
+            const bf16_t* a_k2 = A + kt2 * BK;
+            const bf16_t* w_k2 = W + kt2 * BK;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                pair1(r, 1);
+                if (dma && !ACE355_ABL_NODMA && r < ND) {
+                    if (r < AJ) glds16_sv(a_voff[r], a_k2, sb + r * (NW * 1024));
+                    else glds16_sv(w_voff[r - AJ], w_k2, sb + A_BYTES + (r - AJ) * (NW * 1024));
+                }
+                if (more) {
+                    if (r < 4) { aread(stn, r, 0); aread(stn, r, 1); }
+                    if (r == 4) pw[0][0] = as_bf16x8(*frag_at(stn, 0, 0, MT));
+                    if (r == 5) qw[0][0] = as_bf16x8(*frag_at(stn, 2, 0, MT));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            }
+        };
         auto kstep_mx = [&](int kt, auto more_c, auto dma_c) {
             constexpr bool more = decltype(more_c)::value, dma = decltype(dma_c)::value;
             constexpr int NX = MT * NTW;  // scaled MFMAs per half K-step (64 cycles each: the same pipe time as the 2 NX bf16 ones)
@@ -1362,7 +1417,12 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 for (; kt + 1 < nk; ++kt) kstep_mx(kt, T{}, F{});
                 kstep_mx(kt, F{}, F{});
             } else {
-            if constexpr (PAIRK) {
+            if constexpr (PAIRK1) {
+                for (; kt + NS < nk; ++kt) kstep_pair1(kt, T{}, T{});
+                for (; kt + 1 < nk; ++kt) kstep_pair1(kt, T{}, F{});
+                kstep_pair1(kt, F{}, F{});
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");   // (see below)
+            } else if constexpr (PAIRK) {
                 for (; kt + NS < nk; ++kt) kstep_pair(kt, T{}, T{});
                 for (; kt + 1 < nk; ++kt) kstep_pair(kt, T{}, F{});
                 kstep_pair(kt, F{}, F{});

@@ -382,3 +382,40 @@ def test_slab_split_k_switch(gpu_device, tmp_path):
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ACE355_GEMM_SLAB="1", ACE355_GEMM_CLK="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "slab ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_gemm_tile_forms_give_the_same_bits(gpu_device, tmp_path):
+    """the order of the MFMAs inside a K step is a matter of energy, not of arithmetic - every accumulator still takes K half P, then
+    K half Q, step after step.  So the three K loops of gemm.hip must agree BIT FOR BIT on one problem once the launch-shape-dependent K rotation is off:
+    the 4-wave tiles (half-by-half loop: ACE355_GEMM_BIG=0), the 8-wave 192x256 tile (kstep_pair: =2) and the 8-wave 192x128 tile (kstep_pair1: =3).
+    Fresh processes: the switches are read once."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import ace355\n"
+        "from ace355 import native\n"
+        "lib = native.lib(); P = native.ptr; dev = torch.device('cuda:0')\n"
+        "native.gemm_set_k_rotation(0)\n"
+        "g = torch.Generator().manual_seed(11)\n"
+        "outs = []\n"
+        "for M, N, K in ((6000, 2048, 2048), (1536, 2048, 6144)):\n"
+        "    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)\n"
+        "    o = torch.empty(M, N, device=dev)\n"
+        "    native.check(lib.ace355_gemm_bf16(P(A), P(W), P(o), M, N, K, 0, None, None)); torch.cuda.synchronize()\n"
+        "    ref = A.float() @ W.float().t()\n"
+        "    assert float((o - ref).norm() / ref.norm()) < 2e-5\n"
+        "    outs.append(o.cpu())\n"
+        "torch.save(outs, sys.argv[1])\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for flag in ("0", "2", "3"):
+        path = str(tmp_path / f"big{flag}.pt")
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, ACE355_GEMM_BIG=flag, ACE355_GEMM_CLK="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[flag] = torch.load(path)
+    for flag in ("2", "3"):
+        for a, b in zip(res["0"], res[flag]):
+            assert torch.equal(a, b), f"ACE355_GEMM_BIG={flag} differs from the 4-wave tiles: max abs {float((a - b).abs().max()):.3e}"

@@ -59,6 +59,17 @@ __global__ __launch_bounds__(512) void probe(float* sink, int iters) {
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][c], fa[1][r], acc[r][c], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+        } else if constexpr (MODE == 7) {   // pairs, the K halves in alternating order (P Q | Q P | ...): the A-row operand changes every second instruction
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int h0 = c & 1;
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[h0][c], fa[h0][r], acc[r][c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1 - h0][c], fa[1 - h0][r], acc[r][c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         } else {   // MODE 6: chains of four (a K step of 128 would give a block four MFMAs): half the blocks per loop iteration, same instruction count
             if (it & 1) {
 #pragma unroll
@@ -145,15 +156,15 @@ int main(int argc, char** argv) {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     run<0>(sink, cus, iters);   // warm-up: the board reaches its power-capped state
-    double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < rounds; ++r) {
-        const double t[7] = {run<0>(sink, cus, iters), run<1>(sink, cus, iters), run<2>(sink, cus, iters), run<3>(sink, cus, iters), run<4>(sink, cus, iters), run<5>(sink, cus, iters), run<6>(sink, cus, iters)};
-        printf("round %d: 16x16x32 row-major %7.1f  serpentine %7.1f  row: P then Q reversed %7.1f  block: P, Q back to back %7.1f | 32x32x16 sub-step outermost %7.1f  sub-steps back to back %7.1f | 16x16x32 chains of four %7.1f TFLOP/s\n",
-               r, t[0], t[1], t[2], t[3], t[4], t[5], t[6]);
-        for (int m = 0; m < 7; ++m) sum[m] += t[m];
+        const double t[8] = {run<0>(sink, cus, iters), run<1>(sink, cus, iters), run<2>(sink, cus, iters), run<3>(sink, cus, iters), run<4>(sink, cus, iters), run<5>(sink, cus, iters), run<6>(sink, cus, iters), run<7>(sink, cus, iters)};
+        printf("round %d: 16x16x32 row-major %7.1f  serpentine %7.1f  row: P then Q reversed %7.1f  block: P, Q back to back %7.1f | 32x32x16 sub-step outermost %7.1f  sub-steps back to back %7.1f | 16x16x32 chains of four %7.1f  pairs, K halves alternating %7.1f TFLOP/s\n",
+               r, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+        for (int m = 0; m < 8; ++m) sum[m] += t[m];
     }
     printf("mean   :");
-    for (int m = 0; m < 7; ++m) printf("  mode %d %7.1f (%+.2f %%)", m, sum[m] / rounds, 100.0 * (sum[m] / sum[0] - 1));
+    for (int m = 0; m < 8; ++m) printf("  mode %d %7.1f (%+.2f %%)", m, sum[m] / rounds, 100.0 * (sum[m] / sum[0] - 1));
     printf("\n");
     return 0;
 }

@@ -19,6 +19,7 @@ to a CPU implementation: a missing library or a failed HIP call raises ``Runtime
 """
 from __future__ import annotations
 
+import contextlib
 import inspect
 import logging
 import time
@@ -269,6 +270,9 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         self.offload_to_cpu = False
         self.current_offload_cost = 0.0
         self.model_variant = "sft"  # which checkpoint family's generate_audio semantics apply: "base" | "sft" | "turbo"
+        # data-parallel requests run in the library's launch-shape-independent mode (`shape_independent` below): a song's bits then do
+        # not depend on how many ranks share the request.  False: the default (fastest) launch policy, batch-dependent low bits.
+        self.dp_shape_independent = True
 
     def initialize_service(self, dit_config: DitConfig, decoder_state_dict: Dict[str, torch.Tensor],
                            null_condition_emb: torch.Tensor, vae_config: Optional[VaeConfig] = None,
@@ -345,10 +349,12 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         return theirs).  Every per-request setting (steps, guidance, shift, CFG interval, ADG, ode / sde, explicit timesteps, tiled
         decode, latent shift / rescale, cover strength / cover noise strength) is rank 0's and travels with the request, and so do a cover
         request's tensors (``src_latents``, ``encoder_hidden_states_non_cover``, ``context_latents_non_cover`` in ``service_kwargs``);
-        any other keyword is refused on every rank.  A song's noise, schedule and conditions do not depend on the rank or the batch it
-        runs in; the low bits of its result do (tile shapes, split-K and the K rotation follow the launch shape, and requests of
-        2-3 / 5-6 songs run as two half-batch chains: ~3e-3 relative L2 between "alone" and "in a batch of 8", both at the reference's
-        distance; ``ace355_gemm_set_k_rotation(0)`` + ``set_dual(0)`` remove the batch dependence among launches of one tile regime).  ``extra_outputs`` (pred_latents, src_latents, ...)
+        any other keyword is refused on every rank.  A song's noise, schedule and conditions never depend on the rank or the batch it
+        runs in; by default (``self.dp_shape_independent = True``) neither do its bits: the request runs inside ``shape_independent()`` (one K order,
+        no split-K / split-KV, one sampler chain), so rank 0's G songs equal a single-process call of the same request under the same mode bit
+        for bit (tests/test_dist_gpu.py).  With ``dp_shape_independent = False`` every rank keeps the fastest launch policy for ITS slice and the
+        low bits follow the slice size (~3e-3 relative L2, both at the reference's distance); the payload says which:
+        ``extra_outputs["data_parallel"]["batch_dependent_bits"]``.  ``extra_outputs`` (pred_latents, src_latents, ...)
         describe the RETURNING rank's slice ``extra_outputs["song_range"]``, ``audios`` on rank 0 all G songs.  The per-call cap of 8 (handler/service_generate_request.py:12) then holds per rank."""
         if data_parallel:
             import torch.distributed as dist
@@ -465,14 +471,16 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         def execute(local):
             k = local["knobs"]
             # every setting comes from the BROADCAST request (rank 0's call), none from this rank's own arguments
-            payload, wavs = self._generate_music_local(
-                local["encoder_hidden_states"], local["context_latents"], local["seeds"], int(k["inference_steps"]), k["guidance_scale"],
-                k["shift"], "sde" if k["infer_method_sde"] else "ode", local["timesteps"], bool(k["use_tiled_decode"]),
-                k["latent_shift"], k["latent_rescale"], k["cfg_interval_start"], k["cfg_interval_end"],
-                bool(k["use_adg"]), progress if rank == 0 else None,
-                dict(audio_cover_strength=k["audio_cover_strength"], cover_noise_strength=k["cover_noise_strength"],
-                     src_latents=local["src_latents"], encoder_hidden_states_non_cover=local["encoder_hidden_states_non_cover"],
-                     context_latents_non_cover=local["context_latents_non_cover"]))
+            state["shape_independent"] = bool(self.dp_shape_independent)
+            with self.shape_independent(self.dp_shape_independent):
+                payload, wavs = self._generate_music_local(
+                    local["encoder_hidden_states"], local["context_latents"], local["seeds"], int(k["inference_steps"]), k["guidance_scale"],
+                    k["shift"], "sde" if k["infer_method_sde"] else "ode", local["timesteps"], bool(k["use_tiled_decode"]),
+                    k["latent_shift"], k["latent_rescale"], k["cfg_interval_start"], k["cfg_interval_end"],
+                    bool(k["use_adg"]), progress if rank == 0 else None,
+                    dict(audio_cover_strength=k["audio_cover_strength"], cover_noise_strength=k["cover_noise_strength"],
+                         src_latents=local["src_latents"], encoder_hidden_states_non_cover=local["encoder_hidden_states_non_cover"],
+                         context_latents_non_cover=local["context_latents_non_cover"]))
             state["payload"] = payload
             return wavs
 
@@ -483,36 +491,47 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
             err = err or exc
         if err is None and "error" in state:
             err = state["error"]
-        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=torch.device(self.device))
+        cdev = torch.device("cpu") if a_dist.host_staged() else torch.device(self.device)   # (gloo: collectives on host tensors)
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             return self._error_payload(err if err is not None else RuntimeError("generation failed on another rank"))
         wavs = res["local"]
         if wavs is None:   # this rank owns no song
             wavs = torch.empty(0, 2, 0, device=torch.device(self.device))
-        # song-major gather to rank 0 (samples per song are equal: one request, one duration)
-        n = torch.tensor([wavs.shape[0], wavs.shape[-1]], dtype=torch.int64, device=wavs.device)
-        sizes = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(sizes, n)
+        # song-major gather to rank 0 (ace355.dist.gather_waveforms: sizes through one all_gather, payloads point to point)
+        gathered = a_dist.gather_waveforms(wavs, dst=0)
         payload = state.get("payload") or {"audios": [], "status_message": "Generation completed successfully!", "extra_outputs": {},
                                            "success": True, "error": None}
+        payload["extra_outputs"]["song_range"] = res["range"]
         if rank != 0:
-            if wavs.numel():
-                dist.send(wavs.contiguous(), dst=0)
-            payload["extra_outputs"]["song_range"] = res["range"]
             return payload
         audios = list(payload["audios"])
         for r in range(1, world):
-            b, smp = int(sizes[r][0]), int(sizes[r][1])
-            if b * smp == 0:
-                continue
-            buf = torch.empty(b, wavs.shape[1], smp, dtype=wavs.dtype, device=wavs.device)
-            dist.recv(buf, src=r)
-            audios += [{"tensor": buf[i].cpu(), "sample_rate": self.sample_rate} for i in range(b)]
+            audios += [{"tensor": gathered[r][i].cpu(), "sample_rate": self.sample_rate} for i in range(gathered[r].shape[0])]
         payload["audios"] = audios
-        payload["extra_outputs"]["song_range"] = res["range"]
-        payload["extra_outputs"]["data_parallel"] = {"world": world, "global_batch": res["global_batch"]}
+        payload["extra_outputs"]["data_parallel"] = {"world": world, "global_batch": res["global_batch"],
+                                                     "batch_dependent_bits": not state.get("shape_independent", False)}
         return payload
+
+    @contextlib.contextmanager
+    def shape_independent(self, on: bool = True):
+        """Run the enclosed native calls with ONE arithmetic per song whatever the launch shape: `ace355_gemm_set_k_rotation(0)` (no K
+        rotation, no split-K, no split-KV / key-split attention: include/ace355.h) and one sampler chain (`ace355_dit_set_dual(0)`).  A song
+        generated alone, inside a batch of 8, or on any rank of a data-parallel request then comes out bit for bit the same
+        (tests/test_dist_gpu.py, tests/test_metric_shapes_gpu.py).  Costs the small-request optimisations their gain (measured per
+        request in DESIGN.md section 14); process-wide while active (the K-rotation mode is a library global)."""
+        if not on or self.native_dit is None:
+            yield
+            return
+        from . import native
+        prev_k = native.gemm_set_k_rotation(0)
+        prev_d = self.native_dit.set_dual(0)
+        try:
+            yield
+        finally:
+            native.gemm_set_k_rotation(prev_k)
+            self.native_dit.set_dual(prev_d)
 
     @staticmethod
     def _dp_guard(execute, local, state):

@@ -180,6 +180,11 @@ int ace355_gemm_bf16(const void* A, const void* W, void* C, int M, int N, int K,
     return launch_gemm((const bf16_t*)A, K, (const bf16_t*)W, K, C, N, M, N, K, ep, (hipStream_t)stream);
 }
 
+int ace355_linear_f32(const float* x, const float* w, const float* b, float* out, int64_t M, int N, int K, void* stream) {
+    ACE_CHECK(x && w && out, "linear_f32: null pointer");
+    return launch_linear_f32(x, w, b, out, (long)M, N, K, (hipStream_t)stream);
+}
+
 int ace355_gemm_bf16_fused(const void* A, const void* W, void* out, int M, int N, int K, int mode, const float* g1, const float* g2,
                            int g2_stride, int rows_per_seq, void* stream) {
     ACE_CHECK(A && W && out, "gemm_bf16_fused: null pointer");

@@ -1242,7 +1242,8 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
         int sp = 1;
         // (measured at batch 1, S = 375: the 13-tile cross-attention walk 22.2 -> 13.9 + 5.2 us in 4 parts; the 6-tile self-attention
         //  14.1 -> 12.9 + 5.1 us in 2 parts, a loss: the fp32 partials and the merge launch cost ~8 us, so only long walks split)
-        if (nw == 4 && a.part && !a.kv_len && !a.out_q && wgs < 128 && tiles >= 8) {
+        // (K rotation mode 0, "one summation order whatever the launch shape": no split either - the merge of partial softmaxes is another order)
+        if (nw == 4 && a.part && !a.kv_len && !a.out_q && wgs < 128 && tiles >= 8 && gemm_k_rotation_mode() != 0) {
             while (sp < 8 && wgs * sp * 2 <= 256 && tiles / (sp * 2) >= 2) sp *= 2;
             if (split_env >= 1) sp = split_env;
             if ((long)sp * a.N * a.Hq * a.Sq * 132 > a.part_floats) sp = 1;

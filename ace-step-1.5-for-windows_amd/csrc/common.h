@@ -258,6 +258,8 @@ int launch_expand_add(const float* emb, const float* special, float* out, long r
 int launch_pad_rows_bf16(const float* x, bf16_t* out, long rows, int cols, int ld, hipStream_t s);
 int launch_prepend_special(const float* emb, const float* special, float* out, long rows, int P, int D, hipStream_t s);
 int launch_take_token0(const bf16_t* x, float* out, long rows, int S, int D, hipStream_t s);
+// out f32 [M, N] = x f32 [M, K] W^T (f32 [N, K]) + b (f32 [N] or null), fp64 accumulation: the FSQ projections of the LM-hint path
+int launch_linear_f32(const float* x, const float* W, const float* b, float* out, long M, int N, int K, hipStream_t s);
 int launch_gather_rows_bf16_f32(const bf16_t* src, long src_ld, const int* row_src, float* dst, long dst_ld, long rows, int cols, hipStream_t s);
 
 struct TVals { float t[64]; };

@@ -836,6 +836,40 @@ int launch_prepend_special(const float* emb, const float* special, float* out, l
     ACE_LAUNCH_CHECK();
     return 0;
 }
+// out[m][n] = sum_k x[m][k] W[n][k] + b[n], everything fp32 (fp64 accumulation: the caller rounds the result to FSQ digits, and a
+// half-way case must not depend on a summation order).  The two projections of the residual FSQ on the LM-hint path (K = 6 -> hidden and
+// hidden -> 6; lmhints.py): K <= 64: one lane per output element, else one wave per output element (lanes stride K, butterfly sum).
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                         float* __restrict__ out, long M, int N, int K) {
+    if (K <= 64) {
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= M * N) return;
+        const long m = i / N;
+        const int n = (int)(i - m * N);
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += (double)x[m * K + k] * (double)W[(long)n * K + k];
+        out[i] = (float)(acc + (b ? (double)b[n] : 0.0));
+        return;
+    }
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per output element
+    const int lane = threadIdx.x & 63;
+    if (i >= M * N) return;
+    const long m = i / N;
+    const int n = (int)(i - m * N);
+    double acc = 0.0;
+    for (int k = lane; k < K; k += 64) acc += (double)x[m * K + k] * (double)W[(long)n * K + k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) out[i] = (float)(acc + (b ? (double)b[n] : 0.0));
+}
+int launch_linear_f32(const float* x, const float* W, const float* b, float* out, long M, int N, int K, hipStream_t s) {
+    ACE_CHECK(M > 0 && N > 0 && K > 0 && M * (long)N < (1L << 31), "linear_f32: sizes");
+    const long outs = M * N;
+    const long blocks = K <= 64 ? blocks_for(outs, 256) : (outs + 3) / 4;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, W, b, out, M, N, K);
+    ACE_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_take_token0(const bf16_t* x, float* out, long rows, int S, int D, hipStream_t s) {
     hipLaunchKernelGGL(take_token0_kernel, dim3(blocks_for(rows * D, 256)), dim3(256), 0, s, x, out, rows, S, D);
     ACE_LAUNCH_CHECK();

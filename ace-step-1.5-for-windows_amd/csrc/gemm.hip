@@ -19,45 +19,10 @@
 // every ds_read_b128 fragment read is bank-conflict free; with DMA the swizzle is applied on the source address).
 #include "common.h"
 
-#ifndef ACE355_ABL_HOTK
-#define ACE355_ABL_HOTK 0    // 1 (diagnostic build, WRONG results): every K step of the bf16 loop re-reads K slices 2 / 3 of its panels - the pieces are
-                             // issued as always but never miss the L2: separates the pieces' ISSUE cost from exposed fetch latency
-#endif
-#ifndef ACE355_ABL_NODMA
-#define ACE355_ABL_NODMA 0   // 1 (diagnostic build, WRONG results): the bf16 K loop issues no DMA pieces - what the pieces cost a K step
-#endif
-
-#ifndef ACE355_EPI_VEC
-#define ACE355_EPI_VEC 1     // 0 (A/B build): the folded-norm consumers of the 8-wave kernels load their row sums / bias / head-norm weights from global
-                             // memory at the top of the epilogue, as until round 5, instead of from the LDS vector area a DMA filled under the K loop
-#endif
-#ifndef ACE355_MFMA_ORDER
-#define ACE355_MFMA_ORDER 2  // order of the 16x16x32 MFMAs of a half K step (same accumulators, same sums; A/B builds: tools/r05_mfma_order.sh).  2 (default,
-                             // round 5): row-major over the wave's (2 MT) x (2 NTW) grid of 16x16 blocks walked as a SERPENTINE - exactly one operand register
-                             // set changes from one instruction to the next (the A-row fragment stays for 2 NTW instructions, the W fragment across the
-                             // turn).  0 = the plain row-major order (both operands change at every row turn); 1 / 3 = column-major, plain / serpentine
-                             // (the W fragment held).  The K loops sit at the power cap, where what pays is energy: same-box ABAB per 8-song pass, order 0 ->
-                             // 2: -0.45 % (6 of 6 pairs on two boxes), 0 -> 1: +0.3 %, 0 -> 3: +0.3 % (profiles/r05_mfma_order_ab.txt)
-#endif
-#ifndef ACE355_MFMA_PAIR
-#define ACE355_MFMA_PAIR 1   // 1 / 2: the K loop of the 8-wave 192x256 bf16 tile issues the two MFMAs a 16x16 block gets per K step (its K halves P and Q) BACK TO BACK on
-                             // the block's accumulator (gemm_sp_kernel: kstep_pair) instead of all P MFMAs, then all Q MFMAs.  Same instructions, same sums in the
-                             // same order per accumulator - the second MFMA takes its accumulator from the first without a trip through the register file, which
-                             // under the power cap is worth + 4.7 % on a pure-MFMA loop (tools/probe/mfma_acc_probe.hip).  0: the half-by-half loop (A/B builds)
-#endif
-#ifndef ACE355_MFMA_PAIR1
-#define ACE355_MFMA_PAIR1 1  // the pair K loop on the 8-wave 192x128 tile too (kstep_pair1: phases by column HALF of the wave's one column block); 0: A/B builds
-#endif
-#ifndef ACE355_PAIR_PCS
-#define ACE355_PAIR_PCS 0    // placement of the seven DMA pieces over the twelve pair slots of kstep_pair's phase B (A/B builds)
-#endif
-#ifndef ACE355_WAVE_PAIR
-#define ACE355_WAVE_PAIR 0   // 1 (A/B build): the two waves of a SIMD in the 8-wave tiles share their A rows instead of their W columns (gemm_sp_kernel)
-#endif
-#ifndef ACE355_EPI_NT
-#define ACE355_EPI_NT 0      // cache policy of the residual (mode 2) epilogue's single-use traffic, bit mask: 1 = old-H loads non-temporal, 2 = new-H
-                             // stores non-temporal, 4 = the folded norm's bf16(h * g) stores non-temporal (A/B builds: tools/r05_epi_nt.sh)
-#endif
+// Compile-time A/B arms of rounds 4-5 (K-loop ablations ACE355_ABL_HOTK / ABL_NODMA, EPI_VEC = 0, EPI_NT, MFMA_ORDER 1 / 2 / 3, MFMA_PAIR 0 / 2, PAIR_PCS,
+// WAVE_PAIR) were removed in round 6 once measured (git history up to dd0c588 has them; DESIGN.md sections 12-13 have their numbers).  What is left is
+// what ships.  MFMA issue rule of this file (round 6): every v_mfma_f32_16x16x32_bf16 is issued from asm with D == C, and no two
+// CONSECUTIVE MFMAs of a wave read the same srcA registers - both were found the hard way.
 
 #include <stdio.h>
 #include <type_traits>
@@ -141,19 +106,14 @@ __device__ __forceinline__ int stage_off(int row, int slot) {
 }
 
 __device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-typedef float f32x4nt __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2nt __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 ldf4_h(const float* p) {   // an old-H row segment of the residual epilogue (read once)
-    if constexpr ((ACE355_EPI_NT & 1) != 0) { const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(p)); return float4{v[0], v[1], v[2], v[3]}; }
-    else return *reinterpret_cast<const float4*>(p);
+    return *reinterpret_cast<const float4*>(p);
 }
 __device__ __forceinline__ void stf4_h(float* p, const float4& o) {   // the new-H row segment (next read: the next residual GEMM, ~200 MB of traffic later)
-    if constexpr ((ACE355_EPI_NT & 2) != 0) __builtin_nontemporal_store(f32x4nt{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4nt*>(p));
-    else *reinterpret_cast<float4*>(p) = o;
+    *reinterpret_cast<float4*>(p) = o;
 }
 __device__ __forceinline__ void stu2_xg(bf16_t* p, const uint2& v) {   // bf16(h * g): read by the next GEMM's DMA through every XCD's L2
-    if constexpr ((ACE355_EPI_NT & 4) != 0) __builtin_nontemporal_store(u32x2nt{v.x, v.y}, reinterpret_cast<u32x2nt*>(p));
-    else *reinterpret_cast<uint2*>(p) = v;
+    *reinterpret_cast<uint2*>(p) = v;
 }
 // v + (v of the lane a DPP control selects): cross-lane adds on the VALU, no LDS round trip
 template <int CTRL>
@@ -165,6 +125,16 @@ __device__ __forceinline__ float dpp_add(float v) {
 // of two chained builtins a scratch destination whenever that suits its register allocation, and only the in-place form is chained by the matrix pipe.
 __device__ __forceinline__ void mfma16_pair(f32x4v& c, const bf16x8& a0, const bf16x8& b0, const bf16x8& a1, const bf16x8& b1) {
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %3, %4, %0" : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+
+// c += a b as ONE v_mfma_f32_16x16x32_bf16 with D == C, from asm.  Round 6: left to the builtin, hipcc gave two MFMAs of the 4-wave
+// 128x128 two-stage SwiGLU loop a destination that OVERLAPS A SOURCE operand and differs from the accumulator it reads
+// (`v_mfma_f32_16x16x32_bf16 v[26:29], v[2:5], v[26:29], v[34:37]`: D == B != C; LLVM allows it for 4-register destinations) - and that launch
+// (M = 288 / 400, N = 12288, K = 2048: the condition encoder's gate|up projection, the one launch of the suite on that instantiation with a long K
+// loop) returned different bits on every call, up to 2.6e-2 from fp32 (tools/r06_gemm_determinism.py; profiles/r06_gemm_determinism.txt).  In-place
+// accumulation is the only form the kernels need, so it is the only form they issue.
+__device__ __forceinline__ void mfma16_inplace(f32x4v& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 
 template <int MODE, int MT, int NTW, bool ROWS_FULL, bool FOLD = true, bool L16 = false>   // FOLD: the folded-RMSNorm hooks are compiled in (bf16 kernels)
@@ -906,7 +876,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
     constexpr int EPI_BYTES = NW * MT * 32 * 128 + NW * MT * 32 * 4;  // epilogue staging: MT*32 rows x 128 B per wave (+ mode 4's row sums)
     // Vector area (8-wave bf16 kernels whose epilogue consumes a folded norm; one workgroup per CU, so the 4 KB are free): see gemm_epilogue_wide
-    constexpr bool VEC = (ACE355_EPI_VEC != 0) && !FP8 && WNW == 4 && (MODE == 0 || MODE == 3 || MODE == 4);
+    constexpr bool VEC = !FP8 && WNW == 4 && (MODE == 0 || MODE == 3 || MODE == 4);
     constexpr int VOFF = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[VOFF + (VEC ? 4096 : 0)];
 
@@ -937,10 +907,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     const int m0 = tm * BMv, n0 = tn * BNv;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // Which two waves share a SIMD (waves are dealt round-robin: wave w runs on SIMD w & 3, so the 8-wave tiles put waves w and w + 4 together):
-    // ACE355_WAVE_PAIR 0 = the pair shares its W columns (wn) and differs in its A rows; 1 (A/B build) = the pair shares its A rows.  `vw` is the
-    // wave's index in (wm, wn) order, which is what the epilogue's staging slices and row-sum exchange are laid out by.
-    const int wm = (ACE355_WAVE_PAIR && NW == 8) ? (wave & 1) : wave / WNW, wn = (ACE355_WAVE_PAIR && NW == 8) ? (wave >> 1) : wave % WNW;
+    // (waves are dealt round-robin over the SIMDs: in the 8-wave tiles waves w and w + 4 share one, i.e. the same W columns and different A rows)
+    const int wm = wave / WNW, wn = wave % WNW;
     const int vw = wm * WNW + wn;
 
     const int lrow = lane >> 3, pslot = lane & 7;
@@ -1089,8 +1057,8 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     }
     __builtin_amdgcn_s_barrier();
     load_frags(smem, 0, pa, pw);
-    constexpr bool PAIRK = (ACE355_MFMA_PAIR != 0) && L16 && NTW == 2 && NW == 8 && MT == 3 && (AJ + WJ) == 7;   // (kstep_pair below)
-    constexpr bool PAIRK1 = (ACE355_MFMA_PAIR != 0) && (ACE355_MFMA_PAIR1 != 0) && L16 && NTW == 1 && NW == 8 && MT == 3 && (AJ + WJ) == 5;   // (kstep_pair1: the 192x128 tile)
+    constexpr bool PAIRK = L16 && NTW == 2 && NW == 8 && MT == 3 && (AJ + WJ) == 7;   // (kstep_pair below)
+    constexpr bool PAIRK1 = L16 && NTW == 1 && NW == 8 && MT == 3 && (AJ + WJ) == 5;   // (kstep_pair1: the 192x128 tile)
     if constexpr (PAIRK || PAIRK1) load_frags(smem, 2, qa, qw);   // the pair loop starts a K step with both K halves of its A rows and of column block 0 in registers
     load_scales(smem);
 
@@ -1110,16 +1078,13 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         // 16x16x32 form: (i, hr, j, hc) - quad (hr, hc) of block (i, j), row half from fa[hr][i], column half from fw[hc][j]
         auto mfma_m = [&](int m, bf16x8 (&fa)[2][MT], bf16x8 (&fw)[2][NTW]) {
             if constexpr (L16) {
-                int i = m / (4 * NTW), hr = (m / (2 * NTW)) & 1, j = (m >> 1) % NTW, hc = m & 1;
-                if constexpr (ACE355_MFMA_ORDER == 1) { j = m / (4 * MT), hc = (m / (2 * MT)) & 1, i = (m >> 1) % MT, hr = m & 1; }
-                if constexpr (ACE355_MFMA_ORDER == 2) {   // odd (i, hr) rows walk their 2 NTW column halves backwards
-                    if ((m / (2 * NTW)) & 1) { const int c = 2 * NTW - 1 - (m % (2 * NTW)); j = c >> 1, hc = c & 1; }
-                }
-                if constexpr (ACE355_MFMA_ORDER == 3) {   // order 1 as a serpentine: odd (j, hc) columns walk their 2 MT row halves backwards
-                    const int col = m / (2 * MT), r0 = m % (2 * MT), r = (col & 1) ? 2 * MT - 1 - r0 : r0;
-                    j = col >> 1, hc = col & 1, i = r >> 1, hr = r & 1;
-                }
-                acc[i][j].q[hr * 2 + hc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[hc][j], fa[hr][i], acc[i][j].q[hr * 2 + hc], 0, 0, 0);
+                // plain row-major over the wave's (2 MT) x (2 NTW) grid of 16x16 blocks: srcA (the W fragment) changes with EVERY instruction, srcB (the A-row
+                // fragment) stays for 2 NTW of them.  Round 5's serpentine (one operand set changes per instruction: at every row turn srcA stays) and both
+                // column-major walks (srcA held for 2 MT instructions) are NOT reproducible on this chip when two workgroups share a CU: with a co-resident
+                // workgroup in a bf16 epilogue, 27-30 of 30 launches of a 384-tile GEMM differed (wrong elements: one MFMA's 4th output quarter), order 0: 0 of 30
+                // (tools/r06_order_det.sh, profiles/r06_order_det.txt).  The pair loops of the 8-wave tiles never repeat srcA either.
+                const int i = m / (4 * NTW), hr = (m / (2 * NTW)) & 1, j = (m >> 1) % NTW, hc = m & 1;
+                mfma16_inplace(acc[i][j].q[hr * 2 + hc], fw[hc][j], fa[hr][i]);
             } else {
                 const int h = m / (MT * NTW), i = (m / NTW) % MT, j = m % NTW;
                 acc[i][j].v = mfma32(fw[h][j], fa[h][i], acc[i][j].v);
@@ -1152,7 +1117,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             }
             const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
             const char* stn = smem + ((kt + 1) % NS) * STAGE;
-            const int kt2 = kmap((ACE355_ABL_HOTK ? (kt & 1) : kt) + NS);   // (HOTK: two K slices serve every step)
+            const int kt2 = kmap(kt + NS);   // (HOTK: two K slices serve every step)
             const bf16_t* a_k2 = A + kt2 * BK;  // uniform: tile kt+NS goes into the stage this step just finished reading
             const bf16_t* w_k2 = W + kt2 * BK;
 #pragma unroll
@@ -1163,7 +1128,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 constexpr bool SPREAD = (AJ + WJ <= NM) && (NF <= NM - (AJ + WJ));   // one piece or one read per slot (every product tile)
                 if constexpr (SPREAD) {
                     const int pc = dma_piece_of_slot<NM, AJ + WJ>(m);
-                    if (dma && !ACE355_ABL_NODMA && pc >= 0) {
+                    if (dma && pc >= 0) {
                         if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
                         else glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
                     }
@@ -1174,7 +1139,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
-                if (dma && !ACE355_ABL_NODMA) {
+                if (dma) {
 #pragma unroll
                     for (int q = 0; q < DP; ++q) {
                         const int pc = m * DP + q;
@@ -1227,12 +1192,10 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
                 pair_mfma(pi, 0);
                 if (pi < 2) pw[pi][1] = as_bf16x8(*frag_at(st, 0, pi, MT + 1));
                 else if (pi < 4) qw[pi - 2][1] = as_bf16x8(*frag_at(st, 2, pi - 2, MT + 1));
-                if constexpr (ACE355_MFMA_PAIR == 1) {   // the rows of the second half of the grid (3 .. 5) are read HERE, in the step that uses them (their
-                    if (pi < 6) {                         // registers died with the previous step's last pairs): phase B carries 17 items instead of 23
-                        const int r = 3 + (pi >> 1);
-                        if (pi & 1) qa[r & 1][r >> 1] = as_bf16x8(*frag_at(st, 2, r & 1, r >> 1));
-                        else pa[r & 1][r >> 1] = as_bf16x8(*frag_at(st, 0, r & 1, r >> 1));
-                    }
+                if (pi < 6) {   // the rows of the second half of the grid (3 .. 5) are read HERE, in the step that uses them (their registers died with the
+                    const int r = 3 + (pi >> 1);   // previous step's last pairs): phase B carries 17 items instead of 23
+                    if (pi & 1) qa[r & 1][r >> 1] = as_bf16x8(*frag_at(st, 2, r & 1, r >> 1));
+                    else pa[r & 1][r >> 1] = as_bf16x8(*frag_at(st, 0, r & 1, r >> 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1243,11 +1206,11 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             }
             const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
             const char* stn = smem + ((kt + 1) % NS) * STAGE;
-            const int kt2 = kmap((ACE355_ABL_HOTK ? (kt & 1) : kt) + NS);
+            const int kt2 = kmap(kt + NS);
             const bf16_t* a_k2 = A + kt2 * BK;
             const bf16_t* w_k2 = W + kt2 * BK;
             auto piece = [&](int pc) {
-                if (dma && !ACE355_ABL_NODMA && pc < ND) {
+                if (dma && pc < ND) {
                     if (pc < AJ) glds16_sv(a_voff[pc], a_k2, sb + pc * (NW * 1024));
                     else glds16_sv(w_voff[pc - AJ], w_k2, sb + A_BYTES + (pc - AJ) * (NW * 1024));
                 }
@@ -1260,23 +1223,10 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             };
             // Phase-B schedule (MT = 3, 7 pieces): at most ONE DMA piece per pair slot (a piece takes 60-185 cycles to issue: two in a row hold the wave
             // longer than its partner on the SIMD can cover), the re-read of row r's fragments anywhere from its last pair (slot 2 r + 1) on
-            constexpr bool SPLIT = (ACE355_MFMA_PAIR == 1);   // (2: all six rows re-read in phase B, the first form measured)
-#if ACE355_PAIR_PCS == 1
-            constexpr int PC[12] = {0, 1, 2, 3, 4, 5, 6, -1, -1, -1, -1, -1};          // (A/B: pieces up front)
-#elif ACE355_PAIR_PCS == 2
-            constexpr int PC[12] = {0, -1, 1, -1, 2, -1, 3, -1, 4, 5, 6, -1};          // (A/B: every other slot)
-#elif ACE355_PAIR_PCS == 3
-            constexpr int PC[12] = {0, -1, 1, -1, 2, -1, 3, -1, 4, 5, 6, -1};          // (A/B: every other slot, the reads re-balanced around them)
-#else
             constexpr int PC[12] = {0, 1, -1, 2, -1, 3, 4, -1, 5, -1, 6, -1};          // piece of the slot
-#endif
-#if ACE355_PAIR_PCS == 3
-            constexpr int WR[12] = {0, 1, -1, 2, -1, 3, -1, -1, -1, -1, -1, -1};
-#else
             constexpr int WR[12] = {0, -1, 1, -1, 2, -1, -1, 3, -1, -1, -1, -1};       // column-block-0 fragment of the slot
-#endif
-            constexpr int AP[12] = {-1, 0, -1, 1, -1, 2, -1, SPLIT ? -1 : 3, -1, SPLIT ? -1 : 4, -1, SPLIT ? -1 : 5};   // row whose P-half A fragment is re-read in the slot
-            constexpr int AQ[12] = {-1, -1, 0, -1, 1, -1, 2, -1, SPLIT ? -1 : 3, SPLIT ? -1 : 4, -1, SPLIT ? -1 : 5};   // ... Q half
+            constexpr int AP[12] = {-1, 0, -1, 1, -1, 2, -1, -1, -1, -1, -1, -1};     // row (0 .. 2) whose P-half A fragment is re-read in the slot
+            constexpr int AQ[12] = {-1, -1, 0, -1, 1, -1, 2, -1, -1, -1, -1, -1};     // ... Q half
             static_assert(NPR == 12 && ND == 7, "kstep_pair: the phase-B schedule is written for the 192x256 tile");
 #pragma unroll
             for (int pi = 0; pi < NPR; ++pi) {
@@ -1321,13 +1271,13 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             }
             const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kt % NS) * STAGE);
             const char* stn = smem + ((kt + 1) % NS) * STAGE;
-            const int kt2 = kmap((ACE355_ABL_HOTK ? (kt & 1) : kt) + NS);
+            const int kt2 = kmap(kt + NS);
             const bf16_t* a_k2 = A + kt2 * BK;
             const bf16_t* w_k2 = W + kt2 * BK;
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
                 pair1(r, 1);
-                if (dma && !ACE355_ABL_NODMA && r < ND) {
+                if (dma && r < ND) {
                     if (r < AJ) glds16_sv(a_voff[r], a_k2, sb + r * (NW * 1024));
                     else glds16_sv(w_voff[r - AJ], w_k2, sb + A_BYTES + (r - AJ) * (NW * 1024));
                 }
@@ -1347,7 +1297,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             // first half: k 0..63 of the step = the P fragments (both slots of each operand), k-blocks 0 | 1 -> op_sel 0
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
-                const int i = m / NTW, j = (ACE355_MFMA_ORDER == 2 && ((m / NTW) & 1)) ? NTW - 1 - m % NTW : m % NTW;   // (serpentine: see ACE355_MFMA_ORDER)
+                const int i = m / NTW, j = m % NTW;   // (plain row-major: consecutive MFMAs never share srcA, see mfma_m)
                 if constexpr (!L16) acc[i][j].v = mfma_mx<0>(pw[0][j], pw[1][j], pa[0][i], pa[1][i], acc[i][j].v, scw[j], sca[i]);
 #pragma unroll
                 for (int f = 2 * m; f < 2 * m + 2; ++f)
@@ -1374,7 +1324,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             constexpr int PER = (NF + RS - 1) / RS;
 #pragma unroll
             for (int m = 0; m < NX; ++m) {
-                const int i = m / NTW, j = (ACE355_MFMA_ORDER == 2 && ((m / NTW) & 1)) ? NTW - 1 - m % NTW : m % NTW;
+                const int i = m / NTW, j = m % NTW;
                 if constexpr (!L16) acc[i][j].v = mfma_mx<2>(qw[0][j], qw[1][j], qa[0][i], qa[1][i], acc[i][j].v, scw[j], sca[i]);
                 if (dma) {
 #pragma unroll
@@ -1432,6 +1382,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
             for (; kt + NS < nk; ++kt) kstep(kt, T{}, T{});     // steady state: branch-free
             for (; kt + 1 < nk; ++kt) kstep(kt, T{}, F{});       // the last NS-1 K steps but one: nothing left to prefetch
             kstep(kt, F{}, F{});                                 // last K step
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");        // (asm-issued MFMAs here too: mfma16_inplace)
             }
             }
         }
@@ -1758,7 +1709,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ep.kparts = 1;
     float* slab = ep.sk_slab;
     ep.sk_slab = nullptr;
-    if (variant != 1 && big == 0 && slab && ep.sk_cnt && g_splitk_ok == 1 && ep.mode != 3 && ep.wide_ok && N % 128 == 0) {
+    if (variant != 1 && big == 0 && slab && ep.sk_cnt && g_splitk_ok == 1 && ep.mode != 3 && ep.wide_ok && N % 128 == 0 && k_rotation_mode() != 0) {
         static int slab_env = -1, slab_ks = 0, slab_mink = 4, slab_maxwg = 256;
         if (slab_env < 0) {
             slab_env = env_int("ACE355_GEMM_SLAB", 0);          // 1: slab split-K for the small-M launches (measured slower: see above)
@@ -1792,7 +1743,9 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     // parts use fp32 atomics and the last bits depend on the arrival order.  ACE355_GEMM_KSPLIT=1 disables the split.
     ep.ksplit = 1;
     ep.sk_ord = 0;
-    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && !ep.sk_slab) {
+    // (K rotation mode 0 = "one summation order whatever the launch shape": no split-K either - a one-song launch then adds up a row's K range
+    //  exactly as the same row inside a batch of 8 does)
+    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && !ep.sk_slab && k_rotation_mode() != 0) {
         static int ks_env = -1;
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
         const int nk = K / BK;

@@ -75,9 +75,20 @@ def shard_seeds(seeds: List[int], world: int, rank: int) -> List[int]:
     return list(seeds[s:e])
 
 
+def host_staged() -> bool:
+    """True under the gloo backend: torch's gloo moves CUDA tensors for broadcast / all_reduce only (send, recv, scatter and
+    all_gather are CPU-only there), so every collective buffer of this module then lives in host memory and results are moved to
+    the GPU by their consumer.  That is the configuration of the CPU tests and of the two-ranks-on-one-GPU test
+    (tests/test_dist_gpu.py); under nccl (= RCCL) the buffers are device tensors and nothing is staged."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 def _collective_device(device: Optional[torch.device], bundle: Dict[str, Any]) -> torch.device:
     """Where the collective buffers live.  Under nccl / RCCL they must be GPU tensors on EVERY rank: a receiver that was handed
-    only None values (and no `device`) takes the current CUDA device, never the CPU (src would block forever on a mixed call)."""
+    only None values (and no `device`) takes the current CUDA device, never the CPU (src would block forever on a mixed call).
+    Under gloo: always the host (`host_staged`)."""
+    if host_staged():
+        return torch.device("cpu")
     if device is not None:
         return torch.device(device)
     for t in bundle.values():
@@ -245,13 +256,21 @@ def gather_waveforms(wav: torch.Tensor, dst: int = 0):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [wav]
     world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [torch.zeros(1, dtype=torch.int64, device=wav.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([wav.shape[0]], dtype=torch.int64, device=wav.device))
+    if host_staged():   # (gloo: point-to-point and all_gather are CPU-only; the gathered list then lives in host memory)
+        wav = wav.cpu()
+    # [songs, samples per song]: `dst` sizes its receive buffers from the SENDER's numbers (a rank without a song has no duration)
+    n = torch.tensor([wav.shape[0], wav.shape[-1] if wav.dim() > 1 else 1], dtype=torch.int64, device=wav.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
     if rank != dst:
         if wav.numel():
             dist.send(wav.contiguous(), dst=dst)
         return None
-    out = [torch.empty((int(c.item()),) + tuple(wav.shape[1:]), dtype=wav.dtype, device=wav.device) for c in counts]
+    out = []
+    for r, c in enumerate(counts):
+        b, smp = int(c[0]), int(c[1])
+        shape = (b,) + (tuple(wav.shape[1:-1]) + (smp,) if wav.dim() > 1 else ())
+        out.append(torch.empty(shape, dtype=wav.dtype, device=wav.device))
     out[dst].copy_(wav)
     for r in range(world):
         if r != dst and out[r].numel():
@@ -421,8 +440,9 @@ def run_request(request: Optional[Dict[str, torch.Tensor]], execute: Callable[[D
     if gather:
         if world > 1:
             if result is None:   # this rank owns no song (G < world): it still takes part in the size exchange
-                counts = [torch.zeros(1, dtype=torch.int64, device=ctx.device) for _ in range(world)]
-                dist.all_gather(counts, torch.tensor([0], dtype=torch.int64, device=ctx.device))
+                cdev = torch.device("cpu") if host_staged() else ctx.device
+                counts = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
+                dist.all_gather(counts, torch.zeros(2, dtype=torch.int64, device=cdev))
                 out["gathered"] = None
             else:
                 out["gathered"] = gather_waveforms(result, dst=src)

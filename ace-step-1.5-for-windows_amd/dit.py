@@ -8,6 +8,7 @@ already-loaded PyTorch module's ``state_dict()``, prepare noise on the host with
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from typing import Dict, List, Optional, Sequence, Union
 
@@ -200,11 +201,13 @@ class NativeDit:
         False / 0: off; True / 1: default (calls with >= 1536 token rows); 2: every call the kernels support."""
         native.check(self._lib.ace355_dit_set_norm_fold(self._h, int(enable)), "dit_set_norm_fold")
 
-    def set_dual(self, mode) -> None:
+    def set_dual(self, mode) -> int:
         """Dual-chain sampler (include/ace355.h ace355_dit_set_dual): requests of >= 2 songs as two half-batch samplers on two hardware
         queues.  False / 0: one chain; True / 1 (default): two chains for small requests (<= 2400 token rows in all: 2-3 songs of 30 s); 2: whenever
-        the request has >= 2 songs."""
+        the request has >= 2 songs.  Returns the previous mode."""
         native.check(self._lib.ace355_dit_set_dual(self._h, int(mode)), "dit_set_dual")
+        prev, self._dual_mode = getattr(self, "_dual_mode", int(os.environ.get("ACE355_DUAL", "1"))), int(mode)
+        return prev
 
     def dual_count(self) -> int:
         n = C.c_int64()

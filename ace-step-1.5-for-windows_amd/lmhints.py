@@ -5,9 +5,10 @@ attention pooler natively, FSQ in torch) -> quantised 5 Hz tokens -> detokenizer
 
 Mirror of ``AudioCodesMixin._parse_audio_code_string`` / ``_decode_audio_codes_to_latents``
 (acestep/core/generation/handler/audio_codes.py:20-66).  ``NativeDetokenizer`` is call-compatible with the reference's
-``AudioTokenDetokenizer`` module (``model.detokenizer``).  The FSQ index decode is a [n, 6] x [6, 2048] product and stays in
-torch on the caller's device; its arithmetic belongs to ``vector_quantize_pytorch`` (absent here): the restatement in
-``fsq_output_from_indices`` is parity-unpinned.
+``AudioTokenDetokenizer`` module (``model.detokenizer``).  The FSQ's two projections ([n, 6] x [6, 2048] and its transpose) run on the
+library's own fp32 kernel (``ace355_linear_f32``; no vendor GEMM on this path since round 6), the digit arithmetic around them is a few
+elementwise torch ops on the same device; all of it belongs to ``vector_quantize_pytorch`` (absent here): the restatements in
+``fsq_output_from_indices`` / ``fsq_quantize`` are parity-unpinned.
 """
 from __future__ import annotations
 
@@ -16,13 +17,32 @@ import re
 from typing import Dict, List, Optional, Sequence, Union
 
 import torch
-import torch.nn.functional as F
 
 from . import native
 from .config import DetokConfig
 
 MAX_AUDIO_CODE = 63999
 FSQ_LEVELS = (8, 8, 8, 5, 5, 5)
+
+
+def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.linear`` in fp32 on the library's kernel (``ace355_linear_f32``: fp64 accumulation, one summation order): x [..., K],
+    weight [N, K] -> [..., N] on weight's device.  There is no CPU path: the weights must live on the GPU."""
+    if not weight.is_cuda:
+        raise RuntimeError("ace355: the FSQ projections run on the native library; move the quantizer weights to the GPU")
+    dev = weight.device
+    w = weight.detach().to(torch.float32).contiguous()
+    b = None if bias is None else bias.detach().to(dev, torch.float32).contiguous()
+    x2 = x.detach().to(dev, torch.float32).reshape(-1, x.shape[-1]).contiguous()
+    N, K = w.shape
+    if x2.shape[1] != K:
+        raise ValueError("ace355: FSQ projection input width does not match the weight")
+    out = torch.empty(x2.shape[0], N, device=dev, dtype=torch.float32)
+    if x2.shape[0]:
+        with torch.cuda.device(dev):
+            native.check(native.lib().ace355_linear_f32(native.ptr(x2), native.ptr(w), native.ptr(b), native.ptr(out), x2.shape[0], N, K,
+                                                        native.current_stream_ptr()), "linear_f32")
+    return out.reshape(*x.shape[:-1], N)
 
 
 def parse_audio_code_string(code_str: str) -> List[int]:
@@ -35,13 +55,13 @@ def parse_audio_code_string(code_str: str) -> List[int]:
 def fsq_output_from_indices(indices: torch.Tensor, project_out_weight: torch.Tensor, project_out_bias: Optional[torch.Tensor] = None,
                             levels: Sequence[int] = FSQ_LEVELS) -> torch.Tensor:
     """ResidualFSQ(num_quantizers=1).get_output_from_indices restated: indices [B, T, 1] (or [B, T]) -> [B, T, dim]."""
-    idx = indices[..., 0] if indices.dim() == 3 else indices
+    idx = (indices[..., 0] if indices.dim() == 3 else indices).to(project_out_weight.device)
     lv = torch.tensor(list(levels), dtype=torch.int64, device=idx.device)
     basis = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.int64, device=idx.device), lv[:-1]]), dim=0)
     digits = (idx.to(torch.int64).unsqueeze(-1) // basis) % lv
     half = (lv // 2).to(torch.float32)
     codes = (digits.to(torch.float32) - half) / half
-    return F.linear(codes, project_out_weight.float(), None if project_out_bias is None else project_out_bias.float())
+    return _linear(codes, project_out_weight, project_out_bias)
 
 
 class NativeDetokenizer:
@@ -117,9 +137,9 @@ def fsq_quantize(z: torch.Tensor, project_in_weight: torch.Tensor, project_in_bi
     """ResidualFSQ(num_quantizers=1).forward restated (parity unpinned, like ``fsq_output_from_indices``): z [..., dim] ->
     (quantized [..., dim], indices [..., 1]).  project_in -> bounded tanh (half_l = (L - 1)(1 + eps) / 2, half-step offset for
     even L) -> round -> codes / floor(L / 2) -> project_out; index = mixed-radix number of the shifted digits."""
-    dev = z.device
+    dev = project_in_weight.device
     lv = torch.tensor(list(levels), dtype=torch.float32, device=dev)
-    y = F.linear(z.float(), project_in_weight.float(), None if project_in_bias is None else project_in_bias.float())
+    y = _linear(z, project_in_weight, project_in_bias)
     half_l = (lv - 1) * (1 + eps) / 2
     offset = torch.where(lv.to(torch.int64) % 2 == 0, torch.full_like(lv, 0.5), torch.zeros_like(lv))
     q = torch.round(torch.tanh(y + torch.atanh(offset / half_l)) * half_l - offset)
@@ -127,7 +147,7 @@ def fsq_quantize(z: torch.Tensor, project_in_weight: torch.Tensor, project_in_bi
     lvi = lv.to(torch.int64)
     basis = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.int64, device=dev), lvi[:-1]]), dim=0)
     idx = ((q + half_w).to(torch.int64) * basis).sum(-1, keepdim=True)
-    quantized = F.linear(q / half_w, project_out_weight.float(), None if project_out_bias is None else project_out_bias.float())
+    quantized = _linear(q / half_w, project_out_weight, project_out_bias)
     return quantized, idx
 
 

@@ -157,6 +157,7 @@ SIGNATURES = {
                                    C.c_int, C.c_float, C.c_void_p]),
     "ace355_attention_masked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_float, C.POINTER(C.c_int32), C.c_void_p]),
+    "ace355_linear_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "ace355_apg_euler_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                         C.c_int, C.c_void_p]),
     "ace355_conv1d_nlc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -373,6 +373,13 @@ int ace355_tok_finalize(ace355_tok* h);
 /* x dev f32 [B, T5 * pool_window_size, out_dim] (25 Hz frames, whole windows) -> out dev f32 [B, T5, hidden]. */
 int ace355_tok_run(ace355_tok* h, const float* x_dev, int B, int T5, float* out_dev, void* stream);
 
+/* The two projections of the residual FSQ quantizer on the LM-hint path (`model.tokenizer.quantizer.project_in / project_out`:
+ * hidden -> 6 and 6 -> hidden; reached from H/audio_codes.py:47-66 `_decode_audio_codes_to_latents` through
+ * `quantizer.get_output_from_indices`, and from base.py:1206-1218 `AceStepAudioTokenizer.forward`): out f32 [M, N] = x f32 [M, K] W^T
+ * (W f32 [N, K], nn.Linear layout) + b (f32 [N] or NULL), accumulated in fp64 - the caller rounds project_in's result to FSQ digits, so a
+ * half-way value must not depend on a summation order.  All pointers device memory. */
+int ace355_linear_f32(const float* x_dev, const float* w_dev, const float* b_dev, float* out_dev, int64_t M, int N, int K, void* stream);
+
 /* Post-decode peak clip, H/generate_music_decode.py:191-195: per item, if any peak > 1 divide
  * every item by clamp(peak, min=1).  wav dev f32 [B, per_item]. */
 int ace355_peak_normalize(float* wav_dev, int B, int64_t per_item, void* stream);

@@ -120,3 +120,19 @@ def test_audio_tokenizer_full_size_round_trip_through_the_detokenizer(gpu_device
     print(f"audio tokenizer (full size): pooled rel L2 vs fp32 oracle {rp:.3e}; {100 * agree:.0f} % of the 100 tokens get the oracle's code index")
     assert rp < 2.5e-2, rp        # measured 1.07e-2 (two plain-residual layers + one more bf16 operand than the detokenizer)
     assert agree > 0.7, agree     # measured 0.93
+
+
+@pytest.mark.parametrize("M,N,K", [(1200, 6, 2048), (1200, 2048, 6), (3, 5, 65), (1, 1, 1)])
+def test_fsq_projection_kernel_vs_fp64(gpu_device, M, N, K):
+    """``ace355_linear_f32`` (the residual FSQ's project_in / project_out on the LM-hint path, H/audio_codes.py:47-66): fp32 in / out,
+    fp64 accumulation, against torch fp64 on the host; both kernel forms (one lane / one wave per output); same bits twice."""
+    from ace355.lmhints import _linear
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b = torch.randn(4, M // 4 if M % 4 == 0 else M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    ref = (x.double() @ w.double().t() + b.double()).float()
+    y = _linear(x, w.to(gpu_device), b.to(gpu_device))
+    y2 = _linear(x, w.to(gpu_device), b.to(gpu_device))
+    assert y.shape == ref.shape and torch.equal(y, y2)
+    assert float((y.cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-7   # one fp32 rounding of the fp64 sum
+    with pytest.raises(RuntimeError, match="native library"):
+        _linear(x, w, b)   # CPU weights: no fallback

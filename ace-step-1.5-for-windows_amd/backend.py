@@ -453,11 +453,16 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
                 for kk in ("audio_cover_strength", "cover_noise_strength"):
                     if local_kwargs.get(kk) is not None:
                         knobs = dict(knobs, **{kk: float(local_kwargs[kk])})
+                src_ship = local_kwargs.get("src_latents")
+                if src_ship is None and float(local_kwargs.get("cover_noise_strength") or 0.0) > 0.0:
+                    # the renoised start t x noise + (1 - t) x src is fp32 host arithmetic on the FULL-precision source half of the context; the
+                    # context itself travels in bf16, so the default source is shipped explicitly (advisor r5: same bits as a single-GPU call)
+                    src_ship = context_latents[..., : context_latents.shape[-1] // 2].float()
                 request = a_dist.pack_request(encoder_hidden_states, context_latents, [int(s) for s in seed], None,
                                               timesteps=local_kwargs.get("timesteps"), use_tiled_decode=float(bool(local_kwargs.get("use_tiled_decode", True))),
                                               latent_shift=float(local_kwargs.get("latent_shift", 0.0)),
                                               latent_rescale=float(local_kwargs.get("latent_rescale", 1.0)),
-                                              src_latents=local_kwargs.get("src_latents"),
+                                              src_latents=src_ship,
                                               encoder_hidden_states_non_cover=local_kwargs.get("encoder_hidden_states_non_cover"),
                                               context_latents_non_cover=local_kwargs.get("context_latents_non_cover"), **knobs)
         except Exception as exc:

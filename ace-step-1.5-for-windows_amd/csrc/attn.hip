@@ -710,13 +710,15 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
 //     group 1:  | PV(i-1)  QK(i)    SM(i)   |
 //     group 2:  | SM(i-1)  PV(i-1)  QK(i)   |
 // so each SIMD always has two waves on the matrix pipe and one on the VALU.  Tile i-1's V^T is still read in interval i while tile
-// i+1 lands: K ring of 2 stages, V^T ring of 3 (80 KB).  That leaves 80 KB for Q, i.e. 2 heads x 96 query rows: one workgroup =
+// i+1 lands.  Rings as built (PD = 2 tiles of DMA in flight): K ring KRING = PD + 1 = 3 stages, V^T ring VRING = PD + 2 = 4 stages of 16 KB each =
+// 112 KB, + 48 KB of Q (2 heads x 96 query rows x 256 B) = the whole 160 KB of LDS.  VRING needs the extra stage: the V^T fragments of tile i-1 read by ld_pv
+// cross the barrier of interval i WITHOUT an lgkmcnt wait of their own, so the stage they come from must not be a DMA target before interval i + 1.  One workgroup =
 // (sequence, KV head, 96-row q-block) as attn_gqa_kernel<3>, but with TWELVE waves - each (q head, 32-row tile) is shared by two
 // waves that split every 64-key tile into its two 32-key halves (S is 16 registers instead of 32) and keep separate (m, l, O)
 // states, merged through LDS after the loop (each wave finishes half of the head dim).  Per wave and tile: 8 + 8 MFMAs and 16
 // exponentials; per SIMD and tile 1536 cycles of MFMA issue against ~1500 of VALU, running side by side instead of in turn.
 // Tile images, swizzles, the row permutation and the deferred rescale are attn3_kernel's.
-template <int NRT, int ABL = 0>   // 32-row tiles per q head; waves = 2 heads x NRT x 2 key halves.  ABL: diagnostic ablations (build with -DACE355_ATTN_ABL)
+template <int NRT>   // 32-row tiles per q head; waves = 2 heads x NRT x 2 key halves
 __global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, float scale_log2, float defer_thr) {
     constexpr int NW = 4 * NRT;
     constexpr int QB = NRT * 32;
@@ -854,14 +856,11 @@ __global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, fl
         return wave_live && (k0 < skv) && (k0 - (qw0 + 31) <= win) && (qw0 - (k0 + 31) <= win);
     };
 
-    // ABL bits (diagnostic builds only, results are WRONG; ACE355_ATTN_CLK = 1 + 2 ABL picks the instantiation): 1 = softmax arithmetic off,
-    // 2 = no DMA after the prologue, 4 = no barrier after the second, 8 = no MFMAs, 16 = no fragment reads after the first tile
-    constexpr bool ab_nosm = (ABL & 1) != 0, ab_nodma = (ABL & 2) != 0, ab_nobar = (ABL & 4) != 0, ab_nomma = (ABL & 8) != 0, ab_nold = (ABL & 16) != 0;
+    // (the ablation arms this kernel was tuned with - softmax / DMA / barrier / MFMA / fragment reads off, one at a time - live in tools/r06_attn_abl.patch)
     // Fragment buffers: every wave reads the NEXT segment's fragments while it computes on the current ones (three buffers of 4 x 16 bytes
     // per lane; the rings keep a tile's data valid across the barrier, so a buffer may be filled in one interval and consumed in the next).
     bf16x8 f0[4], f1[4], f2[4];
     auto ld_qk = [&](bf16x8 (&f)[4], int kt, int kb) {   // K fragments f[0..1], Q fragments f[2..3] of contraction steps 2 kb, 2 kb + 1
-        if (ab_nold && kt > kt_lo) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); return; }
         int kx = (half ^ k_swz) << 4, qx = (half ^ q_swz) << 4;
         asm volatile("" : "+v"(kx), "+v"(qx));
         const char* Ks = smem + kstage(kt) * KST + k_row_off;
@@ -877,12 +876,10 @@ __global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, fl
 #pragma unroll
             for (int r = 0; r < 16; ++r) sreg[r] = 0.f;
         }
-        if (ab_nomma) { sreg[0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f[0]).x ^ __builtin_bit_cast(uint4, f[3]).y); return; }
         sreg = mfma32(f[0], f[2], sreg);
         sreg = mfma32(f[1], f[3], sreg);
     };
     auto ld_pv = [&](bf16x8 (&f)[4], int kt, int t) {    // V^T fragments of 16-key step t of this wave's 32 keys: f[dt]
-        if (ab_nold && kt > kt_lo) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); return; }
         int vx = (half ^ v_swz) << 4;
         asm volatile("" : "+v"(vx));
         const char* Vs = smem + VOFF + vstage(kt) * KST + v_row_off;
@@ -891,12 +888,11 @@ __global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, fl
             f[dt] = as_bf16x8(*reinterpret_cast<const uint4*>(Vs + dt * 4096 + ((kh * 64 + t * 32) ^ vx)));
     };
     auto mma_pv = [&](const bf16x8 (&f)[4], int t) {
-        if (ab_nomma) { o[0][0] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, f[0]).x ^ __builtin_bit_cast(uint4, f[3]).y ^ __builtin_bit_cast(uint4, f[1]).z ^ __builtin_bit_cast(uint4, f[2]).w); return; }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = mfma32(f[dt], t ? pf[1] : pf[0], o[dt]);
     };
     auto dma_tile = [&](int kt) {   // this wave's pieces of tile kt (no-op past the last tile)
-        if (kt < kt_hi && !ab_nodma) {
+        if (kt < kt_hi) {
 #pragma unroll
             for (int i = 0; i < NPI; ++i) issue_piece(kt, i);
         }
@@ -912,19 +908,6 @@ __global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, fl
                 const bool ok = (key < skv) & ((unsigned)(qrow - key + win) <= (unsigned)(2 * win));
                 sreg[r] = ok ? sreg[r] : -INFINITY;
             }
-        }
-        if (ab_nosm) {
-            m_run = 0.f; l_run = 1.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                uint4 pb;
-                pb.x = pack_bf2(sreg[8 * t + 0], sreg[8 * t + 1]);
-                pb.y = pack_bf2(sreg[8 * t + 2], sreg[8 * t + 3]);
-                pb.z = pack_bf2(sreg[8 * t + 4], sreg[8 * t + 5]);
-                pb.w = pack_bf2(sreg[8 * t + 6], sreg[8 * t + 7]);
-                pf[t] = as_bf16x8(pb);
-            }
-            return;
         }
         float mx = sreg[0];
 #pragma unroll
@@ -969,14 +952,12 @@ __global__ __launch_bounds__(NRT * 256, NRT) void attn_rot_kernel(AttnArgs a, fl
     // too), the PD - 1 tiles requested after it may stay in flight (waves 0-7 own three pieces of a tile, waves 8-11 two).
     auto tile_sync = [&](int kt) {
         static_assert(PD == 2 && NW == 12, "the counted waits below are written for one tile in flight and 12 waves");
-        if (ab_nodma && kt > kt_lo + 1) {
-        } else if (kt + 1 < kt_hi) {
+        if (kt + 1 < kt_hi) {
             if (wave < 8) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (ab_nobar && kt > kt_lo + 1) return;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                      // that tile is complete in LDS; every wave is done with the previous interval
         __builtin_amdgcn_sched_barrier(0);
@@ -1180,17 +1161,7 @@ int launch_attention(const AttnArgs& a, hipStream_t s) {
             ap.clk_probe = clk;
             const long total = units(3);
             const dim3 grid((unsigned)((total + 7) / 8 * 8));
-#ifdef ACE355_ATTN_ABL
-            switch (clk >> 1) {
-#define ROT_ABL_CASE(x) case x: hipLaunchKernelGGL((attn_rot_kernel<3, x>), grid, dim3(768), 0, s, ap, scale_log2, thr); break;
-                ROT_ABL_CASE(1) ROT_ABL_CASE(2) ROT_ABL_CASE(4) ROT_ABL_CASE(8) ROT_ABL_CASE(16) ROT_ABL_CASE(6) ROT_ABL_CASE(7) ROT_ABL_CASE(17)
-                ROT_ABL_CASE(22) ROT_ABL_CASE(23) ROT_ABL_CASE(24) ROT_ABL_CASE(30) ROT_ABL_CASE(31) ROT_ABL_CASE(14) ROT_ABL_CASE(15)
-#undef ROT_ABL_CASE
-                default: hipLaunchKernelGGL((attn_rot_kernel<3, 0>), grid, dim3(768), 0, s, ap, scale_log2, thr);
-            }
-#else
-            hipLaunchKernelGGL((attn_rot_kernel<3, 0>), grid, dim3(768), 0, s, ap, scale_log2, thr);
-#endif
+            hipLaunchKernelGGL((attn_rot_kernel<3>), grid, dim3(768), 0, s, ap, scale_log2, thr);
             ACE_LAUNCH_CHECK();
             if (clk) {
                 unsigned long long hh[8] = {0};

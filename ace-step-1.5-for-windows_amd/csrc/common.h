@@ -151,11 +151,6 @@ struct GemmEpilogue {
     unsigned long long* nf_sqA; unsigned long long* nf_sqB;   // 2^-24 fixed point: integer adds commute, so the sums (and with them
     const unsigned long long* nc_rowsq; const float* nc_bias;  // every result) do not depend on the order the atomics arrive in
     float nc_inv_d, nc_eps;
-    // host-side launch hints (launch_gemm; the kernels ignore them).  tile_hint 1: the 8-wave 192x256 tile whatever the tile count
-    // (two concurrent half-batch launches of the CFG fork fill the chip together, dit.hip forward_core); no_pers 1: one workgroup per
-    // tile even for multi-round launches (a persistent grid keeps every CU it was given until its last tile: nothing for a kernel of
-    // another stream to slip into)
-    int tile_hint; int no_pers;
     int krot;   // kernel-visible: 1 = non-persistent bf16 launches walk K rotated by (workgroup's XCD) * nk / 8 (gemm.hip: K rotation)
     // cu_slots (0 = the whole chip, 256): the CUs this launch plans for - tile choice, persistent grid size, deep-pipeline decision.  The
     // dual-chain sampler (dit.hip) runs two independent launch sequences on two hardware queues and shapes every launch of both for 128
@@ -329,8 +324,6 @@ struct ConvArgs {
     // set by launch_conv: XCD-aware rasterisation of the (row block, column tile) grid (ras_tn > 1: a 1-D grid of ras_tm * ras_tn
     // workgroups per batch item, the column tiles of one row block on consecutive slots of ONE XCD); 0: the plain (m, n, b) grid
     int ras_tm; int ras_tn;
-    // set by launch_conv (ACE355_CONV_DEPHASE): the first `dephase_n` workgroups' second residents sleep `dephase` x 4096 cycles once
-    int dephase; int dephase_n;
 };
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_ncl_to_nlc(const float* z, bf16_t* out, int B, int C, int T, hipStream_t s);

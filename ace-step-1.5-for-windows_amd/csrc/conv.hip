@@ -20,16 +20,8 @@
 
 #include "common.h"
 
-#ifndef ACE355_CONV_V2
-#define ACE355_CONV_V2 1   // 0: the round-3 chunk / tap loop (A/B builds: tools/build_variant.sh old conv.hip -DACE355_CONV_V2=0)
-#endif
-#ifndef ACE355_CONV_FUSE2
-#define ACE355_CONV_FUSE2 1   // 0: the fused k = 1 stage with register-staged w2 chunks and parameter loads behind its first barrier
-#endif
-#define ACE355_CONV_F2 (ACE355_CONV_V2 && ACE355_CONV_FUSE2)
-#ifndef ACE355_CONV_PRIO
-#define ACE355_CONV_PRIO 0   // 1-3: s_setprio of a wave inside its tap loops (A/B builds)
-#endif
+// (the round-3 chunk / tap loop, the register-staged fused k = 1 stage, s_setprio in the tap loops and the de-phasing of the two resident
+// workgroups were A/B arms of rounds 4-5: measured, not kept, removed in round 6 - git history up to dd0c588, numbers in DESIGN.md 13.7)
 
 namespace ace355 {
 
@@ -90,7 +82,7 @@ __device__ __forceinline__ bf16x8 frag_kperm(const char* base, int row, int q, i
 template <int BN, int TM, int WS = 0>
 __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     static_assert(TM == 128 || (TM == 256 && BN == 128), "tile shapes");
-    static_assert(WS == 0 || (TM == 256 && BN == 128 && ACE355_CONV_F2), "the 32 x 128 wave shape belongs to the fused 8-wave form");
+    static_assert(WS == 0 || (TM == 256 && BN == 128), "the 32 x 128 wave shape belongs to the fused 8-wave form");
     constexpr int NTHR = TM * 2;
     constexpr int WIN_MAX = TM + HALO_MAX;
     constexpr int MT = WS ? 1 : ((BN == 128) ? 2 : 1);
@@ -98,7 +90,7 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     constexpr int WCH = BN * 8 / NTHR;  // 16-B weight chunks per thread per tile
     // (4-wave 128 x 128 form: + a third 16 KB weight buffer and a 2 KB parameter table for the fused k = 1 stage: 74 KB, still two
     //  workgroups per CU like the 8-wave form's 72 KB; WS = 1: the table only, w2 goes through the ring)
-    constexpr int FUSE_LDS = (ACE355_CONV_F2 && BN == 128 && TM == 128) ? (BN * 128 + 2048) : (WS ? 2048 : 0);
+    constexpr int FUSE_LDS = (BN == 128 && TM == 128) ? (BN * 128 + 2048) : (WS ? 2048 : 0);
     __shared__ __attribute__((aligned(16))) char smem[WIN_MAX * 128 + 2 * BN * 128 + FUSE_LDS];
     char* As = smem;
     char* Wbase = smem + WIN_MAX * 128;
@@ -123,19 +115,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             const int l2 = L - full * tn;
             by = l2 % tn;
             bx = full + l2 / tn;
-        }
-    }
-    // De-phasing (ACE355_CONV_DEPHASE, round 5).  The two workgroups of a CU start together and run the same sequence of phases - Snake
-    // staging (VALU), taps (MFMA), epilogue (memory) - in lock step: the matrix pipe is contended in the taps and idle in the stagings.
-    // The first generation's second workgroup per CU (wave slots beyond the first workgroup's: HW_ID.WAVE_ID) sleeps once at the start;
-    // later generations start when a slot frees and inherit the offset.
-    if (a.dephase > 0) {   // workgroup-uniform
-        const long lin = (long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
-        if (lin < a.dephase_n) {
-            const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_REG_HW_ID, WAVE_ID[3:0]: the wave's slot on its SIMD
-            if ((int)slot >= NTHR / 256) {
-                for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(64);   // 64 x 64 cycles per unit
-            }
         }
     }
     const int m0 = bx * TM, n0 = by * BN, b = blockIdx.z;
@@ -194,7 +173,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
     constexpr bool PARPRE = (TM == 128);                  // Snake parameters requested with the rows (16 more registers across the taps)
     u32x4 wv[WLD];
     const bool snake = a.alpha != nullptr;
-#if ACE355_CONV_V2
     // V2 addressing: a buffer descriptor per workgroup and one loop-invariant 32-bit byte offset per thread (its row within a block of
     // NTHR / 8 window rows, its 16-byte slot) plus a uniform offset per (chunk, row block).  The hardware's range check replaces the
     // predicates: the descriptor covers [max(first window element, 0), end of the valid flat range) of this batch item, an offset
@@ -224,19 +202,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             wv[i] = __builtin_bit_cast(u32x4, v);
         }
     };
-#else
-    auto win_load = [&](int ci0) {
-#pragma unroll
-        for (int i = 0; i < WLD; ++i) {
-            const int c = tid + i * NTHR;
-            const int xr = x_row0 + (c >> 3);
-            const long flat = (long)xr * Cin + ci0 + sslot * 8 + a.x_shift;
-            const bool inside = (c < win_rows * 8) && (a.x_valid ? (flat >= 0 && flat < a.x_valid) : (xr >= 0 && xr < a.L_in));
-            wv[i] = u32x4{0u, 0u, 0u, 0u};
-            if (inside) wv[i] = ld_u32x4(xb + flat);
-        }
-    };
-#endif
     // Snake parameters of this thread's 8 channels of a chunk (exp(alpha), 1 / (exp(beta) + 1e-9): fp32 bits).  V2 requests them with
     // the window rows (ahead of the barrier that opens the chunk); they used to be loaded at the top of win_store, behind that
     // barrier, and waited for on the spot: one exposed L2 round trip per chunk
@@ -251,7 +216,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         }
     };
     const int st0 = lds_off(tid >> 3, sslot);
-#if ACE355_CONV_V2
     auto vec_rsrc = [&](const float* p, int n) {
         const uintptr_t u = reinterpret_cast<uintptr_t>(p);
         const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
@@ -309,54 +273,10 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             if (c < win_rows * 8) *reinterpret_cast<u32x4*>(As + st0 + i * (NTHR / 8) * 128) = wv[i];
         }
     };
-#else
-    auto win_store = [&](int ci0) {
-        float sa[8], sib[8];
-        if (snake) {
-#if ACE355_CONV_V2
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sa[e] = __uint_as_float(spa[e >> 2][e & 3]);
-                sib[e] = __uint_as_float(spb[e >> 2][e & 3]);
-            }
-#else
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sa[e] = a.alpha[ci0 + sslot * 8 + e];   // already exp(alpha)
-                sib[e] = a.beta[ci0 + sslot * 8 + e];   // already 1/(exp(beta)+1e-9)
-            }
-#endif
-        }
-#pragma unroll
-        for (int i = 0; i < WLD; ++i) {
-            const int c = tid + i * NTHR;
-            if (c < win_rows * 8) {
-                u32x4 v = wv[i];
-                if (snake) {  // Snake(0) = 0: rows outside the signal stay zero
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) {
-                        const float x0 = bf_lo(v[e2]), x1 = bf_hi(v[e2]);
-                        const float s0 = __sinf(sa[2 * e2] * x0), s1 = __sinf(sa[2 * e2 + 1] * x1);
-                        v[e2] = pack_bf2(x0 + sib[2 * e2] * s0 * s0, x1 + sib[2 * e2 + 1] * s1 * s1);
-                    }
-                }
-#if ACE355_CONV_V2
-                // row block i is NTHR / 8 = 32 or 64 rows further down: (row >> 1) & 7 - the swizzle key - does not change, so the
-                // address is the thread's block-0 address plus an immediate (hipcc kept one address VGPR per block)
-                *reinterpret_cast<u32x4*>(As + st0 + i * (NTHR / 8) * 128) = v;
-#else
-                *reinterpret_cast<u32x4*>(As + lds_off(c >> 3, sslot)) = v;
-#endif
-            }
-        }
-    };
-
-#endif
     // (wave-uniform condition: the clock values stay in SGPRs; with a per-thread `tid == 0` they lived in ten VGPRs of every wave)
     const bool probe = a.clk_probe && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && __builtin_amdgcn_readfirstlane(wave) == 0;
     unsigned long long p_t0 = 0, p_w0 = 0, p_stage = 0, p_taps = 0, p_mark = 0;
     if (probe) p_t0 = clock64(), p_w0 = wall_clock64();
-#if ACE355_CONV_V2
     // Version 2 of the chunk / tap loop (round 5; same MFMA order per output element: results are bit-identical to version 1).
     // What the ISA of version 1 showed (hipcc --save-temps): (a) the Snake parameter loads of a chunk sat behind the chunk's first
     // barrier and were waited for at once; their destination registers were then reused for the tap loop's fragments, and because
@@ -385,9 +305,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
         if (PREFETCH && ci0 + 64 < Cin) { win_load(ci0 + 64); if (PARPRE) par_load(ci0 + 64); }
         if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
 
-#if ACE355_CONV_PRIO
-        __builtin_amdgcn_s_setprio(ACE355_CONV_PRIO);   // the taps' MFMA issue ahead of the other waves' Snake / epilogue VALU streams
-#endif
 #pragma unroll 1   // (hipcc unrolled the WS = 1 form's tap loop by its trip-count guess and hoisted every tap's fragment addresses: 169 VGPRs)
         for (int tap = 0; tap < taps; ++tap) {
             const bool more = (tap + 1) < taps;
@@ -460,57 +377,8 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
                 __syncthreads();
             }
         }
-#if ACE355_CONV_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (probe) p_taps += clock64() - p_mark;
     }
-#else
-    if (PREFETCH) win_load(0);
-    for (int ci0 = 0; ci0 < Cin; ci0 += 64) {
-        if (probe) p_mark = clock64();
-        if (!PREFETCH) win_load(ci0);
-        __syncthreads();  // previous chunk fully consumed
-        win_store(ci0);   // Snake in fp32 registers, parked in LDS once per chunk
-        if (PREFETCH && ci0 + 64 < Cin) win_load(ci0 + 64);
-        // ---- weight tile for tap 0 of this chunk (buffer 0: its last reader, the previous chunk's last tap, is behind the barrier above)
-        w_issue(0, ci0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the DMA is invisible to hipcc's own waits)
-        __syncthreads();
-        if (probe) { const unsigned long long t = clock64(); p_stage += t - p_mark; p_mark = t; }
-
-        for (int tap = 0; tap < taps; ++tap) {
-            const bool more = (tap + 1) < taps;
-            // the next tap's tile lands under this tap's MFMAs (every wave left that buffer at the last barrier).  All pieces up front:
-            // one piece behind each kk group of MFMAs (ILV, the GEMM's placement) measured 43.6 vs 42.8 ms per 8-song decode here - with
-            // two workgroups per CU the other workgroup's MFMAs already cover the issue cost, and the late pieces land later.
-            constexpr bool ILV = false;
-            if (!ILV && more) w_issue(tap + 1, ci0, (tap + 1) & 1);
-            const char* Ws = Wbase + (tap & 1) * (BN * 128);
-            const int arow = wm * (MT * 32) + tap * dil + lq;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 fa[MT], fw[NT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(As + lds_off(arow + i * 32, kk * 2 + half)));
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(Ws + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);  // swapped: lane = one output row, 4 consecutive channels per register quad
-                if (ILV && more && kk < WCH) w_piece(kk, tap + 1, ci0, (tap + 1) & 1);
-            }
-            if (more) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        }
-        if (probe) p_taps += clock64() - p_mark;
-    }
-#endif
     // ---- epilogue operands (declared ahead of the fused stage, which requests them under its MFMAs)
     const bool full = (m0 + TM <= a.M) && (n0 + BN <= a.N) &&
                       ((long)m0 * a.N + n0 + a.y_shift >= 0) && ((long)(m0 + TM - 1) * a.N + n0 + BN - 1 + a.y_shift < a.y_valid);
@@ -609,7 +477,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             epi_bias = a.bias2;
             const float* b7p = a.bias ? a.bias : a.alpha2;  // (unconditional loads: a branch per element would fence them)
             const float b7s = a.bias ? 1.f : 0.f;
-#if ACE355_CONV_F2
             __syncthreads();  // every wave is done with the window and the weight tiles
             char* A2 = smem;                      // 2 planes x 128 rows x 128 B (over the window and the head of ring buffer 0)
             const char* W2c0 = Wbase + 2 * BN * 128;             // w2 channels 0-63: the third buffer (landed under taps 1-4)
@@ -675,80 +542,6 @@ __global__ __launch_bounds__(TM * 2, TM / 64) void conv_kernel(ConvArgs a) {
             }
         }
     }
-#else
-            __syncthreads();  // every wave is done with the window and the weight tiles
-            char* A2 = smem;                      // 2 planes x 128 rows x 128 B
-            char* W2s = Wbase + BN * 128;         // second weight buffer (16 KB), beyond the planes
-            // w2 chunk 0 on its way while Snake runs
-            u32x4 rw2[WCH];
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) rw2[i] = ld_u32x4(a.w2 + (long)min(n0 + (tid >> 3) + (NTHR / 8) * i, a.N - 1) * 128 + sslot * 8);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                u32x4 b4[4], e4[4], i4[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c = n0 + wn * (NT * 32) + j * 32 + 8 * g + 4 * half;
-                    b4[g] = ld_u32x4(b7p + c);
-                    e4[g] = ld_u32x4(a.alpha2 + c);
-                    i4[g] = ld_u32x4(a.beta2 + c);
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float t[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = acc[i][j][4 * g + e] + b7s * __uint_as_float(b4[g][e]);
-                            const float sn = __sinf(__uint_as_float(e4[g][e]) * v);
-                            t[e] = v + __uint_as_float(i4[g][e]) * sn * sn;
-                        }
-                        const int row = wm * (MT * 32) + i * 32 + lq;
-                        uint2 pk = make_uint2(pack_bf2(t[0], t[1]), pack_bf2(t[2], t[3]));
-                        *reinterpret_cast<uint2*>(A2 + wn * 16384 + lds_off(row, j * 4 + g) + 8 * half) = pk;
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(W2s + wst[i]) = rw2[i];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            __syncthreads();
-#pragma unroll
-            for (int c2 = 0; c2 < 2; ++c2) {
-                if (c2 == 0) {
-#pragma unroll
-                    for (int i = 0; i < WCH; ++i) rw2[i] = ld_u32x4(a.w2 + (long)min(n0 + (tid >> 3) + (NTHR / 8) * i, a.N - 1) * 128 + 64 + sslot * 8);
-                }
-                const char* Ap = A2 + c2 * 16384;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    bf16x8 fa[MT], fw[NT];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        fa[i] = as_bf16x8(*reinterpret_cast<const uint4*>(Ap + lds_off(wm * (MT * 32) + i * 32 + lq, kk * 2 + half)));
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        fw[j] = as_bf16x8(*reinterpret_cast<const uint4*>(W2s + lds_off(wn * (NT * 32) + j * 32 + lq, kk * 2 + half)));
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(fw[j], fa[i], acc[i][j]);
-                }
-                if (c2 == 0) {
-                    __syncthreads();  // chunk 0 of w2 consumed by every wave
-#pragma unroll
-                    for (int i = 0; i < WCH; ++i) *reinterpret_cast<u32x4*>(W2s + wst[i]) = rw2[i];
-                    __syncthreads();
-                }
-            }
-        }
-    }
-#endif
     const unsigned long long p_e0 = probe ? clock64() : 0ull;
     auto probe_done = [&]() {
         if (!probe) return;
@@ -894,12 +687,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
                      (a.N % 8) == 0 && (a.y_shift % 8) == 0 &&
                      (a.y_batch_stride % 8) == 0 && (a.res_batch_stride % 8) == 0;
     }
-    static int tm_env = -1, clk_env = -1, ras_env = -1, deph_env = -1;
-    if (deph_env < 0) {
-        const char* e = getenv("ACE355_CONV_DEPHASE");   // units of 4096 cycles the second workgroup of a CU sleeps at the start (0: off)
-        deph_env = e ? atoi(e) : 0;
-    }
-    aw.dephase = deph_env; aw.dephase_n = 512;   // 256 CUs x 2 resident workgroups
+    static int tm_env = -1, clk_env = -1, ras_env = -1;
     if (ras_env < 0) {
         const char* e = getenv("ACE355_CONV_RAS");  // 0: the plain (m, n, b) grid (A/B runs); default 1: XCD-aware rasterisation
         ras_env = e ? atoi(e) : 1;
@@ -945,7 +733,6 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
             aw.ras_tm = (int)grid.x, aw.ras_tn = (int)grid.y;
             grid = dim3(grid.x * grid.y, 1, a.B);
         }
-#if ACE355_CONV_F2
         // fused residual unit (C = 128): the 8-wave form with 32 x 128 wave tiles from the same size threshold as the other k = 7 convs
         // (ACE355_CONV_F8=0 / 1: never / always, A/B runs); both forms give the same bits (frag_kperm)
         static int f8_env = -2;
@@ -959,7 +746,6 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
             aw.ras_tm = aw.ras_tn = 0;
             hipLaunchKernelGGL((conv_kernel<128, 256, 1>), g8, dim3(512), 0, s, aw);
         } else
-#endif
         if (tall) hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), 0, s, aw);
         else hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(256), 0, s, aw);
     } else {

@@ -127,23 +127,14 @@ struct ace355_dit {
         hipStream_t key_stream = nullptr; // ... and the stream that built them (another stream is not ordered behind it)
     } nf;
 
-    // CFG fork (round 4): inside a layer the conditional rows' cross-attention chain (cross-q GEMM -> attention ->
-    // cross-o GEMM: one-tile-deep launches on the conditional half only) and the MLP of the rows that skip cross-attention (the CFG null
-    // branch, whose cross term is a constant) are independent until the next layer's QKV projection: the null rows' gate|up / down GEMMs
-    // go to a side stream between two events.  Sequences are independent through a layer (base.py:515-539), the CFG doubling is only a
-    // cat (base.py:1905-1911).  Results are bit-identical to the single-stream order (every output element is the same accumulation
-    // whatever launch it lands in; the row sums are integer atomics).
+    // The handle's side stream (chain 2 of the dual-chain sampler below) with its fork / join events and its own split-K turn counters.  (Rounds 4-5 also
+    // ran a per-layer "CFG fork" on it - the null rows' MLP beside the conditional rows' cross-attention chain: bit-identical, and slower at every batch
+    // size measured (8 songs: 549 vs 507 ms per pass; 1 / 2 songs: 178 vs 141 / 212 vs 190 ms per request, profiles/r06_small_batch_switches.txt) - removed in
+    // round 6: tools/r06_cfg_fork.patch, DESIGN.md sections 12.1 / 14.)
     struct CfgFork {
-        int mode = 0;                 // ACE355_CFG_FORK / ace355_dit_set_cfg_fork: 0 off (default: measured SLOWER, 549 vs 507 ms per pass - a
-                                      // persistent gate|up grid on the side stream holds every CU and the cross-attention launches wait for it;
-                                      // DESIGN.md section 10), 1 big bf16 sampler launches, 2 every eligible call (tests)
-        int min_rows = 1536;          // both halves must take the big tiles (no split-K counters shared between the streams)
-        int down_big = 1;             // ACE355_FORK_DOWN_BIG: the two half-batch down projections on the 192x256 tile (128 workgroups each)
-        int no_pers = 0;              // ACE355_FORK_NOPERS: side-stream gate|up without persistent workgroups
         hipStream_t side = nullptr;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         int* sk_cnt = nullptr;        // the side stream's own split-K turn counters (two concurrent launches must not share tile counters)
-        long forks = 0;               // layers that took the fork so far (tests)
     } fk;
 
     // Dual-chain sampler (round 4).  The songs of a request are independent through the whole sampling loop (generate_audio carries no
@@ -169,7 +160,6 @@ struct ace355_dit {
         bool concurrent = false;      // the answer for the current call's stream
         long calls = 0;               // sampler calls that ran as two chains (tests)
     } dual;
-    bool fork_blocked = false;   // the current call runs as two chains: the side stream is chain 2's, no per-layer CFG fork on it
     bool alias = false;      // this object is a chain context: weights, slots and rope tables belong to the owning handle
     int cu_slots = 0;        // GemmEpilogue::cu_slots / AttnArgs::cu_slots of this context's launches (0: the whole chip)
 
@@ -565,7 +555,9 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     // call since then used that row as data - and by nothing else (every producer stores rows < M only).
     static int zr_env = -1;
     if (zr_env < 0) { const char* e = getenv("ACE355_GEMM_ZROW"); zr_env = e ? atoi(e) : 1; }
-    if (zr_env && h->zr_M != M) {
+    // (under graph capture ALWAYS: a graph recorded while zr_M == M would hold no memset, and replaying it after a larger call used row M as
+    //  data would read stale pad rows - harmless for the results, the rows are discarded, but not the zeros the comment above promises; advisor r5)
+    if (zr_env && (h->zr_M != M || h->graph_mode)) {
         ACE_HIP(hipMemsetAsync(h->xn + (size_t)M * D, 0, (size_t)D * sizeof(bf16_t), s));
         ACE_HIP(hipMemsetAsync(h->ao + (size_t)M * QD, 0, (size_t)QD * sizeof(bf16_t), s));
         ACE_HIP(hipMemsetAsync(h->act + (size_t)M * F, 0, (size_t)F * sizeof(bf16_t), s));
@@ -596,35 +588,6 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     ep = GemmEpilogue{1, h->b_in, nullptr, nullptr, 0, 0};
     rc = gemm(h, h->xin, 2 * h->cfg.in_channels, h->w_in, 2 * h->cfg.in_channels, h->h, D, M, D, 2 * h->cfg.in_channels, ep, s);
     if (rc) return rc;
-
-    // CFG fork eligibility: a sampler forward (one shared timestep row: per-row gate / norm vectors have stride 0), bf16 kernels,
-    // both halves present and big enough for the big tiles
-    const int fk_min = h->fk.mode >= 2 ? 1 : h->fk.min_rows;
-    const bool fork_ok = h->fk.mode > 0 && !h->fork_blocked && !h->alias && h->fk.side && temb_rows == 1 && n_sc > 0 && Nc > 0 && Mc >= fk_min && M - Mc >= fk_min &&
-                         h->precision != ACE355_PRECISION_MXFP8;
-    // SwiGLU MLP (base.py:530-533) of token rows [r0, r0 + nr) on stream st (bf16 kernels): [norm] -> gate|up + SwiGLU -> down + gated residual
-    auto mlp_rows = [&](int li, int r0, int nr, hipStream_t st) -> int {
-        const LayerW& W = h->layers[li];
-        const float* g_mlp = gs_p + (size_t)(li * 2 + 1) * 2 * D;
-        int rc2 = 0;
-        if (!fold) rc2 = launch_rmsnorm_gs(h->h + (size_t)r0 * D, g_mlp, g_mlp + D, h->xn + (size_t)r0 * D, nr, D, eps, 0, S, st);
-        if (rc2) return rc2;
-        GemmEpilogue e3{3, nullptr, nullptr, nullptr, 0, 0};
-        if (fold) {
-            e3.nc_rowsq = rowsq(li, 2) + r0; e3.nc_bias = nf.bias_gu + ((size_t)li * nf.rows + nf.step) * 2 * F;
-            e3.nc_inv_d = inv_d; e3.nc_eps = eps;
-        }
-        if (st != s) e3.no_pers = h->fk.no_pers;
-        rc2 = gemm(h, h->xn + (size_t)r0 * D, D, W.wgu, D, h->act + (size_t)r0 * F, F, nr, 2 * F, D, e3, st);
-        if (rc2) return rc2;
-        GemmEpilogue e2{2, nullptr, W.sst + 5 * D, tproj_p + 5 * D, 0, S};
-        if (fold && li + 1 < h->NL) {  // the next layer's self-attention norm operand
-            e2.nf_xg = h->xn + (size_t)r0 * D; e2.nf_ldx = D; e2.nf_split = 0;
-            e2.nf_gA = e2.nf_gB = gs_p + (size_t)((li + 1) * 2 + 0) * 2 * D; e2.nf_sqA = e2.nf_sqB = rowsq(li + 1, 0) + r0;
-        }
-        e2.tile_hint = h->fk.down_big;
-        return gemm(h, h->act + (size_t)r0 * F, F, W.wdown, F, h->h + (size_t)r0 * D, D, nr, D, F, e2, st);
-    };
 
     RoctxRange r_fwd("ace355.dit_forward");
     for (int li = 0; li < h->NL; ++li) {
@@ -712,17 +675,6 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
 
-        // ---- CFG fork: the rows that skip cross-attention go on to their MLP on the side stream while the conditional rows run
-        // the cross-attention chain on this one (joined before the next layer's QKV projection)
-        const bool forked = fork_ok;
-        if (forked) {
-            ACE_HIP(hipEventRecord(h->fk.ev_fork, s));
-            ACE_HIP(hipStreamWaitEvent(h->fk.side, h->fk.ev_fork, 0));
-            rc = mlp_rows(li, Mc, M - Mc, h->fk.side);
-            if (rc) return rc;
-            ACE_HIP(hipEventRecord(h->fk.ev_join, h->fk.side));
-            h->fk.forks++;
-        }
         // ---- cross attention (base.py:515-526): un-modulated norm, plain residual, cached K/V, no RoPE
         if (Nc > 0) {
         static int mx_cross = -1;
@@ -776,13 +728,6 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         }
 
         // ---- SwiGLU MLP (base.py:530-533)
-        if (forked) {   // the null rows' MLP is already queued on the side stream; here the conditional rows', then the join
-            rc = mlp_rows(li, 0, Mc, s);
-            if (rc) return rc;
-            ACE_HIP(hipStreamWaitEvent(s, h->fk.ev_join, 0));
-            if (h->tap_dst[li]) ACE_HIP(hipMemcpyAsync(h->tap_dst[li], h->h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-            continue;
-        }
         const bool mx_gu = mx_usable(h, W.mx_gu, M, 2 * F, D, 3) && D == 2048;
         if (fold) rc = 0;
         else if (mx_gu)
@@ -932,7 +877,6 @@ int chain_ctx_sync(ace355_dit* h) {
     if (!h->dual.ctx) {
         ace355_dit* c = new ace355_dit();
         c->alias = true;
-        c->fk.mode = 0;
         c->dual.mode = 0;
         ALLOC(c->allocs, c->flags_dev, 4);
         ALLOC(c->allocs, c->sk_cnt, SK_CNT_INTS);
@@ -1090,17 +1034,8 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     if (const char* e = getenv("ACE355_DUAL")) h->dual.mode = atoi(e);
     if (const char* e = getenv("ACE355_DUAL_SLOTS_MIN_ROWS")) h->dual.slots_min_rows = atoi(e);
     if (const char* e = getenv("ACE355_DUAL_MAX_ROWS")) h->dual.max_rows = atoi(e);
-    if (const char* e = getenv("ACE355_CFG_FORK")) h->fk.mode = atoi(e);
-    if (const char* e = getenv("ACE355_CFG_FORK_MIN_ROWS")) h->fk.min_rows = atoi(e);
-    if (const char* e = getenv("ACE355_FORK_DOWN_BIG")) h->fk.down_big = atoi(e);
-    if (const char* e = getenv("ACE355_FORK_NOPERS")) h->fk.no_pers = atoi(e);
     {
-        int lo = 0, hi = 0;   // (numerically: hi <= 0 <= lo; the greatest value is the lowest priority)
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        int prio = 0;         // ACE355_FORK_PRIO: -1 side stream above the caller's, 0 same, 1 below
-        if (const char* e = getenv("ACE355_FORK_PRIO")) prio = atoi(e);
-        prio = prio < 0 ? hi : (prio > 0 ? lo : 0);
-        ACE_HIP(hipStreamCreateWithPriority(&h->fk.side, hipStreamNonBlocking, prio));
+        ACE_HIP(hipStreamCreateWithFlags(&h->fk.side, hipStreamNonBlocking));
         ACE_HIP(hipEventCreateWithFlags(&h->fk.ev_fork, hipEventDisableTiming));
         ACE_HIP(hipEventCreateWithFlags(&h->fk.ev_join, hipEventDisableTiming));
     }
@@ -1286,7 +1221,6 @@ int ace355_dit_forward(ace355_dit* h, const float* x_dev, const float* ctx_dev, 
     hipStream_t s = (hipStream_t)stream;
     h->vt_key_N = h->vt_key_S = -1;   // (see ace355_dit_sample)
     h->cu_slots = 0;
-    h->fork_blocked = false;
     int rc = ensure_workspace(h, N, T, s);
     if (rc) return rc;
     const int Tpad = 2 * ((T + 1) / 2);
@@ -1358,16 +1292,9 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         ace355_dit* h;
         ~CallState() {
             h->cu_slots = 0;
-            h->fork_blocked = false;
             if (h->dual.ctx) h->dual.ctx->cu_slots = 0;
         }
     } call_state{h};
-    h->fork_blocked = nchains == 2;
-    if (nchains == 1 && h->fk.mode > 0 && h->fk.side && do_cfg) {   // the per-layer CFG fork needs the same guarantee: a side stream on its own queue
-        int rc0 = dual_probe_streams(h, run_s);
-        if (rc0) return rc0;
-        h->fork_blocked = !h->dual.concurrent;
-    }
     int rc;
     for (int k = 0; k < nchains; ++k) {
         ace355_dit* c = ctxs[k];
@@ -1630,19 +1557,6 @@ int ace355_dit_set_dual(ace355_dit* h, int mode) {
 int ace355_dit_dual_count(ace355_dit* h, int64_t* calls) {
     ACE_CHECK(h && calls, "dual_count: null argument");
     *calls = h->dual.calls;
-    return ACE355_OK;
-}
-
-int ace355_dit_set_cfg_fork(ace355_dit* h, int mode) {
-    ACE_CHECK(h && mode >= 0 && mode <= 2, "set_cfg_fork: mode must be 0, 1 or 2");
-    h->fk.mode = mode;
-    h->ws_epoch++;  // a captured sampler graph holds the other variant's launches
-    return ACE355_OK;
-}
-
-int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks) {
-    ACE_CHECK(h && forks, "cfg_fork_count: null argument");
-    *forks = h->fk.forks;
     return ACE355_OK;
 }
 

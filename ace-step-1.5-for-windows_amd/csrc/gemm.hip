@@ -1598,7 +1598,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
 #define ACE_LAUNCH_SP(kern, thr) hipLaunchKernelGGL(kern, grid, dim3(thr), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m, xcd_m)
     if constexpr (MODE == 4) {  // head epilogue: every tile whose N-waves pair up over a 128-column head (not the 2-stage mid tile, not v1)
         if (big == 2) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
-        else if (big && pers && !ep.no_pers && region > pers_x) {
+        else if (big && pers && region > pers_x) {
             const dim3 pgrid(8 * pers_x);
             hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                                xcd_m);
@@ -1615,7 +1615,7 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
             if (mid_ns == 3) ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1, 0, 3>), 512);
             else ACE_LAUNCH_SP((gemm_sp_kernel<MODE, 3, 4, 1>), 512);
         }
-    } else if (big && pers && !ep.no_pers && region > pers_x && (MODE != 2 || pers >= 2)) {
+    } else if (big && pers && region > pers_x && (MODE != 2 || pers >= 2)) {
         const dim3 pgrid(8 * pers_x);
         hipLaunchKernelGGL((gemm_sp_kernel<MODE, 3, 4, 2, 1>), pgrid, dim3(512), 0, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg, group_m,
                            xcd_m);
@@ -1687,7 +1687,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
         // (>= 180 tiles: three quarters of the CUs with one 8-wave workgroup each beat the same work as 384 four-wave workgroups on 512
         //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
-        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 * cus / 256 && (N % 256 == 0 || N >= 1024)) || (ep.tile_hint == 1 && bigenv != 0 && N % 256 == 0)) { mt = 3; bn = 256; big = 1; }
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 * cus / 256 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
         else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 * cus / 256 && t192 <= 320 * cus / 256))) { mt = 3; bn = 128; big = 2; }
     }
     // One sequence's worth of rows (the conditional rows' cross-attention projections of a one-song request: M = 375 -> 48 workgroups of

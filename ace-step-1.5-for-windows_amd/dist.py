@@ -333,13 +333,15 @@ def pack_request(encoder_hidden_states: torch.Tensor, context_latents: torch.Ten
         b["null"] = null_condition_emb.reshape(-1).contiguous()
     # explicit schedule of the sft variant (base.py:1864-1875); empty = derive it from inference_steps / shift
     b["timesteps"] = torch.as_tensor([] if timesteps is None else [float(t) for t in timesteps], dtype=torch.float32)
-    for name, t in (("src", src_latents), ("ctx_non_cover", context_latents_non_cover)):
+    for name, t, ch in (("src", src_latents, ctx.shape[-1] // 2), ("ctx_non_cover", context_latents_non_cover, ctx.shape[-1])):
         if t is None:
             b[name] = torch.zeros(0)
             continue
         t = t if t.dim() == 3 else t[None]
         if t.shape[0] not in (1, G):
             raise ValueError(f"pack_request: {name} must have 1 or {G} rows, got {t.shape[0]}")
+        if t.shape[1] != ctx.shape[1] or t.shape[2] != ch:   # (a mismatch would otherwise ship and fail later on EVERY rank: advisor r5)
+            raise ValueError(f"pack_request: {name} must be [*, {ctx.shape[1]}, {ch}] like the request's context latents, got {tuple(t.shape)}")
         if t.shape[0] > 1 and bool((t == t[:1]).all()):
             t = t[:1]
         b[name] = t.contiguous()

@@ -214,17 +214,6 @@ class NativeDit:
         native.check(self._lib.ace355_dit_dual_count(self._h, C.byref(n)), "dit_dual_count")
         return n.value
 
-    def set_cfg_fork(self, mode) -> None:
-        """CFG fork: the null rows' MLP on a side stream beside the conditional rows' cross-attention chain (include/ace355.h).
-        False / 0: off (the default: measured slower); True / 1: big bf16 sampler calls; 2: every eligible call.  Only single-chain calls fork
-        (set_dual(False), or one song)."""
-        native.check(self._lib.ace355_dit_set_cfg_fork(self._h, int(mode)), "dit_set_cfg_fork")
-
-    def cfg_fork_count(self) -> int:
-        n = C.c_int64()
-        native.check(self._lib.ace355_dit_cfg_fork_count(self._h, C.byref(n)), "dit_cfg_fork_count")
-        return n.value
-
     def set_dedup(self, enable: bool) -> None:
         """Layer-0 de-duplication of the two CFG copies of a song (include/ace355.h: `ace355_dit_set_dedup`); on by default."""
         native.check(self._lib.ace355_dit_set_dedup(self._h, 1 if enable else 0), "dit_set_dedup")

@@ -86,8 +86,6 @@ SIGNATURES = {
     "ace355_gemm_set_k_rotation": (C.c_int, [C.c_int]),
     "ace355_dit_set_dual": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_dual_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
-    "ace355_dit_set_cfg_fork": (C.c_int, [C.c_void_p, C.c_int]),
-    "ace355_dit_cfg_fork_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ace355_dit_set_dedup": (C.c_int, [C.c_void_p, C.c_int]),
     "ace355_dit_dedup_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ace355_dit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -513,7 +513,11 @@ def main():
                                f"{G} songs per request over {world} GPU(s)" + (", DiT-only" if args.no_vae else "") + (", per-item LM hints scattered" if args.lm_hints else ""),
                    "audio_seconds": args.duration, "infer_steps": args.infer_steps, "batch_per_gpu": B, "batch_rank0": B, "global_batch": G,
                    "parallelism": f"dp{world}", "tiny": bool(args.tiny), "gc_disabled_in_timed_region": not args.gc_on,
-                   "sampler_chains_per_gpu": (dit.dual_count() > 0) + 1 if hasattr(dit, "dual_count") else 1},
+                   "sampler_chains_per_gpu": (dit.dual_count() > 0) + 1 if hasattr(dit, "dual_count") else 1,
+                   # the bench keeps the library's default (fastest) launch policy on every rank: a song's low bits then follow the size of the
+                   # slice it runs in (~3e-3 rel L2, both at the reference's distance).  NativeHandler.generate_music(data_parallel=True) selects
+                   # the launch-shape-independent mode instead (same bits on 1 / 2 / 4 / 8 GPUs; tests/test_dist_gpu.py)
+                   "batch_dependent_bits": True},
     }
     if other is not None:
         result[other["scaling"]] = other

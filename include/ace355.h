@@ -191,21 +191,12 @@ int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 int ace355_dit_set_dual(ace355_dit* h, int mode);
 int ace355_dit_dual_count(ace355_dit* h, int64_t* calls);
 
-/* CFG fork (OFF by default - measured slower; ACE355_CFG_FORK=1 in the environment or mode = 1 here turns it on for
- * single-chain calls): under classifier-free guidance the
- * batch is cat([cond, null]) (base.py:1905-1911) and the null half's cross-attention is a constant, so inside a decoder layer
- * (base.py:515-539) the conditional rows' cross-attention chain and the null rows' MLP are independent: ace355_dit_sample queues the
- * latter on a side stream (fork after the self-attention o_proj, join before the next layer's QKV projection; captured like any
- * other launch under ace355_dit_set_graph).  Bit-identical to the single-stream order.  mode: 0 off (default), 1 bf16 calls whose two
- * halves have >= 1536 token rows each, 2 every eligible call (tests).  cfg_fork_count: layers that forked so far. */
-int ace355_dit_set_cfg_fork(ace355_dit* h, int mode);
-int ace355_dit_cfg_fork_count(ace355_dit* h, int64_t* forks);
-
 /* Layer-0 de-duplication under classifier-free guidance (on by default; ace355_dit_set_dedup(h, 0) or ACE355_DEDUP0=0 in the environment switch it off).  The
  * reference feeds the decoder x = cat([xt, xt]) with the same context latents and timestep for both copies (base.py:1905-1911, 1929): up to
  * the first cross-attention (base.py:499-511 of layer 0) the conditional and the null copy of a song are the same numbers.
  * ace355_dit_sample therefore runs layer 0's first norm, QKV projection and self-attention on the conditional half only and lets the
- * o_proj GEMM read that half's attention output for both halves.  dedup_count: forwards that took the shortcut so far. */
+ * o_proj GEMM read that half's attention output for both halves.  dedup_count: forwards that took the shortcut so far - counted when a
+ * forward is ENQUEUED: replays of a captured sampler graph (ace355_dit_set_graph) run the shortcut without advancing it. */
 int ace355_dit_set_dedup(ace355_dit* h, int enable);
 int ace355_dit_dedup_count(ace355_dit* h, int64_t* forwards);
 

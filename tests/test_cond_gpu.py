@@ -106,8 +106,17 @@ def test_condition_encoder_full_size_vs_oracle(gpu_device):
     h, m = enc(text, tmask, lyric, lmask, refer, order)
     assert torch.equal(m.cpu(), ref_m)
     r = _rel(h.cpu(), ref_h)
-    print(f"condition encoder full size: rel L2 vs fp32 oracle {r:.3e}")
-    assert r < 3e-2, r   # measured 1.2e-2: 12 bf16 layers with PLAIN residuals (the DiT's gated ones accumulate less)
+    # Reproducibility (this value wandered between 1.29e-2 and 1.59e-2 for five evidence runs under a 3e-2 gate, the output
+    # changed from call to call; cause and fix: DESIGN.md section 14): four more calls must return the SAME bits, and the bits are the ones
+    # recorded here when the fault was fixed (sha256 of the fp32 output; a deliberate change of the encoder's arithmetic updates it).
+    import hashlib
+    sha = hashlib.sha256(h.cpu().numpy().tobytes()).hexdigest()[:16]
+    for _ in range(4):
+        h2, _m = enc(text, tmask, lyric, lmask, refer, order)
+        assert torch.equal(h, h2), f"the same request twice: {_rel(h2.cpu(), h.cpu()):.3e} apart"
+    print(f"condition encoder full size: rel L2 vs fp32 oracle {r:.3e}, output sha {sha}, 5 calls bit-identical")
+    assert r < 2e-2, r   # measured 1.166e-2 (rounds 2-5 before the fault, and again since): 12 bf16 layers with PLAIN residuals
+    assert sha == "d8528bec82a8c1a6", sha
     # and its output drives the DiT's condition slot unchanged
     assert h.dtype == torch.float32 and h.is_contiguous() and h.shape == (B, Ll + 2 + Lt, cfg.hidden_size)
 

@@ -125,43 +125,6 @@ def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
     assert torch.equal(folded, again) and not torch.equal(folded, plain)
 
 
-def test_tiny_sampler_with_cfg_fork_forced(gpu_device, golden_dir):
-    """The CFG fork on the small launches (forced with set_cfg_fork(2): 4-wave tiles, ordered split-K is off for forked halves only
-    when they are big, so here both streams run the small-M kernels) against the single-stream order and the reference's golden."""
-    from ace355 import weightgen
-    from ace355.dit import generate_latents
-    G = np.load(f"{golden_dir}/g3_tiny_sampler.npz")
-    name = "cfg7_shift1"
-    cfg, w, dit = _make(TINY, int(G["seed"]), gpu_device)
-    null = weightgen.make_null_condition_emb(cfg.hidden_size, seed=int(G["seed"]))
-    enc = torch.from_numpy(G[f"{name}_enc"])
-    ctx = torch.from_numpy(G[f"{name}_ctx"])
-    B = ctx.shape[0]
-    lo, hi = G[f"{name}_interval"].tolist()
-    kw = dict(seed=G[f"{name}_seeds"].tolist(), infer_steps=int(G[f"{name}_steps"]), diffusion_guidance_sale=float(G[f"{name}_guidance"]),
-              cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=G[f"{name}_timesteps"].tolist() or None)
-    ref = torch.from_numpy(G[f"{name}_out"])
-    res = {}
-    dit.set_dual(False)   # (the per-layer fork lives in single-chain calls)
-    for fold in (0, 2):
-        dit.set_norm_fold(fold)
-        dit.set_cfg_fork(0)
-        single = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
-        dit.set_cfg_fork(2)
-        n0 = dit.cfg_fork_count()
-        forked = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
-        if dit.cfg_fork_count() == n0:   # (no side stream on a hardware queue of its own in this process: the fork stays off by design)
-            assert torch.equal(forked, single)
-            pytest.skip("no side stream on a hardware queue of its own in this process: the CFG fork was (correctly) not taken")
-        res[fold] = (_rel(forked, ref), _rel(forked, single))
-    # (bit-identity holds where the forked and the whole-batch launches take the same K split - the big tiles never split K, asserted at
-    #  the metric shape in test_metric_shapes_gpu.py; here the residual GEMMs of the halves may split K differently from the whole batch:
-    #  another summation order, bf16-noise apart)
-    print(f"tiny sampler, cfg fork forced: vs reference {res[0][0]:.3e} (norm kernels) / {res[2][0]:.3e} (folded); forked vs single stream "
-          f"{res[0][1]:.3e} / {res[2][1]:.3e}")
-    assert res[0][0] < 5e-3 and res[2][0] < 5e-3 and res[0][1] < 2e-3 and res[2][1] < 2e-3, res
-
-
 def test_tiny_sampler_layer0_dedup_on_off(gpu_device, golden_dir):
     """Layer-0 de-duplication under CFG (ace355_dit_set_dedup): the conditional and the null copy of a song are the same numbers up to the
     first cross-attention (x = cat([xt, xt]), base.py:1929), so layer 0's first norm, QKV projection and self-attention run on one half

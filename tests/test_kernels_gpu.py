@@ -419,3 +419,51 @@ def test_gemm_tile_forms_give_the_same_bits(gpu_device, tmp_path):
     for flag in ("2", "3"):
         for a, b in zip(res["0"], res[flag]):
             assert torch.equal(a, b), f"ACE355_GEMM_BIG={flag} differs from the 4-wave tiles: max abs {float((a - b).abs().max()):.3e}"
+
+
+@pytest.mark.parametrize("kind,M,N,K,reps", [
+    # the 4-wave two-stage kernels with two workgroups per CU (more tiles than CUs, too few for the 8-wave forms): the regime whose launches were not
+    # reproducible until round 6 (MFMA destination overlapping srcB; consecutive MFMAs sharing srcA beside a co-resident bf16 epilogue)
+    ("swiglu", 400, 12288, 2048, 16), ("swiglu", 288, 12288, 2048, 16), ("store_bf16", 520, 8192, 2048, 16), ("headnorm", 520, 8192, 2048, 16),
+    ("store_f32", 520, 8192, 2048, 8), ("residual", 520, 8192, 2048, 8),
+    # deep-pipeline 4-wave kernels (one workgroup per CU), 64-row tiles, ordered split-K
+    ("swiglu", 48, 12288, 2048, 8), ("headnorm", 400, 4096, 2048, 8), ("residual", 400, 2048, 6144, 8), ("residual", 375, 2048, 2048, 8),
+    # the 8-wave pair loops at the metric batch (persistent 192x256, one-round 192x256, 192x128)
+    ("swiglu", 6000, 12288, 2048, 4), ("headnorm", 6000, 4096, 2048, 4), ("residual", 6000, 2048, 6144, 4), ("store_bf16", 400, 12288, 2048, 8),
+])
+def test_gemm_launches_are_bit_reproducible(lib, gpu_device, kind, M, N, K, reps):
+    """Every epilogue mode in every tile regime of launch_gemm, `reps` launches on the same operands: ONE result (the
+    condition encoder's gate|up launch returned different bits on every call and nothing in the suite launched that instantiation with a long K loop),
+    and the result is the right one (fp32 torch)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    W = _bf(torch.randn(N, K, generator=g) * 0.05).to(gpu_device)
+    wq = torch.ones(128, device=gpu_device)
+    outs = []
+    for _ in range(reps):
+        if kind == "store_f32":
+            out = torch.empty(M, N, device=gpu_device)
+            _chk(lib.ace355_gemm_bf16(_p(A), _p(W), _p(out), M, N, K, 0, None, None))
+        elif kind == "store_bf16":
+            out = torch.empty(M, N, device=gpu_device, dtype=torch.bfloat16)
+            _chk(lib.ace355_gemm_bf16(_p(A), _p(W), _p(out), M, N, K, 1, None, None))
+        elif kind == "swiglu":
+            out = torch.empty(M, N // 2, device=gpu_device, dtype=torch.bfloat16)
+            _chk(lib.ace355_gemm_bf16_fused(_p(A), _p(W), _p(out), M, N, K, 1, None, None, 0, 0, None))
+        elif kind == "residual":
+            out = torch.ones(M, N, device=gpu_device)
+            _chk(lib.ace355_gemm_bf16_residual(_p(A), _p(W), _p(out), M, N, K, None, None, 0, M, None, 0, None))
+        else:
+            out = torch.empty(M, N, device=gpu_device, dtype=torch.bfloat16)
+            _chk(lib.ace355_gemm_bf16_headnorm(_p(A), _p(W), _p(out), M, N, K, N // 2, N // 4 * 3, _p(wq), _p(wq), 1e-6, 1, M, 1e6, None))
+        outs.append(out)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), f"{kind} M={M} N={N} K={K}: launches differ by {_rel(o, outs[0]):.3e}"
+    if kind in ("store_f32", "store_bf16"):
+        assert _rel(outs[0], A.float() @ W.float().t()) < (2e-5 if kind == "store_f32" else 4e-3)
+    elif kind == "residual":
+        assert _rel(outs[0] - 1.0, A.float() @ W.float().t()) < 2e-5
+    elif kind == "swiglu":
+        Wv = W.view(N // 64, 2, 32, K)
+        ref = F.silu(A.float() @ Wv[:, 0].reshape(N // 2, K).float().t()) * (A.float() @ Wv[:, 1].reshape(N // 2, K).float().t())
+        assert _rel(outs[0], ref) < 4e-3

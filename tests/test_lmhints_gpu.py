@@ -53,6 +53,7 @@ def test_detokenizer_full_size_vs_oracle_and_code_path(gpu_device):
     r = _rel(y.cpu(), ref)
     print(f"detokenizer (full size) vs fp32 oracle: rel L2 {r:.3e}")
     assert r < 1.5e-2, r   # measured 5.6e-3
+    assert torch.equal(y, decode_audio_codes_to_latents(s, det, pw.to(gpu_device), pb.to(gpu_device))), "the same codes twice: not bit-identical"
     assert decode_audio_codes_to_latents("no codes here", det, pw, pb) is None
     with pytest.raises(ValueError):
         det(torch.zeros(1, 4, cfg.hidden_size), attention_mask=torch.ones(1, 4))
@@ -107,6 +108,7 @@ def test_audio_tokenizer_full_size_round_trip_through_the_detokenizer(gpu_device
     ref_pool = o_detok.tokenizer_pool(o_cfg, wt, x.reshape(2, 50, 5, 64))
     rp = _rel(pooled.cpu(), ref_pool)
     quant, idx = tok.tokenize(x)
+    assert torch.equal(pooled, tok.pool(x)), "the same frames twice: not bit-identical"
     assert quant.shape == (2, 50, cfg.hidden_size) and idx.shape == (2, 50, 1) and int(idx.min()) >= 0 and int(idx.max()) < 64000
     # the two FSQ restatements agree with each other: decoding the indices gives the quantised output back
     back = fsq_output_from_indices(idx, q["quantizer.project_out.weight"].to(gpu_device), q["quantizer.project_out.bias"].to(gpu_device))
@@ -116,7 +118,7 @@ def test_audio_tokenizer_full_size_round_trip_through_the_detokenizer(gpu_device
                                     q["quantizer.project_in.bias"], q["quantizer.project_out.weight"], q["quantizer.project_out.bias"])
     agree = float((oidx == idx.cpu()).float().mean())
     hints = det(quant)
-    assert hints.shape == (2, 250, 64) and bool(torch.isfinite(hints).all())
+    assert hints.shape == (2, 250, 64) and bool(torch.isfinite(hints).all()) and torch.equal(hints, det(quant))
     print(f"audio tokenizer (full size): pooled rel L2 vs fp32 oracle {rp:.3e}; {100 * agree:.0f} % of the 100 tokens get the oracle's code index")
     assert rp < 2.5e-2, rp        # measured 1.07e-2 (two plain-residual layers + one more bf16 operand than the detokenizer)
     assert agree > 0.7, agree     # measured 0.93

@@ -58,6 +58,10 @@ def test_metric_shape_forward_vs_reference_golden(gpu_device, golden_dir, full_d
         t = [float(G["t"])] * N
         v = dit.forward(x, ctx, t, t, [0] * B + [1] * B)
         torch.cuda.synchronize()
+        tap23 = taps[23].clone()
+        v_again = dit.forward(x, ctx, t, t, [0] * B + [1] * B)
+        torch.cuda.synchronize()
+        assert torch.equal(v, v_again) and torch.equal(tap23, taps[23]), "the same forward twice: not bit-identical"
     finally:
         for li in taps:
             dit.set_tap(li, None)
@@ -92,6 +96,45 @@ def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_d
     per = [_rel(out[i], ref[i]) for i in range(B)]
     print(f"metric-batch sampler (B=8, 3 steps, CFG 7 + APG): rel L2 vs reference fp32 = {r:.3e}; per item max {max(per):.3e}")
     assert r < 1e-2 and max(per) < 1.2e-2, (r, per)  # measured 4.0e-3 / 4.0e-3
+
+
+def test_a_song_does_not_depend_on_its_batch_in_the_shape_independent_mode(gpu_device, golden_dir, full_dit_seed4):
+    """VERDICT r5 weak 3 / ADVICE r4: "1 GPU vs 8 GPUs gives the same song".  G12's request (8 songs x 30 s, CFG 7 + APG, 3 steps) as ONE call,
+    as calls of 4 + 4, 2 + ... and of single songs - the 1 / 2 / 4 / 8-GPU shares of the metric batch - in the library's
+    launch-shape-independent mode (`ace355_gemm_set_k_rotation(0)`: no K rotation, no split-K, no split-KV / key-split attention; one sampler
+    chain), which the data-parallel handler path selects by default: every song must come out bit for bit the same whatever call it was part of,
+    and still match the reference.  With the default (fastest) policy the same comparison gives ~3e-3 - printed for the record."""
+    from ace355 import native
+    from ace355.dit import generate_latents
+    G = np.load(f"{golden_dir}/g12_metric_sampler.npz")
+    dit, cfg, null, wsum = full_dit_seed4
+    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
+    B, T = 8, 750
+    _, ctx1 = _inputs(B, T)
+    seeds = G["seeds"].tolist()
+    ref = torch.from_numpy(G["out"])
+
+    def run(items):
+        n = len(items)
+        return generate_latents(dit, null, enc.expand(n, -1, -1), ctx1.expand(n, -1, -1).contiguous(), seed=[seeds[i] for i in items],
+                                infer_steps=int(G["steps"]), diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
+
+    fast8, fast1 = run(range(8)), run([5])
+    krot = native.gemm_set_k_rotation(0)
+    dual = dit.set_dual(0)
+    try:
+        all8 = run(range(8))
+        halves = torch.cat([run(range(0, 4)), run(range(4, 8))])
+        pairs = torch.cat([run([0, 1]), run([2, 3]), run([4, 5]), run([6, 7])])
+        singles = torch.cat([run([i]) for i in (0, 5, 7)])
+    finally:
+        native.gemm_set_k_rotation(krot)
+        dit.set_dual(dual)
+    r = _rel(all8, ref)
+    print(f"shape-independent mode (B=8, 3 steps): vs reference fp32 {r:.3e}; 8 == 4+4: {torch.equal(all8, halves)}, == 2+2+2+2: {torch.equal(all8, pairs)}, "
+          f"songs 0 / 5 / 7 alone == inside the batch: {torch.equal(singles, all8[[0, 5, 7]])}; default policy: song 5 alone vs in the batch {_rel(fast1, fast8[5:6]):.3e}")
+    assert r < 1e-2, r
+    assert torch.equal(all8, halves) and torch.equal(all8, pairs) and torch.equal(singles, all8[[0, 5, 7]])
 
 
 def test_metric_batch_sampler_norm_fold_on_off(gpu_device, golden_dir, full_dit_seed4):
@@ -140,7 +183,6 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
         return generate_latents(dit, null, enc.expand(b, -1, -1), ctx1.expand(b, -1, -1).contiguous(), seed=[seeds[i] for i in items],
                                 infer_steps=steps, diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
     try:
-        dit.set_cfg_fork(0)   # (the one-chain comparison calls must not fork per layer: chains never do)
         dit.set_dual(1)
         n0 = dit.dual_count()
         d2 = run(range(2))
@@ -179,58 +221,6 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
           f"two chains == one-chain calls on the half-batches: {torch.equal(dual, halves)} (B=8), {torch.equal(d5, s5)} (B=5), {torch.equal(d2, s2)} (B=2)")
     assert torch.equal(dual, halves) and torch.equal(d5, s5) and torch.equal(d2, s2)
     assert r_d < 1e-2 and r_s < 1e-2 and r_ds < 6e-3, (r_d, r_s, r_ds)
-
-
-def test_cfg_fork_is_bit_identical_to_the_single_stream_order(gpu_device, golden_dir, full_dit_seed4):
-    """CFG fork (include/ace355.h ace355_dit_set_cfg_fork; base.py:515-539, 1905-1911; OFF by default - measured slower, DESIGN.md
-    section 10 - and kept as a switch): the null rows' MLP on a side stream beside the conditional rows' cross-attention chain.  The metric batch (G12: 8 songs x 30 s, CFG 7 + APG, 3 steps) with the fork on and off,
-    folded norms and norms as kernels, eager and as a replayed graph: every output must be bit-identical to the single-stream order,
-    the fork must really have been taken (24 layers x 3 steps), and the result still matches the reference golden."""
-    from ace355.dit import generate_latents
-    G = np.load(f"{golden_dir}/g12_metric_sampler.npz")
-    dit, cfg, null, wsum = full_dit_seed4
-    enc = torch.from_numpy(np.load(f"{golden_dir}/g4_full_forward.npz")["enc"])
-    B, T = 8, 750
-    _, ctx1 = _inputs(B, T)
-    ref = torch.from_numpy(G["out"])
-    steps = int(G["steps"])
-
-    def run():
-        return generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), seed=G["seeds"].tolist(),
-                                infer_steps=steps, diffusion_guidance_sale=float(G["guidance"]))["target_latents"].cpu()
-    from ace355 import native
-    krot = native.gemm_set_k_rotation(0)   # (the two half-batch launches of the fork tile the rows differently: bit-identity needs ONE K order)
-    try:
-        dit.set_dual(False)   # (the per-layer fork lives in single-chain calls: the side stream is chain 2's otherwise)
-        for fold in (True, False):
-            dit.set_norm_fold(fold)
-            dit.set_cfg_fork(0)
-            n0 = dit.cfg_fork_count()
-            single = run()
-            assert dit.cfg_fork_count() == n0
-            dit.set_cfg_fork(1)
-            forked = run()
-            if dit.cfg_fork_count() == n0:   # (no side stream on a hardware queue of its own in this process: the fork stays off by design)
-                assert torch.equal(single, forked)
-                pytest.skip("no side stream on a hardware queue of its own in this process: the CFG fork was (correctly) not taken")
-            assert dit.cfg_fork_count() == n0 + cfg.num_hidden_layers * steps, (dit.cfg_fork_count(), n0)
-            assert torch.equal(single, forked), f"fold={fold}: fork changed the result by {_rel(forked, single):.3e}"
-            dit.set_graph(True)
-            try:
-                g1 = run()   # capture (the side stream joins the capture through the fork event)
-                g2 = run()   # replay
-                assert dit.graph_stats()["replays"] >= 1
-            finally:
-                dit.set_graph(False)
-            assert torch.equal(single, g1) and torch.equal(single, g2), f"fold={fold}: graph replay of the forked sequence differs"
-            r = _rel(forked, ref)
-            print(f"cfg fork, fold={fold}: forked == single-stream bit for bit (eager and graph); vs reference fp32 {r:.3e}")
-            assert r < 1e-2, r
-    finally:
-        native.gemm_set_k_rotation(krot)
-        dit.set_norm_fold(True)
-        dit.set_cfg_fork(0)
-        dit.set_dual(1)
 
 
 def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -333,6 +323,7 @@ def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, fu
         torch.cuda.synchronize()
     finally:
         dit.set_tap(23, None)
+    assert torch.equal(v2, dit.forward(torch.cat([x1, x1]), ctx1.expand(2, -1, -1).contiguous(), [t, t], [t, t], [0, 1])), "not bit-reproducible"
     r2 = _rel(v2, ref)
     r23 = _rel(tap.view(2, S, -1)[:, ::100], torch.from_numpy(G["l23_out"]))
     # batch of 16: item 3 (cond) and item 11 (null) carry the golden pair, the rest other seeds
@@ -378,6 +369,7 @@ def test_240s_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4
     dit.set_condition(1, null.reshape(1, -1), L=enc.shape[1])
     t = float(G["t"])
     v = dit.forward(torch.cat([x1, x1]), ctx1.expand(2, -1, -1).contiguous(), [t, t], [t, t], [0, 1])
+    assert torch.equal(v, dit.forward(torch.cat([x1, x1]), ctx1.expand(2, -1, -1).contiguous(), [t, t], [t, t], [0, 1])), "not bit-reproducible"
     r = _rel(v, torch.from_numpy(G["v"]))
     print(f"240 s forward (N=2, T=6000): rel L2 vs reference fp32 = {r:.3e}")
     assert torch.isfinite(v).all() and r < 1.5e-2, r

@@ -70,6 +70,11 @@ def test_decode_at_the_metric_length_vs_oracle(gpu_device):
     z = torch.randn(1, 64, T, generator=torch.Generator().manual_seed(750))
     wav = vae.decode(z)
     assert wav.shape == (1, cfg.audio_channels, cfg.hop * T) and torch.isfinite(wav).all()
+    assert torch.equal(wav, vae.decode(z)), "the same latents twice: not bit-identical"
+    # ... and inside the batch the bench decodes (B = 8, this item in slot 5): the same waveform bit for bit
+    z8 = torch.randn(8, 64, T, generator=torch.Generator().manual_seed(751))
+    z8[5] = z[0]
+    assert torch.equal(vae.decode(z8)[5], wav[0]), "an item's waveform depends on the batch it is decoded in"
     o_cfg = o_vae.VaeConfig()
     ref = o_vae.decode(o_cfg, w, z)
     emu = o_vae.decode(o_cfg, w, z, emulate_bf16=True)

@@ -221,17 +221,19 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
             constexpr int HW = 4 / NTW;  // waves per 128-column head: a pair (64 columns each) or all four N-waves of a 128-wide tile
             if (hn) {
                 hw = vec ? reinterpret_cast<const float*>(vec + 3072) : ((nw0 < ep.hn_q_cols) ? ep.hn_wq : ep.hn_wk);
-                float ss[MT][RPB];
+                // One partial per 32-COLUMN BLOCK of the head (4 of them), summed in block order: the sum of a row's 128 squares then has ONE fp32 order whatever
+                // the tile form (a pair of 64-column waves or four 32-column waves used to group it differently, and with it the last bit of rstd - the one
+                // place where the cross-attention q projection of a single song (64-row tiles) and of a batch (192 x 128 tiles) disagreed; round 6)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int j = 0; j < NTW; ++j) {
+                    float ss[MT][RPB];
 #pragma unroll
-                    for (int rr = 0; rr < RPB; ++rr) ss[i][rr] = 0.f;
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NTW; ++j)
+                        for (int rr = 0; rr < RPB; ++rr) ss[i][rr] = 0.f;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const float4 bq = fold_bias(j, g);
-                        constexpr int dummy = 0; (void)dummy;
 #pragma unroll
                         for (int i = 0; i < MT; ++i) {
                             const float rs = rs_in[i][q_rr<L16>(g)];
@@ -241,14 +243,15 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
                         }
                     }
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int rr = 0; rr < RPB; ++rr) {
-                        // the lanes that hold the other columns of this row: l ^ 32 (32x32 layout), l ^ 16 and l ^ 32 (16x16 layout)
-                        if constexpr (L16) ss[i][rr] += __shfl_xor(ss[i][rr], 16, 64);
-                        ss[i][rr] += __shfl_xor(ss[i][rr], 32, 64);
-                        if (lane < (L16 ? 16 : 32)) xw[wave * (MT * 32) + i * 32 + rr * 16 + lrow] = ss[i][rr];
-                    }
+                        for (int rr = 0; rr < RPB; ++rr) {
+                            // the lanes that hold the other columns of this row: l ^ 32 (32x32 layout), l ^ 16 and l ^ 32 (16x16 layout)
+                            if constexpr (L16) ss[i][rr] += __shfl_xor(ss[i][rr], 16, 64);
+                            ss[i][rr] += __shfl_xor(ss[i][rr], 32, 64);
+                            if (lane < (L16 ? 16 : 32)) xw[(wave * NTW + j) * (MT * 32) + i * 32 + rr * 16 + lrow] = ss[i][rr];
+                        }
+                }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -257,7 +260,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
                     for (int rr = 0; rr < RPB; ++rr) {
                         float tot = 0.f;
 #pragma unroll
-                        for (int k = 0; k < HW; ++k) tot += xw[((wave & ~(HW - 1)) + k) * (MT * 32) + i * 32 + rr * 16 + lrow];
+                        for (int k = 0; k < 4; ++k) tot += xw[((wave & ~(HW - 1)) * NTW + k) * (MT * 32) + i * 32 + rr * 16 + lrow];
                         rstd[i][rr] = rsqrtf(tot * (1.f / 128.f) + ep.hn_eps);
                     }
                 if (eprobe) g_clk_probe[9] = clock64() - ep0;    // row scales + head sums of squares exchanged
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     constexpr int AJ = BMv / (8 * NW);          // A DMA pieces per wave per tile (8 rows each)
     constexpr int WJ = BNv / (8 * NW);          // W DMA pieces per wave per tile
     static_assert(BMv % (8 * NW) == 0 && BNv % (8 * NW) == 0, "tile rows must split evenly over the waves");
-    constexpr int EPI_BYTES = NW * MT * 32 * 128 + NW * MT * 32 * 4;  // epilogue staging: MT*32 rows x 128 B per wave (+ mode 4's row sums)
+    constexpr int EPI_BYTES = NW * MT * 32 * 128 + NW * NTW * MT * 32 * 4;  // epilogue staging: MT*32 rows x 128 B per wave (+ mode 4's row sums per 32-column block)
     // Vector area (8-wave bf16 kernels whose epilogue consumes a folded norm; one workgroup per CU, so the 4 KB are free): see gemm_epilogue_wide
     constexpr bool VEC = !FP8 && WNW == 4 && (MODE == 0 || MODE == 3 || MODE == 4);
     constexpr int VOFF = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;

@@ -196,10 +196,12 @@ class NativeDit:
         with torch.cuda.device(self.device):
             native.check(self._lib.ace355_dit_set_precision(self._h, code), "dit_set_precision")
 
-    def set_norm_fold(self, enable) -> None:
-        """RMSNorms folded into the neighbouring GEMM epilogues in big-M sampler calls (default on; include/ace355.h).
-        False / 0: off; True / 1: default (calls with >= 1536 token rows); 2: every call the kernels support."""
+    def set_norm_fold(self, enable) -> int:
+        """RMSNorms folded into the neighbouring GEMM epilogues of sampler calls (default on; include/ace355.h).
+        False / 0: off; True / 1: default (calls with >= 64 token rows); 2: every call the kernels support.  Returns the previous mode."""
         native.check(self._lib.ace355_dit_set_norm_fold(self._h, int(enable)), "dit_set_norm_fold")
+        prev, self._fold_mode = getattr(self, "_fold_mode", int(os.environ.get("ACE355_NORM_FOLD", "1"))), int(enable)
+        return prev
 
     def set_dual(self, mode) -> int:
         """Dual-chain sampler (include/ace355.h ace355_dit_set_dual): requests of >= 2 songs as two half-batch samplers on two hardware

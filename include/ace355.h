@@ -168,12 +168,14 @@ int ace355_dit_set_precision(ace355_dit* h, int precision);
 int ace355_dit_set_graph(ace355_dit* h, int enable);
 int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
 
-/* RMSNorm folding (on by default; ACE355_NORM_FOLD=0 in the environment or enable = 0 here turns it off): in ace355_dit_sample calls
- * whose launches take the big GEMM tiles (>= 1536 token rows, bf16 precision) the three RMSNorms of a decoder layer (base.py:493-533)
- * are not kernels of their own: the residual GEMM that finishes hidden_states also writes bf16(h * g) and the rows' sums of squares,
- * the consuming projection applies rsqrt(mean(h^2) + eps) and the modulation shift's projection (shift W^T, precomputed per step of
- * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently.
- * enable: 0 off, 1 default (calls with >= 1536 token rows: below that the norm launches are cheaper), 2 every call (tests). */
+/* RMSNorm folding (on by default; ACE355_NORM_FOLD=0 in the environment or enable = 0 here turns it off): in bf16 ace355_dit_sample calls
+ * of >= 64 token rows (ACE355_NORM_FOLD_MIN_ROWS; since round 3 it pays at every real size) the three RMSNorms of a decoder layer
+ * (base.py:493-533) are not kernels of their own: the residual GEMM that finishes hidden_states also writes bf16(h * g) and the rows' sums of
+ * squares, the consuming projection applies rsqrt(mean(h^2) + eps) and the modulation shift's projection (shift W^T, precomputed per step of
+ * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently - and a row's sum of
+ * squares is gathered per GEMM tile in fp32 before it becomes an integer, so its last bit follows the tile width: the one launch-shape-dependent
+ * rounding ace355_gemm_set_k_rotation(0) does not remove (NativeHandler.shape_independent() therefore runs the norms as kernels).
+ * enable: 0 off, 1 default, 2 every call the kernels support whatever its size (tests). */
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 
 /* Dual-chain sampler.  The songs of a request are independent through the whole sampling loop of generate_audio (per-item noise,

@@ -161,15 +161,12 @@ int ace355_latent_check(const float* lat_dev, int64_t numel, int32_t* flags_host
 // (one array per process, allocated on first use: launches through the hooks are serial).
 static int hook_counters(GemmEpilogue& ep) {
     static int* cnt = nullptr;
-    static float* slab = nullptr;
     if (!cnt) {
         ACE_HIP(hipMalloc((void**)&cnt, SK_CNT_INTS * sizeof(int)));
         ACE_HIP(hipMemset(cnt, 0, SK_CNT_INTS * sizeof(int)));
-        if (gemm_slab_wanted()) ACE_HIP(hipMalloc((void**)&slab, SK_SLAB_FLOATS * sizeof(float)));
         if (int rc = gemm_verify_splitk_placement()) return rc;
     }
     ep.sk_cnt = cnt;
-    ep.sk_slab = slab; ep.sk_slab_cap = SK_SLAB_FLOATS;
     return 0;
 }
 

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
     }
     auto issue_piece = [&](int kt, int i) {  // this wave's i-th DMA instruction of tile kt
         const int key0 = kt * KB;
-        const unsigned bb = lds0 + (unsigned)(kt & 1) * BUF;
+        const unsigned bb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(kt & 1) * BUF));   // (uniform: the tile range comes from a load)
         const bf16_t* kb_s = kbase + (long)key0 * a.k_row_stride;  // uniform
         const bf16_t* vb_s = vbase + key0;
         const bool tail = key0 + KB > a.Skv;
@@ -472,28 +472,23 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
     const bool probe = a.clk_probe && blockIdx.x == 0 && tid == 0;
     unsigned long long pc0 = 0, pw0 = 0, pbar = 0;
     if (probe) { pc0 = clock64(); pw0 = wall_clock64(); }
-    // ACE355_ATTN_CLK bits 1..3 (diagnostic ablations, results are WRONG): 2 = softmax arithmetic off (P = S), 4 = no barrier /
-    // DMA after the first tile, 8 = K / Q / V^T fragments read once and reused
-    const bool ab_nosm = (a.clk_probe & 2) != 0, ab_nosync = (a.clk_probe & 4) != 0;
 
     for (int kt = kt_lo; kt < kt_hi; ++kt) {
         const int key0 = kt * KB;
         unsigned long long pb0 = 0;
         if (probe) pb0 = clock64();
-        if (!ab_nosync || kt == kt_lo) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (and, first time, its Q rows)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                      // tile kt complete in LDS; every wave is done with tile kt-1
         __builtin_amdgcn_sched_barrier(0);
         if (probe) pbar += clock64() - pb0;
-        }
         // The next tile's DMA is NOT issued here: an LDS-DMA instruction takes 60-185 cycles to issue, and with every wave doing
         // it right behind the barrier the matrix pipe sat idle (ablation: 6.4 k -> 4.0 k cycles per tile without barrier + DMA).
         // The pieces ride between the Q K^T batches below (safe any time after the barrier: the target stage was last read in
         // tile kt-1); waves that skip this tile issue theirs at once.
-        const bool prefetch = (kt + 1 < kt_hi) && !ab_nosync;
+        const bool prefetch = kt + 1 < kt_hi;
 
-        const char* Ks = smem + (ab_nosync ? (kt_lo & 1) : (kt & 1)) * BUF;
+        const char* Ks = smem + (kt & 1) * BUF;
         const char* Vs = Ks + 16384;
         const bool in_band = (key0 - (qw0 + 31) <= win) && (qw0 - (key0 + KB - 1) <= win);
         if (!wave_live || !in_band) {
@@ -561,10 +556,6 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
                     s[t2][r] = ok ? s[t2][r] : -INFINITY;
                 }
         }
-        if (ab_nosm) {  // ablation: no max / exp / sum
-            l_run = 1.f;
-            m_run = 0.f;
-        } else {
         float mx = s[0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
@@ -592,7 +583,6 @@ __global__ __launch_bounds__(NWH * 128, (2 * NWH + 3) / 4) void attn_gqa_kernel(
             for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
         }
         // ---- O^T += V^T P^T: keys 0..31 with the fragments already here, the second half's reads issued under those MFMAs
 #pragma unroll

@@ -136,13 +136,7 @@ struct GemmEpilogue {
     // time); part y of a tile waits until parts 0 .. y-1 have added their share to H, then does the plain read-modify-write itself, so
     // the sum has one order and the result is bit-reproducible.  sk_ord is set by launch_gemm.  NULL: the atomics path.
     int* sk_cnt; int sk_ord;
-    // slab split-K (every mode, small-M launches; round 3): the K range is cut into `kparts` parts over blockIdx.y; parts 0 .. kparts-2
-    // park their raw fp32 accumulators in `sk_slab` (per-lane layout, 16-byte coalesced; the parts of a tile run on one XCD, so the slab
-    // lives in that XCD's L2) and bump the tile's counter in sk_cnt; the LAST part (dispatched last, so everybody it waits for is resident)
-    // adds them to its own accumulators in part order - one summation order, bit-reproducible - and runs the normal epilogue ONCE
-    // (ksplit stays 1: no atomics, no serialised read-modify-writes of H).  kparts / sk_slab are set by launch_gemm; the caller lends
-    // sk_slab_cap floats.
-    float* sk_slab; long sk_slab_cap; int kparts;
+    int kparts;   // set by launch_gemm: K parts over blockIdx.y (= ksplit; > 1 only for the ordered / atomic split-K of mode 2)
     // mode 4, v tiles (columns >= hn_qk_cols): written TRANSPOSED straight from the accumulators, vt[seq][head][d][s] (row pitch vt_ld,
     // s = row % rows_per_seq), instead of as rows of C - the separate transpose_v launch of a small-M forward disappears (2-byte stores,
     // 32 consecutive key positions per half wave: fine for the few tiles of a small-M launch, too slow for the big tiles, so launch_gemm
@@ -182,13 +176,11 @@ int launch_fp8_weight_roundtrip(bf16_t* w, long ld, int N, int K, hipStream_t s)
 inline int mx_rows_pad(int rows) { return ((rows + 255) / 256) * 256 + 256; }
 
 constexpr int SK_MAX_TILES = 4096;
-constexpr long SK_SLAB_FLOATS = 8L << 20;   // slab a handle lends for the slab split-K: 32 MB = 341 parked 192x128 accumulator tiles
 constexpr int SK_CNT_INTS = SK_MAX_TILES + 8;   // size of a turn-counter array: the tiles' counters + [SK_MAX_TILES] = missed-turn count
 // A part that waited ~1 s for its turn (a counter left behind by a faulted launch, or a placement the one-time probe did not see)
 // goes ahead so the device cannot hang, but counts the event in sk_cnt[SK_MAX_TILES]: gemm_splitk_poll reads it (stream sync), and on a
 // non-zero count re-zeroes the counters and reports an error - the residual stream of that call is not trustworthy.
 int gemm_splitk_poll(int* sk_cnt, hipStream_t s);
-bool gemm_slab_wanted();   // ACE355_GEMM_SLAB != 0: the handles allocate the 32 MB slab only then (the path is off by default; advisor r3)
 
 struct AttnArgs {
     const bf16_t* q; long q_seq_stride; int q_row_stride;           // q[n][s][h*128 + d]

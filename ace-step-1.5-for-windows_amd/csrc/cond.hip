@@ -61,7 +61,6 @@ struct EncBase {
     float *rope_cos = nullptr, *rope_sin = nullptr;
     int rope_S = 0;
     int* sk_cnt = nullptr;   // split-K counters (GemmEpilogue::sk_cnt), allocated with the rope tables
-    float* sk_slab = nullptr;   // slab split-K scratch (GemmEpilogue::sk_slab)
 };
 
 struct ace355_cond : EncBase {
@@ -169,7 +168,6 @@ int ensure_rope(EncBase* h, int S, hipStream_t s) {
     h->rope_S = cap;
     if (!h->sk_cnt) {
         ALLOC(h->allocs, h->sk_cnt, SK_CNT_INTS);
-        if (gemm_slab_wanted()) ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
         ACE_HIP(hipMemsetAsync(h->sk_cnt, 0, SK_CNT_INTS * sizeof(int), s));
         if (int prc = gemm_verify_splitk_placement()) return prc;
     }
@@ -246,7 +244,7 @@ int encoder_layers(EncBase* h, const EncoderW& E, int N, int S, const int* kv_le
         rc = launch_attention(a, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};  // h += o_proj(attn)
-        ep.sk_cnt = h->sk_cnt; ep.sk_slab = h->sk_slab; ep.sk_slab_cap = SK_SLAB_FLOATS;
+        ep.sk_cnt = h->sk_cnt;
         rc = launch_gemm(h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
         if (rc) return rc;
         // SwiGLU MLP (base.py:430-433)
@@ -256,7 +254,7 @@ int encoder_layers(EncBase* h, const EncoderW& E, int N, int S, const int* kv_le
         rc = launch_gemm(h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
         if (rc) return rc;
         ep = GemmEpilogue{2, nullptr, nullptr, nullptr, 0, S};
-        ep.sk_cnt = h->sk_cnt; ep.sk_slab = h->sk_slab; ep.sk_slab_cap = SK_SLAB_FLOATS;
+        ep.sk_cnt = h->sk_cnt;
         rc = launch_gemm(h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
         if (rc) return rc;
     }

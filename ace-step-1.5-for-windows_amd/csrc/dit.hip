@@ -164,7 +164,6 @@ struct ace355_dit {
     int cu_slots = 0;        // GemmEpilogue::cu_slots / AttnArgs::cu_slots of this context's launches (0: the whole chip)
 
     int* sk_cnt = nullptr;   // split-K counters lent to launch_gemm (GemmEpilogue::sk_cnt)
-    float* sk_slab = nullptr;   // slab split-K scratch lent to launch_gemm (GemmEpilogue::sk_slab, SK_SLAB_FLOATS)
     float* attn_part = nullptr;   // split-KV scratch lent to launch_attention (AttnArgs::part): small problems only
     long attn_part_floats = 0;
 
@@ -290,7 +289,6 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
     GemmEpilogue e2 = ep;
     const bool side = h->fk.side && s == h->fk.side;
     e2.sk_cnt = side ? h->fk.sk_cnt : h->sk_cnt;
-    e2.sk_slab = side ? nullptr : h->sk_slab; e2.sk_slab_cap = SK_SLAB_FLOATS;
     e2.cu_slots = h->cu_slots;
     // pad rows of the last row tile read the workspace's zero row (forward_core keeps row fwd_M of xn / ao / act zero)
     if (h->zr_on && h->zr_M == h->fwd_M && h->fwd_M >= M) {
@@ -1021,7 +1019,6 @@ int ace355_dit_create(const ace355_dit_config* cfg, ace355_dit** out) {
     ALLOC(h->allocs, h->sst_out, 2 * D);
     ALLOC(h->allocs, h->flags_dev, 4);
     ALLOC(h->allocs, h->sk_cnt, SK_CNT_INTS);
-    if (gemm_slab_wanted()) ALLOC(h->allocs, h->sk_slab, (size_t)SK_SLAB_FLOATS);
     ALLOC(h->allocs, h->fk.sk_cnt, SK_CNT_INTS);
     ACE_HIP(hipMemset(h->fk.sk_cnt, 0, SK_CNT_INTS * sizeof(int)));
     h->attn_part_floats = 16L << 20;   // 64 MB: 8 parts of a 2 x 16 x 375-row problem (12.7 M floats); larger problems do not split

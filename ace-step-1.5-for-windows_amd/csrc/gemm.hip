@@ -1396,55 +1396,6 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         }
         unsigned long long e0 = 0;
         if (probe) e0 = clock64();
-        if constexpr (!PERS && !FP8) {
-            if (ep.sk_slab) {   // slab split-K (workgroup-uniform): see GemmEpilogue::sk_slab
-                constexpr int NTH = NW * 64, VEC = MT * NTW * 4;   // float4 vectors per lane
-                const int tile = tm * tiles_n + tn;
-                const int nparts = ep.kparts - 1;
-                if ((int)blockIdx.y < nparts) {
-                    float4* dst = reinterpret_cast<float4*>(ep.sk_slab) + ((long)tile * nparts + blockIdx.y) * (VEC * NTH) + tid;
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                float4 v;
-                                v.x = aq<L16>(acc[i][j], q, 0); v.y = aq<L16>(acc[i][j], q, 1); v.z = aq<L16>(acc[i][j], q, 2); v.w = aq<L16>(acc[i][j], q, 3);
-                                dst[((i * NTW + j) * 4 + q) * NTH] = v;
-                            }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this part's accumulators are in L2
-                    __syncthreads();
-                    if (tid == 0) atomicAdd(ep.sk_cnt + tile, 1);
-                    if (probe && blockIdx.y == 0) g_clk_probe[8] = clock64() - e0;   // park + signal
-                    return;
-                }
-                if (tid == 0) {
-                    int spins = 0;
-                    for (; atomicAdd(ep.sk_cnt + tile, 0) != nparts && spins < (1 << 20); ++spins) __builtin_amdgcn_s_sleep(2);
-                    if (spins >= (1 << 20)) atomicAdd(ep.sk_cnt + SK_MAX_TILES, 1);   // counted: gemm_splitk_poll turns it into an error
-                }
-                __syncthreads();
-                if (probe) g_clk_probe[6] = clock64() - e0;   // wait for the other parts
-                const float4* src = reinterpret_cast<const float4*>(ep.sk_slab) + (long)tile * nparts * (VEC * NTH) + tid;
-                for (int pp = 0; pp < nparts; ++pp) {   // part order: one summation order whatever the arrival order
-                    float4 v[VEC];
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) v[e] = src[((long)pp * VEC + e) * NTH];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float4 w = v[(i * NTW + j) * 4 + q];
-                                aq_add<L16>(acc[i][j], q, 0, w.x); aq_add<L16>(acc[i][j], q, 1, w.y); aq_add<L16>(acc[i][j], q, 2, w.z); aq_add<L16>(acc[i][j], q, 3, w.w);
-                            }
-                }
-                if (tid == 0) atomicExch(ep.sk_cnt + tile, 0);   // (only this workgroup looks at the counter from here on)
-                if (probe) g_clk_probe[7] = clock64() - e0;   // ... + reduction
-            }
-        }
         if constexpr (MODE == 2 && !PERS && !FP8) {
             if (ep.sk_ord) {
                 // ordered split-K: wait until the parts before this one have added their share of this tile to H.  A part's
@@ -1539,11 +1490,6 @@ static int gemm_variant() {
 }
 bool gemm_fold_supported() { return gemm_variant() != 1; }
 static bool variant_is_v1() { return gemm_variant() == 1; }
-bool gemm_slab_wanted() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ACE355_GEMM_SLAB"); v = (e && atoi(e) != 0) ? 1 : 0; }
-    return v == 1;
-}
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -1703,38 +1649,10 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
         if (mt1_env && t128 * 2 <= cus && M > 64) mt = 1;
     }
-    // Small-M launches (batch-1 / batch-2 requests, the strong-scaling endpoint of SURVEY 8e): too few tiles to fill 256 CUs, every
-    // workgroup alone on its CU with a long serial K loop.  Slab split-K (ACE355_GEMM_SLAB=1, OFF by default): the 8-wave 192x128 tile, K
-    // cut into as many parts as it takes to put ~one workgroup on every CU; parts exchange raw accumulators through the XCD's L2 and the
-    // last one runs the epilogue (GemmEpilogue::sk_slab).  Every mode but SwiGLU (whose epilogue pairs two column tiles per wave).
-    // Measured in round 3: correct and bit-reproducible, but the exchange (park 1.2 us + wait 2-4 us + 1 us per
-    // partial) costs what the shorter K loops save - 157.4 vs 149.9 ms per batch-1 request - so it stays a switch.
+    // (Slab split-K - K cut over blockIdx.y for EVERY mode, partial accumulators parked in an XCD's L2 and reduced by the last part - was built in
+    //  round 3, measured slower than the deep pipeline it competes with (157.4 vs 149.9 ms per one-song request) and removed in round 6:
+    //  tools/r06_slab_splitk.patch)
     ep.kparts = 1;
-    float* slab = ep.sk_slab;
-    ep.sk_slab = nullptr;
-    if (variant != 1 && big == 0 && slab && ep.sk_cnt && g_splitk_ok == 1 && ep.mode != 3 && ep.wide_ok && N % 128 == 0 && k_rotation_mode() != 0) {
-        static int slab_env = -1, slab_ks = 0, slab_mink = 4, slab_maxwg = 256;
-        if (slab_env < 0) {
-            slab_env = env_int("ACE355_GEMM_SLAB", 0);          // 1: slab split-K for the small-M launches (measured slower: see above)
-            slab_ks = env_int("ACE355_GEMM_SLAB_KS", 0);        // force the part count
-            slab_mink = env_int("ACE355_GEMM_SLAB_MINK", 4);    // fewest K steps a part may own
-            slab_maxwg = env_int("ACE355_GEMM_SLAB_MAXWG", 256);
-        }
-        const long t2 = (long)((M + 191) / 192) * (N / 128);
-        const int nkk = K / BK;
-        int ks = 1;
-        while (ks < 16 && t2 * (ks * 2) <= slab_maxwg && nkk / (ks * 2) >= slab_mink) ks *= 2;
-        if (slab_ks >= 1) ks = std::min(slab_ks, nkk);
-        while (ks > 1 && (ks - 1) * ((nkk + ks - 1) / ks) >= nkk) --ks;   // every part owns at least one K step
-        const bool fits = t2 <= SK_MAX_TILES && t2 * (ks - 1) * (192L * 128) <= ep.sk_slab_cap;
-        static const int mid3 = env_int("ACE355_GEMM_MIDNS", 3) == 3;
-        const bool head_ok = ep.mode != 4 || (ep.hn_q_cols % 128 == 0 && ep.hn_qk_cols % 128 == 0 && mid3);
-        if (slab_env && ks > 1 && fits && head_ok) {
-            mt = 3; bn = 128; big = 2;
-            ep.kparts = ks;
-            ep.sk_slab = slab;
-        }
-    }
     const int tiles_n = (N + bn - 1) / bn;
     const int bm = mt * 64;
     const int tiles_m = (M + bm - 1) / bm;
@@ -1748,7 +1666,7 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ep.sk_ord = 0;
     // (K rotation mode 0 = "one summation order whatever the launch shape": no split-K either - a one-song launch then adds up a row's K range
     //  exactly as the same row inside a batch of 8 does)
-    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && !ep.sk_slab && k_rotation_mode() != 0) {
+    if (variant != 1 && ep.mode == 2 && big == 0 && g_splitk_ok == 1 && k_rotation_mode() != 0) {
         static int ks_env = -1;
         if (ks_env < 0) ks_env = env_int("ACE355_GEMM_KSPLIT", 0);
         const int nk = K / BK;
@@ -1827,8 +1745,6 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
                           (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / (double)h[2], (double)h[1] * 0.01 / (double)h[2], h[2],
                           (double)h[5], (double)h[3], (double)h[4], "");
         if (h[1] && (ep.mode == 4 || ep.mode == 0 || ep.mode == 3) && h[10]) fprintf(stderr, "[ace355 gemm clk]   epilogue phases (wave 0): sums exchanged %llu, staged %llu cycles\n", h[9], h[10]);
-        if (h[1] && ep.sk_slab) fprintf(stderr, "[ace355 gemm clk]   slab: part 0 park + signal %llu cycles; last part: wait %llu, wait + reduce %llu cycles (then the epilogue)\n",
-                                        h[8], h[6], h[7]);
     }
     return 0;
 }
@@ -1887,7 +1803,6 @@ int launch_gemm_mx(const uint8_t* Aq, const uint32_t* sa, int sa_ld, const uint8
     }
     ep.ksplit = 1;
     ep.kparts = 1;
-    ep.sk_slab = nullptr;
     ep.sk_ord = 0;
     ep.vt_out = nullptr;
     if (ep.vt_done) *ep.vt_done = 0;

@@ -15,7 +15,7 @@ SOURCES = ["gemm.hip", "attn.hip", "elementwise.hip", "conv.hip", "dit.hip", "va
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 # gemm.hip: MFMA results stay in architectural VGPRs.  Left to itself the register allocator moves the 16x16x32 accumulators of the
 # one-wave-per-SIMD kernels (3-4 LDS stages: 512 registers available) to AGPRs and then ROTATES them through v_accvgpr_read/write every
-# K step (104 moves and 31 s_nops in a 32-MFMA loop: 1435 instead of 857 cycles per K step, profiles/r04_m16_gemm_clk_inpass.txt).
+# K step (104 moves and 31 s_nops in a 32-MFMA loop: 1435 instead of 857 cycles per K step, profiles/r04/r04_m16_gemm_clk_inpass.txt).
 FILE_FLAGS = {"gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 

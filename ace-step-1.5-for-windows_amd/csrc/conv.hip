@@ -710,15 +710,15 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         // (the fused k = 1 stage of a residual unit is written for the 4-wave 128-row tile only: forcing the tall tile onto it with
         //  ACE355_CONV_TM=256 gave a - 6 dB decode, caught by test_decode_at_the_metric_length_vs_oracle; it is refused here)
         // Round 4, after the Snake move (the transposed convs stage plain rows now) and a per-launch sweep of the forced heights
-        // (profiles/r04_conv_tile_height_sweep.txt, 8 x 30 s): the k = 7 convs at C = 1024 are 3776 four-wave tiles - below the old 4096
+        // (profiles/r04/r04_conv_tile_height_sweep.txt, 8 x 30 s): the k = 7 convs at C = 1024 are 3776 four-wave tiles - below the old 4096
         // threshold - and run 1076-1097 us on them against 875-897 us on 1888 tall ones: (threshold lowered, see below); the plain-row transposed convs with Cin >= 1024 gain too (782 -> 689 and 1096 -> 1008 us), the ones with
         // Cin <= 512 lose (1128 -> 1174, 1349 -> 1510, 1660 -> 2112 us) and stay on the four-wave tile, like the k = 1 convs (+ 5-25 %).
-        // The same sweep at 4 / 2 / 1 songs (profiles/r04_conv_tile_height_sweep_small_batches.txt) shows the size threshold itself was
+        // The same sweep at 4 / 2 / 1 songs (profiles/r04/r04_conv_tile_height_sweep_small_batches.txt) shows the size threshold itself was
         // wrong for the k = 7 convs: the tall tile wins at every batch (one song: 205 -> 190, 259 -> 221, 240 -> 197 us at C = 1024 / 512 /
         // 256; two songs: 328 -> 254, 450 -> 376 us), down to the 472 four-wave tiles of one 30 s song at C = 1024: threshold 448.  The
         // plain-row transposed convs with Cin >= 1024 gain from ~ 900 four-wave tiles up (one song, 2048 -> 1024, 480 tiles: 149 -> 170 us).
         // Round 5, after version 2 of the chunk / tap loop (the 8-wave form no longer spills, its window loads are no longer serialised
-        // by scratch reloads): re-swept at 1 / 2 / 4 / 8 songs (profiles/r05_conv_tile_height_sweep.txt).  The 8-wave tile now wins on
+        // by scratch reloads): re-swept at 1 / 2 / 4 / 8 songs (profiles/r05/r05_conv_tile_height_sweep.txt).  The 8-wave tile now wins on
         // EVERY k >= 2 launch that fills the chip about one and a half times (512 tall workgroups are resident at once = 1024 four-wave
         // tiles): the transposed convs at every Cin (8 songs: 1645 -> 1388, 1256 -> 1069, 1020 -> 845 us for Cin = 128 / 256 / 512), the k = 7
         // convs from ~1400 four-wave tiles (one song: C = 256 204 -> 175 us, C = 512 224 -> 221, C = 1024 (472 tiles) 177 -> 197: stays 4-wave;

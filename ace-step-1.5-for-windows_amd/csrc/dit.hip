@@ -1266,7 +1266,7 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
     //  CU slots of the rounds a one-chain N = 2048 launch needs that hold a tile: 16 column tiles of the 192x128 mid tile up to 3072 rows, 8 of
     //  the 192x256 tile above.  Same-box ABAB, 30 s songs with decode, one chain -> two: 2 songs 198.7 -> 194.5 ms, 3: 266.1 -> 251.0, 4 (fill
     //  1.0): 290.4 -> 303.5, 5 (0.63): 397.0 -> 362.7, 6 (0.75): 430.4 -> 408.9, 7 (0.88): 461.0 -> 457.6 on one box and 451.9 -> 460.5 on
-    //  another (hence the 0.85), 8 (1.0): 486.7 -> 518.5, 9 (0.56): 657.6 -> 581.9, 10 (0.63): 681.9 -> 654.0: profiles/r04_dual_policy_quiet_ab.txt)
+    //  another (hence the 0.85), 8 (1.0): 486.7 -> 518.5, 9 (0.56): 657.6 -> 581.9, 10 (0.63): 681.9 -> 654.0: profiles/r04/r04_dual_policy_quiet_ab.txt)
     auto one_chain_fill = [](long rows) -> double {
         const long tiles = ((rows + 191) / 192) * (rows <= 3072 ? 16 : 8);
         return (double)tiles / (double)(((tiles + 255) / 256) * 256);

@@ -86,7 +86,7 @@ template <bool L16> __device__ __forceinline__ int q_rr(int q) { return L16 ? (q
 // carry the next step's fragment reads).  The ND pieces sit on every (NM / ND)-th slot instead of back to back behind the barrier: a
 // piece blocks the issuing wave for 60-180 cycles while the address unit of the CU works through all eight waves' pieces (no-DMA
 // ablation: 1985 -> 1678 cycles per K step), and spread out the two waves of a SIMD are less often blocked together: 1984 -> 1821
-// cycles per K step on the gate|up launch, 1942 -> 1771 on QKV (profiles/r04_dma_placement_sweep.txt: "pat1"); wave-group-specific
+// cycles per K step on the gate|up launch, 1942 -> 1771 on QKV (profiles/r04/r04_dma_placement_sweep.txt: "pat1"); wave-group-specific
 // placements (the second wave of each SIMD one slot later / after its reads) were no better and spilled in the persistent kernels.
 template <int NM, int ND>
 __device__ __forceinline__ constexpr int dma_piece_of_slot(int m) {
@@ -145,7 +145,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
     // first operand tile (gemm_sp_kernel: vec_issue): [0, 2048) the u64 row sums of squares of the tile's rows, [2048, 3072) nc_bias of its
     // columns, [3072, 3584) the head's norm weights (mode 4).  mt0 / nt0 = this wave's first row / column inside the tile.  The row sums
     // were written by memory-side atomics of the producer GEMM: as global loads they opened the epilogue with a fabric round trip, and the
-    // per-column vectors cost an L2 round trip per phase; from LDS they are ~64-cycle reads (in registers they spilled: profiles/r05_presq_*).
+    // per-column vectors cost an L2 round trip per phase; from LDS they are ~64-cycle reads (in registers they spilled: profiles/r05/r05_presq_*).
     constexpr int RPB = L16 ? 2 : 1;   // rows of a 32x32 block one lane holds (AccTile)
     const int lrow = L16 ? (lane & 15) : (lane & 31);   // the lane's row inside its 16- / 32-row group
     const bool eprobe = ep.clk_probe && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0;   // ACE355_GEMM_CLK: phases of this epilogue
@@ -442,7 +442,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
         // (Round 4, measured and removed: the big tiles requesting half 1's old H rows as soon as half 0's accumulators are staged, i.e.
         //  ahead of half 0's stores.  100 B of scratch - the per-column vectors spill - and the in-pass probe of this epilogue at M = 6000
         //  went from 42.3 k to 51.7 k cycles, the pass from 515.8 to 523.5 ms (ABAB).  The burst is bandwidth bound as it is: 122 MB per
-        //  launch in 23.7 us = 5.1 TB/s, beside 5.4 TB/s for the pure-store burst of the patchify GEMM; profiles/r04_gemm_clk_inpass.txt.)
+        //  launch in 23.7 us = 5.1 TB/s, beside 5.4 TB/s for the pure-store burst of the patchify GEMM; profiles/r04/r04_gemm_clk_inpass.txt.)
         constexpr bool PRE = (MODE == 2 && MT == 2 && NTW == 2);
         constexpr int NPJ = PRE ? NTW : 1;
         float4 hvp[NPJ][NT], g1p[NPJ], a2p[NPJ], b2p[NPJ], cvp[NPJ], ngAp[NPJ], ngBp[NPJ];
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
     bf16x8 pa[2][MT], pw[2][NTW], qa[2][MT], qw[2][NTW];
     // Epilogue vectors of this tile -> LDS vector area, one DMA piece per wave 0-3 BEHIND the prologue's operand tiles (ahead of them
     // they held tile 0 back: loads retire in order and the row sums are a fabric round trip - prologue + 500 cycles, the epilogues' gain
-    // gone; profiles/r05_epi_vec_first_ab.txt).  As the youngest request a piece only makes the counted waits of its wave conservative by
+    // gone; profiles/r05/r05_epi_vec_first_ab.txt).  As the youngest request a piece only makes the counted waits of its wave conservative by
     // one, the first K step's wait covers it and that step's barrier publishes it.  Waves 0 / 1: the row sums of squares (two rows per
     // lane; M even, so a pair never straddles the end of the array: rows >= M take the last pair's values and are never stored), wave 2
     // the bias of the tile's columns, wave 3 the head's norm weights.  Only whole tiles on the wide path (workgroup-uniform).

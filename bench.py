@@ -185,7 +185,9 @@ def pmc_traffic_bytes_per_launch():
     try:
         import glob
         # the profile taken on THIS library if there is one (source sha stamped into the summary), else the last by name (reported as stale)
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")))
+        # (the current round's files sit at the top of profiles/, earlier rounds' under profiles/rNN/)
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_FETCH_SIZE.json")) +
+                       glob.glob(os.path.join(ROOT, "profiles", "r*", "r*_pmc_FETCH_SIZE.json")), key=os.path.basename)
         cur = library_source_sha()
         same = [c for c in cands if json.load(open(c)).get("_meta", {}).get("lib_src_sha") == cur]
         f = (same or cands)[-1]
@@ -369,7 +371,7 @@ def main():
     # Host threads within the container's CPU quota (per rank): torch defaults to half the logical CPUs of the HOST (128 here) while the
     # cgroup grants 16; the OpenMP teams torch.randn / torch.cat spin up for the per-request noise then burn the quota and the kernel
     # throttles the process for up to a 100 ms period with the GPU idle (tools/probe/noise_hiccup_probe.py: randn p99 76.7 ms against a
-    # 1.4 ms median; one pass in ~8 took 570-620 ms instead of 475, profiles/r04_bench_invocation_spread_before_gc.txt).
+    # 1.4 ms median; one pass in ~8 took 570-620 ms instead of 475, profiles/r04/r04_bench_invocation_spread_before_gc.txt).
     torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus() // max(1, min(world, torch.cuda.device_count())))))
 
     import ace355  # noqa: F401
@@ -459,7 +461,7 @@ def main():
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]   # (recorded, never waited on inside the timed region)
         # The cyclic collector stays out of the timed passes: a generation-2 sweep of this process's heap (torch + the reference-shaped
         # state dicts) stops the host for ~55 ms in the middle of a pass with the GPU waiting (ACE355_BENCH_TRACE=1 showed it inside
-        # prepare_noise / set_condition at random: profiles/r04_pass_trace.txt) - the interpreter's housekeeping, not work of the request.
+        # prepare_noise / set_condition at random: profiles/r04/r04_pass_trace.txt) - the interpreter's housekeeping, not work of the request.
         gc.collect()
         gc_was = gc.isenabled()
         if not args.gc_on:

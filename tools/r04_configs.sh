@@ -1,5 +1,5 @@
 #!/bin/bash
-# The other BASELINE.json configs on the round's final code (one box, one command each): lines kept as profiles/r04_cfg*_line.json
+# The other BASELINE.json configs on the round's final code (one box, one command each): lines kept as profiles/r04/r04_cfg*_line.json
 cd "$(dirname "$0")/.."
 O=gpurun_out
 run() { n=$1; shift; python bench.py --no-cpu-baseline --no-roofline "$@" 2>/dev/null | tail -1 > $O/r04_${n}_line.json; python -c "import json; d=json.load(open('$O/r04_${n}_line.json')); print('$n', round(d['ms_per_step'],1), 'ms', round(d['value'],3), d['unit'])"; }

@@ -522,8 +522,8 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
     @contextlib.contextmanager
     def shape_independent(self, on: bool = True):
         """Run the enclosed native calls with ONE arithmetic per song whatever the launch shape: `ace355_gemm_set_k_rotation(0)` (no K
-        rotation, no split-K, no split-KV / key-split attention: include/ace355.h), one sampler chain (`ace355_dit_set_dual(0)`) and the RMSNorms as
-        kernels (`ace355_dit_set_norm_fold(0)`).  A song
+        rotation, no split-K, no split-KV / key-split attention: include/ace355.h) and one sampler chain (`ace355_dit_set_dual(0)`).  (The folded RMSNorms stay on: their
+        row sums are gathered per aligned 128-column group in one fp32 order whatever the GEMM tile)  A song
         generated alone, inside a batch of 8, or on any rank of a data-parallel request then comes out bit for bit the same
         (tests/test_dist_gpu.py, tests/test_metric_shapes_gpu.py).  Costs the small-request optimisations their gain (measured per
         request in DESIGN.md section 14); process-wide while active (the K-rotation mode is a library global)."""
@@ -533,15 +533,11 @@ class NativeHandler(NativeDitMixin, NativeVaeMixin):
         from . import native
         prev_k = native.gemm_set_k_rotation(0)
         prev_d = self.native_dit.set_dual(0)
-        # (the folded RMSNorm's per-row sums of squares are fp32 partial sums per GEMM tile before they become integers: their grouping follows the
-        #  tile width, so the folded path is the one remaining shape-dependent rounding - the norm kernels sum a row in one fixed order)
-        prev_f = self.native_dit.set_norm_fold(0)
         try:
             yield
         finally:
             native.gemm_set_k_rotation(prev_k)
             self.native_dit.set_dual(prev_d)
-            self.native_dit.set_norm_fold(prev_f)
 
     @staticmethod
     def _dp_guard(execute, local, state):

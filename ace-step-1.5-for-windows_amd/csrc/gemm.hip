@@ -431,7 +431,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
         const int rps = ep.rows_per_seq;
         // folded RMSNorm, producer side (mode 2).  Under an ordered split-K only the last part sees the finished h.
         const bool nf_on = FOLD && MODE == 2 && ep.nf_xg && (ep.ksplit <= 1 || (int)blockIdx.y == ep.ksplit - 1);
-        float nf_rs[NT];  // this lane group's row sums of h_new^2 over the wave's columns
+        float nf_rs[NT];  // this lane group's row sums of h_new^2 over the wave's 32-column blocks, in block order (b0, or b0 + b1)
 #pragma unroll
         for (int t = 0; t < NT; ++t) nf_rs[t] = 0.f;
         // Small tile (128x128, the launches of one- and two-song requests): EVERY load of both column halves is requested before
@@ -621,23 +621,33 @@ __device__ __forceinline__ void gemm_epilogue_wide(AccTile<L16> (&acc)[MT][NTW],
         }
         if constexpr (MODE == 2 && FOLD) {
             if (nf_on) {   // (workgroup-uniform)
-                // the N-waves of a workgroup hold partial sums of the SAME rows: they meet in LDS (xw, behind the staging slices) and one
-                // wave per row block issues the atomics - a quarter of them (8 / 16 per row instead of 32 / 64)
+                // A row's sum of squares leaves the workgroup as ONE integer per aligned 128-COLUMN GROUP, its four 32-column blocks (each the fixed 8-lane
+                // sum above) added as (b0 + b1) + (b2 + b3) in fp32, then 2^-24 fixed point, then a memory-side integer atomic.  Integer adds commute, and
+                // the fp32 part is the same expression in every tile form: a wave with two blocks holds b_even + b_odd already (the 128- and 256-wide tiles:
+                // the pairs meet through LDS), four one-block waves (the 8-wave 192 x 128 tile) pair up here.
+                // The folded norm's rstd therefore no longer depends on the tile a row happened to be computed in (round 6; until then the partials were
+                // summed wave after wave across the whole tile width, and with them the last bit of rstd followed the launch shape).
                 if (slot == 0) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) xw[wave * (MT * 32) + t * 8 + rsub] = nf_rs[t];
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_s_barrier();
-                const int wn = wave % wnw;
-                if (wn == 0 && slot == 0) {
+                // (one atomic per row and TILE as before: a 256-wide tile converts its two groups separately and adds the integers)
+                if (wave % wnw == 0 && slot == 0) {
+                    auto fix = [](float v) { return (unsigned long long)(long long)fminf(v * 16777216.f, 1.4e17f); };   // 2^-24 units; capped at 2^57: the partials of a row cannot wrap
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        float tot = 0.f;
-                        for (int k = 0; k < wnw; ++k) tot += xw[(wave + k) * (MT * 32) + t * 8 + rsub];   // (fixed order)
+                        const float* x = xw + wave * (MT * 32) + t * 8 + rsub;
+                        unsigned long long q;
+                        if constexpr (NTW == 2) {
+                            q = fix(x[0] + x[MT * 32]);
+                            if (wnw == 4) q += fix(x[2 * MT * 32] + x[3 * MT * 32]);
+                        } else {
+                            q = fix((x[0] + x[MT * 32]) + (x[2 * MT * 32] + x[3 * MT * 32]));
+                        }
                         const int m = mw0 + t * 8 + rsub;
-                        if (ROWS_FULL || m < M)
-                            atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, (unsigned long long)(long long)fminf(tot * 16777216.f, 1.4e17f));  // (2^-24 units; capped at 2^57: the partials of a row cannot wrap)
+                        if (ROWS_FULL || m < M) atomicAdd((m < ep.nf_split ? ep.nf_sqA : ep.nf_sqB) + m, q);
                     }
                 }
             }

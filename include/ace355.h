@@ -172,9 +172,9 @@ int ace355_dit_graph_stats(ace355_dit* h, int64_t* captures, int64_t* replays);
  * of >= 64 token rows (ACE355_NORM_FOLD_MIN_ROWS; since round 3 it pays at every real size) the three RMSNorms of a decoder layer
  * (base.py:493-533) are not kernels of their own: the residual GEMM that finishes hidden_states also writes bf16(h * g) and the rows' sums of
  * squares, the consuming projection applies rsqrt(mean(h^2) + eps) and the modulation shift's projection (shift W^T, precomputed per step of
- * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently - and a row's sum of
- * squares is gathered per GEMM tile in fp32 before it becomes an integer, so its last bit follows the tile width: the one launch-shape-dependent
- * rounding ace355_gemm_set_k_rotation(0) does not remove (NativeHandler.shape_independent() therefore runs the norms as kernels).
+ * the schedule at the start of the call) to its fp32 accumulators.  Same math, one bf16 rounding placed differently.  A row's sum of squares
+ * is gathered per aligned 128-column group - (b0 + b1) + (b2 + b3) over its four 32-column blocks in fp32, then 2^-24 fixed point and integer adds -
+ * so it does not depend on the GEMM tile form a row was computed in (round 6).
  * enable: 0 off, 1 default, 2 every call the kernels support whatever its size (tests). */
 int ace355_dit_set_norm_fold(ace355_dit* h, int enable);
 

@@ -40,6 +40,17 @@ else:
     k=oldhead.index('Status at the end of round 3')
     app='## Appendix A. The status paragraphs and verdict tables of rounds 1-5, as written at the time\n\n(Moved here from the top of the file in round 6; the numbers in them are those rounds\' numbers.)\n\n'+oldhead[k:]
 sec14=open('/root/repo/tools/r06_docs/sec14.md').read().replace('r06_final', TAG)
+import collections
+cost=collections.defaultdict(lambda: collections.defaultdict(list))
+for ln in open(f'{ROOT}/profiles/r06_shape_independent_cost.txt'):
+    m=re.match(r'b=(\d+)\s+(default|shape-independent)\s+([\d.]+)', ln)
+    if m: cost[int(m.group(1))][m.group(2)].append(float(m.group(3)))
+names={1:'one song',2:'two',4:'four',8:'eight'}
+parts=[]
+for bsz in (1,2,4,8):
+    dd=sum(cost[bsz]['default'])/len(cost[bsz]['default']); si=sum(cost[bsz]['shape-independent'])/len(cost[bsz]['shape-independent'])
+    parts.append(f"{names[bsz]} {si:.1f} vs {dd:.1f} ms (+ {100*(si/dd-1):.1f} %)")
+sec14=sec14.replace('@@INVCOST@@', ', '.join(parts))
 new=head+body.rstrip('\n')+'\n\n'+sec14.rstrip('\n')+'\n\n'+app
 open(f'{ROOT}/DESIGN.md','w').write(new)
 print('DESIGN.md', len(new))

@@ -29,7 +29,7 @@ Reproducibility: the same request gives the same bits (round 6 found the one lau
 issued - and fixed it: DESIGN.md section 14.1; `test_gemm_launches_are_bit_reproducible` covers every tile regime).  With the default (fastest) launch policy a
 song's low bits follow the batch it runs in (~3e-3 relative L2, both at the reference's distance); in the launch-shape-independent mode
 (`NativeHandler.shape_independent()`, what `generate_music(data_parallel=True)` uses) they do not: a song alone, in a batch of 8 or on any rank count comes out
-bit for bit the same, for + 2-7 % of time per request (DESIGN.md section 14.2 / 14.4).
+bit for bit the same, for + 6 % of time per request at one song per GPU, under 1 % at two to four, + 2 % at eight (DESIGN.md section 14.2 / 14.4).
 
 What is slow and why (DESIGN.md sections 5, 12-14): the big GEMMs sit at the chip's power cap (changes that removed waiting did not move the pass, changes that
 removed energy did); attention (9 % of the pass) runs at 0.20 of the MFMA peak with its softmax and MFMA phases in step; one-song requests are bound by the

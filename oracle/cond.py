@@ -63,15 +63,15 @@ def encoder_layer(cfg: CondConfig, w: Dict[str, Tensor], p: str, x: Tensor, cos:
     eps = cfg.rms_norm_eps
     h = o_dit.rms_norm(x, w[p + "input_layernorm.weight"], eps)
     sp = p + "self_attn."
-    q = o_dit.rms_norm(o_dit._heads(F.linear(h, w[sp + "q_proj.weight"]), cfg.head_dim), w[sp + "q_norm.weight"], eps).transpose(1, 2)
-    k = o_dit.rms_norm(o_dit._heads(F.linear(h, w[sp + "k_proj.weight"]), cfg.head_dim), w[sp + "k_norm.weight"], eps).transpose(1, 2)
-    v = o_dit._heads(F.linear(h, w[sp + "v_proj.weight"]), cfg.head_dim).transpose(1, 2)
+    q = o_dit.rms_norm(o_dit._heads(o_dit._linear(h, w[sp + "q_proj.weight"]), cfg.head_dim), w[sp + "q_norm.weight"], eps).transpose(1, 2)
+    k = o_dit.rms_norm(o_dit._heads(o_dit._linear(h, w[sp + "k_proj.weight"]), cfg.head_dim), w[sp + "k_norm.weight"], eps).transpose(1, 2)
+    v = o_dit._heads(o_dit._linear(h, w[sp + "v_proj.weight"]), cfg.head_dim).transpose(1, 2)
     q, k = o_dit.apply_rope(q, k, cos, sin)
     a = o_dit.attention(q, k, v, mask, cfg.head_dim ** -0.5)
-    x = x + F.linear(a, w[sp + "o_proj.weight"])
+    x = x + o_dit._linear(a, w[sp + "o_proj.weight"])
     h = o_dit.rms_norm(x, w[p + "post_attention_layernorm.weight"], eps)
     mp = p + "mlp."
-    return x + F.linear(F.silu(F.linear(h, w[mp + "gate_proj.weight"])) * F.linear(h, w[mp + "up_proj.weight"]), w[mp + "down_proj.weight"])
+    return x + o_dit._linear(F.silu(o_dit._linear(h, w[mp + "gate_proj.weight"])) * o_dit._linear(h, w[mp + "up_proj.weight"]), w[mp + "down_proj.weight"])
 
 
 def _encoder_stack(cfg: CondConfig, w: Dict[str, Tensor], p: str, n_layers: int, x: Tensor, attention_mask: Optional[Tensor]) -> Tensor:
@@ -88,7 +88,7 @@ def _encoder_stack(cfg: CondConfig, w: Dict[str, Tensor], p: str, n_layers: int,
 def lyric_encoder(cfg: CondConfig, w: Dict[str, Tensor], inputs_embeds: Tensor, attention_mask: Tensor) -> Tensor:
     """AceStepLyricEncoder.forward, base.py:603-731: embed_tokens (Linear with bias) -> 8 layers -> norm."""
     p = "lyric_encoder."
-    x = F.linear(inputs_embeds, w[p + "embed_tokens.weight"], w[p + "embed_tokens.bias"])
+    x = o_dit._linear(inputs_embeds, w[p + "embed_tokens.weight"], w[p + "embed_tokens.bias"])
     return _encoder_stack(cfg, w, p, cfg.num_lyric_encoder_hidden_layers, x, attention_mask)
 
 
@@ -113,7 +113,7 @@ def unpack_timbre_embeddings(packed: Tensor, order_mask: Tensor) -> Tuple[Tensor
 def timbre_encoder(cfg: CondConfig, w: Dict[str, Tensor], refer_packed: Tensor, order_mask: Tensor) -> Tuple[Tensor, Tensor]:
     """AceStepTimbreEncoder.forward, base.py:1063-1178: embed -> 4 layers (no padding mask) -> norm -> token 0 -> unpack."""
     p = "timbre_encoder."
-    x = F.linear(refer_packed, w[p + "embed_tokens.weight"], w[p + "embed_tokens.bias"])
+    x = o_dit._linear(refer_packed, w[p + "embed_tokens.weight"], w[p + "embed_tokens.bias"])
     x = _encoder_stack(cfg, w, p, cfg.num_timbre_encoder_hidden_layers, x, None)
     return unpack_timbre_embeddings(x[:, 0, :], order_mask)
 
@@ -134,7 +134,7 @@ def condition_encoder(cfg: CondConfig, w: Dict[str, Tensor], text_hidden_states:
                       lyric_hidden_states: Tensor, lyric_attention_mask: Tensor, refer_packed: Tensor,
                       refer_order_mask: Tensor) -> Tuple[Tensor, Tensor]:
     """AceStepConditionEncoder.forward, base.py:1526-1554 -> (encoder_hidden_states [B, Ll+Nt+Lt, D], mask)."""
-    text = F.linear(text_hidden_states, w["text_projector.weight"])
+    text = o_dit._linear(text_hidden_states, w["text_projector.weight"])
     lyric = lyric_encoder(cfg, w, lyric_hidden_states, lyric_attention_mask)
     timbre, timbre_mask = timbre_encoder(cfg, w, refer_packed, refer_order_mask)
     enc, mask = pack_sequences(lyric, timbre, lyric_attention_mask, timbre_mask)

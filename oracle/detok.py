@@ -89,7 +89,7 @@ def detokenizer(cfg: DetokConfig, w: Dict[str, Tensor], x: Tensor) -> Tensor:
     """
     B, T, D = x.shape
     P = cfg.pool_window_size
-    h = F.linear(x, w["embed_tokens.weight"], w["embed_tokens.bias"])
+    h = o_dit._linear(x, w["embed_tokens.weight"], w["embed_tokens.bias"])
     h = h.unsqueeze(2).repeat(1, 1, P, 1) + w["special_tokens"].expand(B, T, -1, -1)
     h = h.reshape(B * T, P, D)
     cos, sin = o_dit.rope_cos_sin(P, cfg.head_dim, cfg.rope_theta)
@@ -99,7 +99,7 @@ def detokenizer(cfg: DetokConfig, w: Dict[str, Tensor], x: Tensor) -> Tensor:
         m = slide if cfg.layer_types[li] == "sliding_attention" else full
         h = o_cond.encoder_layer(cfg, w, f"layers.{li}.", h, cos, sin, m)
     h = o_dit.rms_norm(h, w["norm.weight"], cfg.rms_norm_eps)
-    h = F.linear(h, w["proj_out.weight"], w["proj_out.bias"])
+    h = o_dit._linear(h, w["proj_out.weight"], w["proj_out.bias"])
     return h.reshape(B, T * P, -1)
 
 
@@ -138,9 +138,9 @@ def tokenizer_pool(cfg: DetokConfig, w: Dict[str, Tensor], x: Tensor) -> Tensor:
     """x [B, T5, P, 64] -> pooled [B, T5, D]: AceStepAudioTokenizer.forward up to the quantizer."""
     B, T, P, _ = x.shape
     D = cfg.hidden_size
-    h = F.linear(x, w["audio_acoustic_proj.weight"], w["audio_acoustic_proj.bias"])
+    h = o_dit._linear(x, w["audio_acoustic_proj.weight"], w["audio_acoustic_proj.bias"])
     a = "attention_pooler."
-    h = F.linear(h, w[a + "embed_tokens.weight"], w[a + "embed_tokens.bias"])
+    h = o_dit._linear(h, w[a + "embed_tokens.weight"], w[a + "embed_tokens.bias"])
     h = torch.cat([w[a + "special_token"].expand(B, T, 1, -1), h], dim=2).reshape(B * T, P + 1, D)
     S = P + 1
     cos, sin = o_dit.rope_cos_sin(S, cfg.head_dim, cfg.rope_theta)

@@ -12,6 +12,7 @@ pinned by tests/golden/make_golden.py against the imported reference.
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
@@ -20,6 +21,35 @@ import torch
 import torch.nn.functional as F
 
 Tensor = torch.Tensor
+
+# ---- "bf16 storage" emulation (the drift this restatement shows against itself sets the tolerance of the bf16 HIP path) ----
+# Inside `with bf16_storage():` every operand of a contraction (linear / conv inputs, Q, K, V, the softmax probabilities) is rounded to
+# bfloat16 on its way in; arithmetic, accumulation, norms and the residual stream stay fp32.  The caller passes weights rounded with
+# `bf16_weights`.  Outside the context nothing is rounded: the default path is the fp32 restatement the golden vectors pin.
+_BF16_STORAGE = False
+
+
+@contextlib.contextmanager
+def bf16_storage():
+    global _BF16_STORAGE
+    old, _BF16_STORAGE = _BF16_STORAGE, True
+    try:
+        yield
+    finally:
+        _BF16_STORAGE = old
+
+
+def bf16_weights(w: Dict[str, "Tensor"]) -> Dict[str, "Tensor"]:
+    """Every matrix (ndim >= 2) of a weight set rounded to bfloat16 and back; vectors and the scale-shift tables stay fp32."""
+    return {k: (v.to(torch.bfloat16).to(v.dtype) if v.ndim >= 2 and "scale_shift" not in k else v) for k, v in w.items()}
+
+
+def _q(x: "Tensor") -> "Tensor":
+    return x.to(torch.bfloat16).to(x.dtype) if _BF16_STORAGE else x
+
+
+def _linear(x: "Tensor", weight: "Tensor", bias: Optional["Tensor"] = None) -> "Tensor":
+    return F.linear(_q(x), weight, bias)
 
 
 @dataclass
@@ -73,6 +103,7 @@ def sinusoid_embedding(t: Tensor, dim: int = 256, scale: float = 1000.0, max_per
 
 def timestep_embed(t: Tensor, w: Dict[str, Tensor], prefix: str) -> Tuple[Tensor, Tensor]:
     """TimestepEmbedding.forward, base.py:248-254 -> (temb [N,D], timestep_proj [N,6,D])."""
+    # (F.linear, not _linear: the HIP path feeds these three small projections fp32 inputs - only their weights are bf16)
     t_freq = sinusoid_embedding(t, 256).to(t.dtype)
     temb = F.linear(t_freq, w[prefix + ".linear_1.weight"], w[prefix + ".linear_1.bias"])
     temb = F.silu(temb)
@@ -127,11 +158,11 @@ def attention(q: Tensor, k: Tensor, v: Tensor, mask: Optional[Tensor], scale: fl
     groups = q.shape[1] // k.shape[1]
     k = k.repeat_interleave(groups, dim=1)
     v = v.repeat_interleave(groups, dim=1)
-    w = torch.matmul(q, k.transpose(2, 3)) * scale
+    w = torch.matmul(_q(q), _q(k).transpose(2, 3)) * scale
     if mask is not None:
         w = w + mask
     w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
-    o = torch.matmul(w, v)
+    o = torch.matmul(_q(w), _q(v))
     return o.transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
 
 
@@ -146,8 +177,8 @@ def cross_kv(cfg: DitConfig, w: Dict[str, Tensor], li: int, enc: Tensor) -> Tupl
     base.py:320-321: K = k_norm(k_proj(enc)) (no RoPE), V = v_proj(enc); both [N,Hkv,L,d].
     """
     p = f"layers.{li}.cross_attn."
-    k = rms_norm(_heads(F.linear(enc, w[p + "k_proj.weight"]), cfg.head_dim), w[p + "k_norm.weight"], cfg.rms_norm_eps)
-    v = _heads(F.linear(enc, w[p + "v_proj.weight"]), cfg.head_dim)
+    k = rms_norm(_heads(_linear(enc, w[p + "k_proj.weight"]), cfg.head_dim), w[p + "k_norm.weight"], cfg.rms_norm_eps)
+    v = _heads(_linear(enc, w[p + "v_proj.weight"]), cfg.head_dim)
     return k.transpose(1, 2), v.transpose(1, 2)
 
 
@@ -172,9 +203,9 @@ def dit_layer(
     # self attention (base.py:499-511, 304, 338-343)
     xn = rms_norm(h, w[p + "self_attn_norm.weight"], eps) * (1 + scale_msa) + shift_msa
     sp = p + "self_attn."
-    q = rms_norm(_heads(F.linear(xn, w[sp + "q_proj.weight"]), cfg.head_dim), w[sp + "q_norm.weight"], eps).transpose(1, 2)
-    k = rms_norm(_heads(F.linear(xn, w[sp + "k_proj.weight"]), cfg.head_dim), w[sp + "k_norm.weight"], eps).transpose(1, 2)
-    v = _heads(F.linear(xn, w[sp + "v_proj.weight"]), cfg.head_dim).transpose(1, 2)
+    q = rms_norm(_heads(_linear(xn, w[sp + "q_proj.weight"]), cfg.head_dim), w[sp + "q_norm.weight"], eps).transpose(1, 2)
+    k = rms_norm(_heads(_linear(xn, w[sp + "k_proj.weight"]), cfg.head_dim), w[sp + "k_norm.weight"], eps).transpose(1, 2)
+    v = _heads(_linear(xn, w[sp + "v_proj.weight"]), cfg.head_dim).transpose(1, 2)
     q, k = apply_rope(q, k, cos, sin)
     a = attention(q, k, v, self_mask, scale)
     if taps is not None:
@@ -183,21 +214,21 @@ def dit_layer(
         taps[f"l{li}.k"] = k
         taps[f"l{li}.v"] = v
         taps[f"l{li}.self_attn"] = a
-    h = h + F.linear(a, w[sp + "o_proj.weight"]) * gate_msa
+    h = h + _linear(a, w[sp + "o_proj.weight"]) * gate_msa
 
     # cross attention (base.py:515-526, 304, 310-333): plain residual, no RoPE, zero mask
     xn = rms_norm(h, w[p + "cross_attn_norm.weight"], eps)
     cp = p + "cross_attn."
-    q = rms_norm(_heads(F.linear(xn, w[cp + "q_proj.weight"]), cfg.head_dim), w[cp + "q_norm.weight"], eps).transpose(1, 2)
+    q = rms_norm(_heads(_linear(xn, w[cp + "q_proj.weight"]), cfg.head_dim), w[cp + "q_norm.weight"], eps).transpose(1, 2)
     a = attention(q, kv[0], kv[1], None, scale)
     if taps is not None:
         taps[f"l{li}.cross_attn"] = a
-    h = h + F.linear(a, w[cp + "o_proj.weight"])
+    h = h + _linear(a, w[cp + "o_proj.weight"])
 
     # SwiGLU MLP (base.py:530-533; transformers Qwen3MLP)
     xn = rms_norm(h, w[p + "mlp_norm.weight"], eps) * (1 + c_scale) + c_shift
     mp = p + "mlp."
-    ff = F.linear(F.silu(F.linear(xn, w[mp + "gate_proj.weight"])) * F.linear(xn, w[mp + "up_proj.weight"]), w[mp + "down_proj.weight"])
+    ff = _linear(F.silu(_linear(xn, w[mp + "gate_proj.weight"])) * _linear(xn, w[mp + "up_proj.weight"]), w[mp + "down_proj.weight"])
     h = h + ff * c_gate
     if taps is not None:
         taps[f"l{li}.out"] = h
@@ -238,14 +269,14 @@ def dit_forward(
     if T0 % cfg.patch_size:
         h = F.pad(h, (0, 0, 0, cfg.patch_size - T0 % cfg.patch_size))
     # proj_in: Conv1d(192 -> D, k=2, s=2) (base.py:1264-1274)
-    h = F.conv1d(h.transpose(1, 2), w["proj_in.1.weight"], w["proj_in.1.bias"], stride=cfg.patch_size).transpose(1, 2)
+    h = F.conv1d(_q(h).transpose(1, 2), w["proj_in.1.weight"], w["proj_in.1.bias"], stride=cfg.patch_size).transpose(1, 2)
     S = h.shape[1]
 
     # condition_embedder runs every step in the reference (base.py:1359); its only
     # consumer is the cross K/V which is cached after step 0, so we compute it only then.
     kvs = {}
     if cache is None or not cache.kv:
-        enc = F.linear(enc_hs, w["condition_embedder.weight"], w["condition_embedder.bias"])
+        enc = _linear(enc_hs, w["condition_embedder.weight"], w["condition_embedder.bias"])
         for li in range(cfg.num_hidden_layers):
             kvs[li] = cross_kv(cfg, w, li, enc)
         if cache is not None:
@@ -266,7 +297,7 @@ def dit_forward(
     shift, scale = (w["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)
     h = rms_norm(h, w["norm_out.weight"], cfg.rms_norm_eps) * (1 + scale) + shift
     # proj_out: ConvTranspose1d(D -> 64, k=2, s=2) (base.py:1287-1297), then crop (:1501)
-    v = F.conv_transpose1d(h.transpose(1, 2), w["proj_out.1.weight"], w["proj_out.1.bias"], stride=cfg.patch_size).transpose(1, 2)
+    v = F.conv_transpose1d(_q(h).transpose(1, 2), w["proj_out.1.weight"], w["proj_out.1.bias"], stride=cfg.patch_size).transpose(1, 2)
     return v[:, :T0, :]
 
 

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+import _drift
+
 pytestmark = pytest.mark.gpu
 
 
@@ -79,8 +81,18 @@ def test_condition_encoder_vs_reference_golden(gpu_device, golden_dir, case):
     vm = ref_m.bool()
     ra, rv, rp = _rel(h.cpu(), ref_h), _rel(h.cpu()[vm], ref_h[vm]), _rel(h.cpu()[~vm], ref_h[~vm])
     print(f"condition encoder case {case}: rel L2 vs reference fp32 all rows {ra:.3e}, valid {rv:.3e}, padding {rp:.3e}")
-    # gates = 2.5-3x the measured 3.3e-3 - 3.8e-3 (padding rows incl. uniform-attention rows and the zero timbre rows)
-    assert ra < 1e-2 and rv < 1e-2 and rp < 1e-2, (ra, rv, rp)
+    # gates = 2 x the oracle's own bf16-storage drift on this fixture, per row class (measured 3.3e-3 - 3.8e-3; padding rows incl. uniform-attention rows
+    # and the zero timbre rows)
+    from oracle import cond as o_cond
+    o_cfg = o_cond.CondConfig(**{k: getattr(cfg, k) for k in ("hidden_size", "intermediate_size", "num_attention_heads", "num_key_value_heads", "head_dim",
+                                                              "text_hidden_dim", "timbre_hidden_dim", "num_lyric_encoder_hidden_layers",
+                                                              "num_timbre_encoder_hidden_layers", "sliding_window")})
+    emu, _m = _drift.emulated(o_cond.condition_encoder, o_cfg, w, T(G[f"{case}_text"]), T(G[f"{case}_tmask"]), T(G[f"{case}_lyric"]), T(G[f"{case}_lmask"]),
+                              T(G[f"{case}_refer"]), T(G[f"{case}_order"]))
+    print(f"    vs the oracle with bf16 storage: all rows {_rel(h.cpu(), emu):.3e}")
+    _drift.check(f"condition encoder {case}, all rows", ra, _rel(emu, ref_h))
+    _drift.check(f"condition encoder {case}, valid rows", rv, _rel(emu[vm], ref_h[vm]))
+    _drift.check(f"condition encoder {case}, padding rows", rp, _rel(emu[~vm], ref_h[~vm]))
 
 
 def test_condition_encoder_full_size_vs_oracle(gpu_device):
@@ -117,7 +129,9 @@ def test_condition_encoder_full_size_vs_oracle(gpu_device):
     print(f"condition encoder full size: rel L2 vs fp32 oracle {r:.3e}, output sha {sha}, 5 calls bit-identical")
     # measured 1.166e-2 in rounds 2-5 before the fault and again once it was fixed (sha d8528bec82a8c1a6); 1.169e-2 since the head-norm epilogue sums a
     # row's squares block by block in every tile form (another fp32 order of the same sum): 12 bf16 layers with PLAIN residuals
-    assert r < 2e-2, r
+    emu, _m = _drift.emulated(o_cond.condition_encoder, o_cfg, w, text, tmask, lyric, lmask, refer, order)
+    print(f"    vs the oracle with bf16 storage: {_rel(h.cpu(), emu):.3e}")
+    _drift.check("condition encoder, full size", r, _rel(emu, ref_h))
     assert sha == "14079fa2dede1709", sha
     # and its output drives the DiT's condition slot unchanged
     assert h.dtype == torch.float32 and h.is_contiguous() and h.shape == (B, Ll + 2 + Lt, cfg.hidden_size)

@@ -183,7 +183,11 @@ def test_native_handler_generate_music_and_mixin_host_at_full_size(gpu_device):
     snr = float(10 * torch.log10((gain * b).pow(2).sum() / (a - gain * b).pow(2).sum()))
     print(f"NativeHandler.generate_music (configs[0], full size): latents rel L2 {r:.3e} vs oracle.sampler, waveform SNR {snr:.1f} dB vs "
           f"oracle.sampler -> oracle.oobleck (gain {gain:.4f}); GPU diffusion {tc['diffusion_time_cost']:.3f} s, decode {tc['vae_decode_time_cost']:.3f} s")
-    assert r < 6e-3, r
+    # SURVEY 8d gate on the latents: twice the oracle's own drift when it stores weights / contraction operands in bf16 and hands its result over as
+    # bf16 the way the seam does (handler/diffusion.py:128); measured 2.5e-3
+    import _drift
+    emu = _drift.emulated(o_sampler.generate_audio, o_dit.DitConfig(), w, null, enc, ctx, seed=[1000], infer_steps=steps, diffusion_guidance_sale=7.0)
+    _drift.check("configs[0] latents through the handler", r, _rel(emu.to(torch.bfloat16).float(), ref))
     assert 0.0 < gain <= 1.0 + 2e-2 and snr > 31.0, (gain, snr)
 
     # error contract on the same initialised handler: an exception inside the path becomes the reference's payload

@@ -1,14 +1,17 @@
 """GPU parity of the native DiT forward + sampler (through the C ABI) against golden vectors captured from the
 imported reference (tests/golden/make_golden.py) and against the oracle on fresh seeded inputs.
 
-Tolerance model: weights/activations are bf16 on the MFMA path (the reference's own CUDA dtype,
-handler/init_service_orchestrator.py:51), the golden vectors are the reference's fp32 CPU path.  Every gate below is
-2-3x the value MEASURED on MI355X (round 2, gpurun_out/r02_pytest1.log; the measured value is quoted next to each gate and
-printed by the test), so a kernel regression of 3x fails.
+Tolerance model (tests/_drift.py): weights / contraction operands are bf16 on the MFMA path (the reference's own CUDA
+dtype, handler/init_service_orchestrator.py:51), the golden vectors are the reference's fp32 CPU path.  Every parity gate is TWICE the
+distance the oracle itself shows from that fp32 result when it stores weights and contraction operands in bf16 (`oracle.dit.bf16_storage`),
+measured in the same run (`_drift.emulated`) or, for the full-size fixtures, read from tests/golden/bf16_storage_drift.json; each test also
+prints how far the HIP result is from that bf16-storage oracle.  (Until round 6 the gates were "2-3 x what was measured".)
 """
 import numpy as np
 import pytest
 import torch
+
+import _drift
 
 pytestmark = pytest.mark.gpu
 
@@ -45,8 +48,11 @@ def test_tiny_forward_vs_reference_golden(gpu_device, golden_dir, case):
     v = dit.forward(x, ctx, t.tolist(), t.tolist(), list(range(N)))
     ref = torch.from_numpy(G[f"{case}_v"])
     r = _rel(v, ref)
-    print(f"tiny forward case {case}: rel L2 vs reference fp32 = {r:.3e}")
-    assert r < 8e-3, r  # measured 3.1e-3 (all three cases)
+    from oracle import dit as o_dit
+    emu = _drift.emulated(o_dit.dit_forward, o_dit.DitConfig(**TINY, sliding_window=window), w, x, t, t, enc, ctx)
+    print(f"tiny forward case {case}: rel L2 vs reference fp32 = {r:.3e}; vs the oracle with bf16 storage {_rel(v, emu):.3e}")
+    _drift.check(f"tiny forward {case}", r, _rel(emu, ref))   # measured 3.13e-3 against a drift of 3.12e-3
+    assert abs(_rel(emu, ref) / _drift.table(f"g2/{case}", "v") - 1) < 0.02   # ... which is also the table's entry for this case
     assert float((v.cpu() - ref).abs().max()) < 0.05 * float(ref.abs().max())
 
 
@@ -68,9 +74,10 @@ def test_tiny_forward_matches_oracle_with_bf16_weights(gpu_device):
     v = dit.forward(x, ctx, t, tr, [0, 1, 2])
     o_cfg = o_dit.DitConfig(**TINY)
     ref = o_dit.dit_forward(o_cfg, wb, x, torch.tensor(t), torch.tensor(tr), enc, ctx)
+    emu = _drift.emulated(o_dit.dit_forward, o_cfg, wb, x, torch.tensor(t), torch.tensor(tr), enc, ctx)   # + operands stored in bf16
     r = _rel(v, ref)
-    print(f"tiny forward vs oracle (bf16 weights): rel L2 = {r:.3e}")
-    assert r < 6e-3, r  # measured 2.1e-3
+    print(f"tiny forward vs oracle (bf16 weights): rel L2 = {r:.3e}; vs the same oracle with bf16 operand storage {_rel(v, emu):.3e}")
+    _drift.check("tiny forward, bf16 weights on both sides", r, _rel(emu, ref))   # measured 2.1e-3
 
 
 @pytest.mark.parametrize("name", ["cfg7_shift1", "cfg1_shift3", "cfg7_interval", "sft_timesteps"])
@@ -91,9 +98,13 @@ def test_tiny_sampler_vs_reference_golden(gpu_device, golden_dir, name):
                            cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=ts)
     ref = torch.from_numpy(G[f"{name}_out"])
     r = _rel(out["target_latents"], ref)
-    print(f"tiny sampler {name}: rel L2 vs reference fp32 = {r:.3e}")
+    from oracle import dit as o_dit, sampler as o_sampler
+    emu = _drift.emulated(o_sampler.generate_audio, o_dit.DitConfig(**TINY), w, null, enc.expand(B, -1, -1), ctx, seed=G[f"{name}_seeds"].tolist(),
+                          infer_steps=int(G[f"{name}_steps"]), diffusion_guidance_sale=float(G[f"{name}_guidance"]),
+                          cfg_interval_start=lo, cfg_interval_end=hi, shift=float(G[f"{name}_shift"]), timesteps=ts)
+    print(f"tiny sampler {name}: rel L2 vs reference fp32 = {r:.3e}; vs the oracle with bf16 storage {_rel(out['target_latents'], emu):.3e}")
     assert set(out["time_costs"]) == {"encoder_time_cost", "diffusion_time_cost", "diffusion_per_step_time_cost", "total_time_cost"}
-    assert r < 5e-3, r
+    _drift.check(f"tiny sampler {name}", r, _rel(emu, ref))   # measured 0.73e-3 - 1.65e-3, each within 0.3 % of its drift
 
 
 def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
@@ -121,7 +132,9 @@ def test_tiny_sampler_with_norm_fold_forced(gpu_device, golden_dir):
     again = generate_latents(dit, null, enc.expand(B, -1, -1), ctx, **kw)["target_latents"].cpu()
     r_f, r_p, r_x = _rel(folded, ref), _rel(plain, ref), _rel(folded, plain)
     print(f"tiny sampler, norm fold forced: folded vs reference {r_f:.3e}, norms as kernels vs reference {r_p:.3e}, folded vs kernels {r_x:.3e}")
-    assert r_f < 5e-3 and r_p < 5e-3, (r_f, r_p)
+    d = _drift.table("g3/cfg7_shift1", "out")
+    _drift.check("tiny sampler, folded norms", r_f, d)
+    _drift.check("tiny sampler, norms as kernels", r_p, d)
     assert torch.equal(folded, again) and not torch.equal(folded, plain)
 
 
@@ -168,8 +181,11 @@ def test_tiny_sampler_layer0_dedup_on_off(gpu_device, golden_dir):
         dit.set_dedup(True)
     print(f"tiny sampler, layer-0 dedup: on vs reference {res[0][0]:.3e} / {res[2][0]:.3e} (norm kernels / folded), off {res[0][1]:.3e} / {res[2][1]:.3e}, "
           f"on vs off {res[0][2]:.3e} / {res[2][2]:.3e}")
+    d = _drift.table("g3/cfg7_shift1", "out")
     for fold in (0, 2):
-        assert res[fold][0] < 5e-3 and res[fold][1] < 5e-3 and res[fold][2] < 2e-3, res
+        _drift.check(f"dedup on, fold {fold}", res[fold][0], d)
+        _drift.check(f"dedup off, fold {fold}", res[fold][1], d)
+        assert res[fold][2] < 2e-3, res   # (native vs native: other tile shapes for the half-size launches)
 
 
 def test_zero_row_and_tile64_switches_keep_the_bits(gpu_device):
@@ -263,8 +279,12 @@ def test_tiny_sampler_cover_switch(gpu_device, golden_dir):
                          src_latents=t["src"], encoder_hidden_states_non_cover=t["enc_nc"], context_latents_non_cover=t["ctx_nc"])
     outs = [o["target_latents"].cpu()]
     r = _rel(torch.cat(outs), t["out"])
-    print(f"cover switch: rel L2 vs reference fp32 = {r:.3e}")
-    assert r < 4e-3, r  # measured 1.25e-3
+    from oracle import dit as o_dit, sampler as o_sampler
+    emu = _drift.emulated(o_sampler.generate_audio, o_dit.DitConfig(**TINY), w, null, t["enc"], t["ctx"], seed=[int(v) for v in G["cover_seeds"]],
+                          infer_steps=8, diffusion_guidance_sale=4.0, shift=2.0, audio_cover_strength=0.5, cover_noise_strength=0.3,
+                          src_latents=t["src"], encoder_hidden_states_non_cover=t["enc_nc"], context_latents_non_cover=t["ctx_nc"])
+    print(f"cover switch: rel L2 vs reference fp32 = {r:.3e}; vs the oracle with bf16 storage {_rel(outs[0], emu):.3e}")
+    _drift.check("cover switch", r, _rel(emu, t["out"]))   # measured 1.25e-3
 
 
 def test_full_size_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -292,9 +312,10 @@ def test_full_size_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_
     r23 = _rel(taps[23].view(2, S, -1)[:, ::25], torch.from_numpy(G["l23_out"]))
     print(f"full-size forward: rel L2 vs reference fp32 = {r:.3e} (taps: layer 0 {r0:.3e}, layer 23 {r23:.3e}); "
           f"per-seq {[_rel(v[i], ref[i]) for i in range(2)]}")
-    # gates = 2-3x the measured values (5.8e-3 on v in round 1; taps measured in round 2)
-    assert r < 1.5e-2, r
-    assert r0 < 1e-2 and r23 < 1.2e-2, (r0, r23)  # measured 3.8e-3 / 4.1e-3
+    # gates = 2 x the oracle's bf16-storage drift on this fixture (tests/golden/make_drift.py; measured here: v 5.8e-3, taps 3.8e-3 / 4.1e-3)
+    _drift.check("G4 velocity", r, _drift.table("g4", "v"))
+    _drift.check("G4 layer-0 tap", r0, _drift.table("g4", "l0"))
+    _drift.check("G4 layer-23 tap", r23, _drift.table("g4", "l23"))
     assert not torch.isnan(v).any()
 
 
@@ -326,8 +347,10 @@ def test_baseline_config0_full_size_sampler_and_decode_vs_oracle(gpu_device):
     ref = o_sampler.generate_audio(o_dit.DitConfig(), w, null, enc, ctx, seed=[1000], infer_steps=steps, diffusion_guidance_sale=7.0)
     cpu_s = time.time() - t0
     r = _rel(lat, ref)
-    print(f"config0 full-size sampler: latents rel L2 {r:.3e} (GPU {out['time_costs']['diffusion_time_cost']:.3f}s, CPU oracle {cpu_s:.1f}s)")
-    assert r < 6e-3, r
+    emu = _drift.emulated(o_sampler.generate_audio, o_dit.DitConfig(), w, null, enc, ctx, seed=[1000], infer_steps=steps, diffusion_guidance_sale=7.0)
+    print(f"config0 full-size sampler: latents rel L2 {r:.3e} (GPU {out['time_costs']['diffusion_time_cost']:.3f}s, CPU oracle {cpu_s:.1f}s); "
+          f"vs the oracle with bf16 storage {_rel(lat, emu):.3e}")
+    _drift.check("config0 latents", r, _rel(emu, ref))   # measured 2.2e-3 (the weights are bf16-representable on both sides: operand storage only)
     vcfg = ace355.VaeConfig()
     vw = weightgen.make_vae_weights(vcfg.weight_shapes(), seed=7, mode="init")
     vae = NativeVae(vcfg, gpu_device)
@@ -355,8 +378,9 @@ def test_adg_and_sde_branches_vs_oracle(gpu_device):
     ref = o_sampler.generate_audio(o_cfg, w, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, use_adg=True)
     out = generate_latents(dit, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, use_adg=True)["target_latents"]
     r = _rel(out, ref)
-    print(f"ADG sampler: rel L2 {r:.3e}")
-    assert r < 5e-3, r  # measured 1.8e-3
+    emu = _drift.emulated(o_sampler.generate_audio, o_cfg, w, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, use_adg=True)
+    print(f"ADG sampler: rel L2 {r:.3e}; vs the oracle with bf16 storage {_rel(out, emu):.3e}")
+    _drift.check("ADG sampler", r, _rel(emu, ref))   # measured 1.8e-3
     with pytest.raises(ValueError, match="batch size 1"):
         generate_latents(dit, null, enc.expand(2, -1, -1), ctx.expand(2, -1, -1).contiguous(), seed=[1, 2], infer_steps=2, use_adg=True)
     # SDE: the oracle draws randn_like(x) once per step from the global CPU generator; replay the same draws natively
@@ -367,8 +391,10 @@ def test_adg_and_sde_branches_vs_oracle(gpu_device):
     out = generate_latents(dit, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, infer_method="sde",
                            sde_noise=noise)["target_latents"]
     r = _rel(out, ref)
-    print(f"SDE sampler: rel L2 {r:.3e}")
-    assert r < 7e-3, r  # measured 2.6e-3
+    emu = _drift.emulated(o_sampler.generate_audio, o_cfg, w, null, enc, ctx, seed=[3], infer_steps=steps, diffusion_guidance_sale=5.0, infer_method="sde",
+                          sde_noise=noise)
+    print(f"SDE sampler: rel L2 {r:.3e}; vs the oracle with bf16 storage {_rel(out, emu):.3e}")
+    _drift.check("SDE sampler", r, _rel(emu, ref))   # measured 2.6e-3
 
 
 def test_null_branch_shortcut_equals_generic_path(gpu_device):
@@ -468,8 +494,10 @@ def test_cover_switch_with_conditions_of_different_lengths_vs_oracle(gpu_device)
     out = generate_latents(dit, null, enc, ctx, **kw)["target_latents"].cpu()
     ref = o_sampler.generate_audio(o_dit.DitConfig(**TINY), w, null, enc, ctx, **kw)
     r = _rel(out, ref)
-    print(f"cover switch, encoder lengths {L1} -> {L2}: rel L2 vs the oracle = {r:.3e}")
-    assert torch.isfinite(out).all() and r < 4e-3, r
+    emu = _drift.emulated(o_sampler.generate_audio, o_dit.DitConfig(**TINY), w, null, enc, ctx, **kw)
+    print(f"cover switch, encoder lengths {L1} -> {L2}: rel L2 vs the oracle = {r:.3e}; vs the oracle with bf16 storage {_rel(out, emu):.3e}")
+    assert torch.isfinite(out).all()
+    _drift.check("cover switch, different encoder lengths", r, _rel(emu, ref))
 
 
 @pytest.mark.parametrize("name", ["shift3", "explicit", "cover", "sde_shift3"])
@@ -490,8 +518,14 @@ def test_turbo_sampler_vs_reference_golden(gpu_device, golden_dir, name):
                                  infer_method="sde" if name.startswith("sde") else "ode",  # renoise level = next table value
                                  sde_noise=t(f"{name}_sde_noise") if name.startswith("sde") else None)["target_latents"]
     r = _rel(out, t(f"{name}_out"))
-    print(f"turbo sampler {name}: rel L2 vs the turbo reference (fp32 CPU) = {r:.3e}")
-    assert r < (4e-3 if name.startswith("sde") else 2.5e-3), r  # measured 0.8e-3 (ode), 1.5e-3 (sde)
+    from oracle import dit as o_dit, sampler as o_sampler
+    emu = _drift.emulated(o_sampler.generate_audio_turbo, o_dit.DitConfig(**TINY), w, t("enc"), t("ctx"), seed=G["seeds"].tolist(),
+                          shift=float(G[f"{name}_shift"]), timesteps=ts if ts else None, audio_cover_strength=float(G[f"{name}_acs"]),
+                          cover_noise_strength=float(G[f"{name}_cns"]), src_latents=t("src"), encoder_hidden_states_non_cover=t("enc_nc"),
+                          context_latents_non_cover=t("ctx_nc"), infer_method="sde" if name.startswith("sde") else "ode",
+                          sde_noise=t(f"{name}_sde_noise") if name.startswith("sde") else None)
+    print(f"turbo sampler {name}: rel L2 vs the turbo reference (fp32 CPU) = {r:.3e}; vs the oracle with bf16 storage {_rel(out, emu):.3e}")
+    _drift.check(f"turbo sampler {name}", r, _rel(emu, t(f"{name}_out")))   # measured 0.8e-3 (ode), 1.5e-3 (sde)
 
 
 def test_schedule_tables_equal_per_step_embeddings(gpu_device, golden_dir, tmp_path):
@@ -530,7 +564,7 @@ def test_schedule_tables_equal_per_step_embeddings(gpu_device, golden_dir, tmp_p
     ref = torch.from_numpy(np.load(f"{golden_dir}/g3_tiny_sampler.npz")["cfg7_shift1_out"])
     print(f"schedule tables on / off vs reference: {_rel(outs['1'], ref):.3e} / {_rel(outs['0'], ref):.3e}; on vs off max abs {float((outs['1'] - outs['0']).abs().max()):.1e}")
     assert torch.equal(outs["1"], outs["0"])
-    assert _rel(outs["1"], ref) < 5e-3
+    _drift.check("schedule tables on", _rel(outs["1"], ref), _drift.table("g3/cfg7_shift1", "out"))
 
 
 def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_path):
@@ -566,7 +600,9 @@ def test_head_epilogue_and_two_kernel_path_agree(gpu_device, golden_dir, tmp_pat
     ref = torch.from_numpy(np.load(f"{golden_dir}/g2_tiny_forward.npz")["a_v"])
     r1, r0, rx = _rel(outs["1"], ref), _rel(outs["0"], ref), _rel(outs["1"], outs["0"])
     print(f"head epilogue: fused vs reference {r1:.3e}, two-kernel vs reference {r0:.3e}, fused vs two-kernel {rx:.3e}")
-    assert r1 < 8e-3 and r0 < 8e-3 and rx < 2.5e-3, (r1, r0, rx)  # measured 3.1e-3, 3.1e-3, 7.8e-4
+    _drift.check("head epilogue fused", r1, _drift.table("g2/a", "v"))
+    _drift.check("head epilogue as two kernels", r0, _drift.table("g2/a", "v"))
+    assert rx < 2.5e-3, rx  # (native vs native) measured 7.8e-4
 
 
 def test_vt_from_the_qkv_epilogue_equals_the_transpose_kernel(gpu_device, golden_dir, tmp_path):

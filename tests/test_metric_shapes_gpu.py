@@ -4,13 +4,17 @@ Mc = 3000 cross-attention rows) and at configs[2] (120 s, S = 1500), against vec
 192x256 persistent tiles, the 192x128 mid tile, the residual / SwiGLU / head-norm epilogues at M = 6000, attn3_kernel<4> at
 N = 16 and attn3_kernel<8> at S = 1500.  Inputs are regenerated from seeds (CPU generators) and pinned by checksums.
 
-Gates are 2-3x the values measured on MI355X (printed by every test; DESIGN.md section 3 lists them).
+Gates: twice the distance the oracle itself shows from the fixture's fp32 result when it stores weights and
+contraction operands in bf16 - measured per fixture by tests/golden/make_drift.py (the oracle needs minutes to hours for these shapes) and read
+from tests/golden/bf16_storage_drift.json (tests/_drift.py).  Until round 6 they were "2-3 x what was measured".
 """
 import os
 
 import numpy as np
 import pytest
 import torch
+
+import _drift
 
 pytestmark = pytest.mark.gpu
 
@@ -32,8 +36,6 @@ def _inputs(B, T, seed0=1000, ctx_seed=45):
 def _close(a, b):
     return abs(a - b) <= 1e-9 * abs(b)
 
-
-GATE_G15 = 1e-2  # measured 3.47e-3 (folded and unfolded alike)
 
 
 def test_metric_shape_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -74,8 +76,9 @@ def test_metric_shape_forward_vs_reference_golden(gpu_device, golden_dir, full_d
     print(f"metric-shape forward (N=16, T=750): rel L2 vs reference fp32 = {r:.3e} (cond {r_c:.3e}, null {r_u:.3e}); "
           f"taps layer 0 {r0:.3e}, layer 23 {r23:.3e}")
     assert torch.isfinite(v).all()
-    assert r < 1.5e-2 and r_c < 1.5e-2 and r_u < 1.5e-2, (r, r_c, r_u)
-    assert r0 < 1e-2 and r23 < 1.2e-2, (r0, r23)  # measured: v 5.8e-3 (cond 6.2e-3, null 5.1e-3), taps 3.8e-3 / 4.1e-3
+    # measured: v 5.8e-3 (cond 6.2e-3, null 5.1e-3), taps 3.8e-3 / 4.1e-3
+    for what, val, key in (("v", r, "v"), ("v, conditional half", r_c, "v_cond"), ("v, null half", r_u, "v_null"), ("layer-0 tap", r0, "l0"), ("layer-23 tap", r23, "l23")):
+        _drift.check(f"G11 {what}", val, _drift.table("g11", key))
 
 
 def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -95,7 +98,8 @@ def test_metric_batch_sampler_vs_reference_golden(gpu_device, golden_dir, full_d
     r = _rel(out, ref)
     per = [_rel(out[i], ref[i]) for i in range(B)]
     print(f"metric-batch sampler (B=8, 3 steps, CFG 7 + APG): rel L2 vs reference fp32 = {r:.3e}; per item max {max(per):.3e}")
-    assert r < 1e-2 and max(per) < 1.2e-2, (r, per)  # measured 4.0e-3 / 4.0e-3
+    _drift.check("G12 all songs", r, _drift.table("g12", "out"))   # measured 4.0e-3
+    _drift.check("G12 worst song", max(per), _drift.table("g12", "per_song_max"))
 
 
 def test_a_song_does_not_depend_on_its_batch_in_the_shape_independent_mode(gpu_device, golden_dir, full_dit_seed4):
@@ -133,7 +137,7 @@ def test_a_song_does_not_depend_on_its_batch_in_the_shape_independent_mode(gpu_d
     r = _rel(all8, ref)
     print(f"shape-independent mode (B=8, 3 steps): vs reference fp32 {r:.3e}; 8 == 4+4: {torch.equal(all8, halves)}, == 2+2+2+2: {torch.equal(all8, pairs)}, "
           f"songs 0 / 5 / 7 alone == inside the batch: {torch.equal(singles, all8[[0, 5, 7]])}; default policy: song 5 alone vs in the batch {_rel(fast1, fast8[5:6]):.3e}")
-    assert r < 1e-2, r
+    _drift.check("G12 in the shape-independent mode", r, _drift.table("g12", "out"))
     assert torch.equal(all8, halves) and torch.equal(all8, pairs) and torch.equal(singles, all8[[0, 5, 7]])
 
 
@@ -158,7 +162,9 @@ def test_metric_batch_sampler_norm_fold_on_off(gpu_device, golden_dir, full_dit_
     r_on, r_off, r_ab = _rel(outs[True], ref), _rel(outs[False], ref), _rel(outs[True], outs[False])
     print(f"norm fold: on vs reference {r_on:.3e}, off vs reference {r_off:.3e}, on vs off {r_ab:.3e}")
     assert torch.isfinite(outs[True]).all()
-    assert r_on < 1e-2 and r_off < 1e-2 and r_ab < 6e-3, (r_on, r_off, r_ab)
+    _drift.check("G12 folded norms", r_on, _drift.table("g12", "out"))
+    _drift.check("G12 norms as kernels", r_off, _drift.table("g12", "out"))
+    assert r_ab < 6e-3, r_ab   # (native vs native)
     assert not torch.equal(outs[True], outs[False])  # the two paths really are different launch sequences
 
 
@@ -220,7 +226,9 @@ def test_dual_chain_sampler_contract(gpu_device, golden_dir, full_dit_seed4):
     print(f"dual-chain sampler (B=8, 3 steps): two chains vs reference fp32 {r_d:.3e}, one chain vs reference {r_s:.3e}, two chains vs one {r_ds:.3e}; "
           f"two chains == one-chain calls on the half-batches: {torch.equal(dual, halves)} (B=8), {torch.equal(d5, s5)} (B=5), {torch.equal(d2, s2)} (B=2)")
     assert torch.equal(dual, halves) and torch.equal(d5, s5) and torch.equal(d2, s2)
-    assert r_d < 1e-2 and r_s < 1e-2 and r_ds < 6e-3, (r_d, r_s, r_ds)
+    _drift.check("G12 two sampler chains", r_d, _drift.table("g12", "out"))
+    _drift.check("G12 one sampler chain", r_s, _drift.table("g12", "out"))
+    assert r_ds < 6e-3, r_ds   # (native vs native)
 
 
 def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -247,7 +255,9 @@ def test_full_schedule_sampler_vs_reference_golden(gpu_device, golden_dir, full_
         dit.set_norm_fold(True)
     print(f"full-schedule sampler (B=3, 27 steps, CFG 7 + APG) vs reference fp32: folded {res[True][0]:.3e} (per item max {res[True][1]:.3e}), "
           f"norms as kernels {res[False][0]:.3e} (per item max {res[False][1]:.3e})")
-    assert res[True][0] < GATE_G15 and res[False][0] < GATE_G15, res
+    for fold in (True, False):   # measured 3.47e-3 (folded and unfolded alike)
+        _drift.check(f"G15 fold {fold}", res[fold][0], _drift.table("g15", "out"))
+        _drift.check(f"G15 fold {fold}, worst song", res[fold][1], _drift.table("g15", "per_song_max"))
 
 
 def test_bench_request_sampler_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4):
@@ -275,7 +285,9 @@ def test_bench_request_sampler_vs_reference_golden(gpu_device, golden_dir, full_
         dit.set_norm_fold(True)
     print(f"bench-request sampler (B=8, 27 steps, CFG 7 + APG) vs reference fp32: folded {res[True][0]:.3e} (per item max {res[True][1]:.3e}), "
           f"norms as kernels {res[False][0]:.3e} (per item max {res[False][1]:.3e})")
-    assert res[True][0] < GATE_G15 and res[False][0] < GATE_G15, res
+    for fold in (True, False):   # measured 3.48e-3
+        _drift.check(f"G16 (the bench's request) fold {fold}", res[fold][0], _drift.table("g16", "out"))
+        _drift.check(f"G16 fold {fold}, worst song", res[fold][1], _drift.table("g16", "per_song_max"))
 
 
 @pytest.mark.parametrize("B", [1, 2])
@@ -295,7 +307,8 @@ def test_small_batch_request_vs_reference_golden(gpu_device, golden_dir, full_di
     b = generate_latents(dit, null, enc.expand(B, -1, -1), ctx1.expand(B, -1, -1).contiguous(), **kw)["target_latents"].cpu()
     r = _rel(a, ref)
     print(f"batch-{B} request (27 steps, CFG 7 + APG) vs the reference's items of G16: rel L2 {r:.3e}")
-    assert torch.isfinite(a).all() and r < GATE_G15, r
+    assert torch.isfinite(a).all()
+    _drift.check(f"first {B} song(s) of G16 as their own request", r, _drift.slice_drift("g16", B))
     assert torch.equal(a, b), "same request twice must be bit-identical"
 
 
@@ -345,12 +358,15 @@ def test_120s_forward_vs_reference_golden_and_batch16(gpu_device, golden_dir, fu
     print(f"120 s forward: N=2 vs reference {r2:.3e} (layer-23 tap {r23:.3e}); inside N=16 (attn3_kernel<8>) vs reference {r16:.3e}, "
           f"vs the N=2 run {rx:.3e} (K rotation mode {krot}), {rxn:.3e} with the rotation off ({_rel(v2n, ref):.3e} vs the reference)")
     assert torch.isfinite(v16).all()
-    assert r2 < 1.5e-2 and r16 < 1.5e-2 and r23 < 1.2e-2, (r2, r16, r23)  # measured 5.9e-3, 5.9e-3, 4.2e-3
+    _drift.check("G13 pair alone", r2, _drift.table("g13", "v"))   # measured 5.9e-3, 5.9e-3, 4.2e-3
+    _drift.check("G13 pair inside N = 16", r16, _drift.table("g13", "v"))
+    _drift.check("G13 layer-23 tap", r23, _drift.table("g13", "l23"))
     # The default K rotation and the key-split attention kernel of the 96-row launches sum
     # in an order that depends on the launch shape: 3.2e-3 between the two runs, both at the reference's distance; with mode 0 the two
     # runs agree exactly (measured 0.0).
     assert rx < (5e-3 if krot else 2e-3), rx
-    assert rxn == 0.0 and _rel(v2n, ref) < 1.5e-2, rxn
+    assert rxn == 0.0, rxn
+    _drift.check("G13 pair, K rotation off", _rel(v2n, ref), _drift.table("g13", "v"))
     assert _rel(v16[2], v16[3]) > 0.3  # other seeds really are other songs
 
 
@@ -371,7 +387,8 @@ def test_240s_forward_vs_reference_golden(gpu_device, golden_dir, full_dit_seed4
     assert torch.equal(v, dit.forward(torch.cat([x1, x1]), ctx1.expand(2, -1, -1).contiguous(), [t, t], [t, t], [0, 1])), "not bit-reproducible"
     r = _rel(v, torch.from_numpy(G["v"]))
     print(f"240 s forward (N=2, T=6000): rel L2 vs reference fp32 = {r:.3e}")
-    assert torch.isfinite(v).all() and r < 1.5e-2, r
+    assert torch.isfinite(v).all()
+    _drift.check("G14 (240 s)", r, _drift.table("g14", "v"))
 
 
 @pytest.mark.parametrize("name,T,B,steps,precision", [

@@ -186,7 +186,11 @@ def test_request_chain_cond_encoder_to_sampler_to_vae(gpu_device):
     n_lat = generate_latents(dit, null, n_enc, ctx, **kw)["target_latents"]
     r = _rel(n_lat.cpu(), o_lat)
     print(f"encoder -> sampler chain: latents rel L2 vs the oracle chain {r:.3e}")
-    assert r < 2e-2, r
+    # twice the drift of the oracle CHAIN when both of its stages store weights / contraction operands in bf16 (measured 1.70e-3)
+    e_enc, _m = _drift.emulated(o_cond.condition_encoder, o_cond.CondConfig(**tiny, text_hidden_dim=64, timbre_hidden_dim=64, num_lyric_encoder_hidden_layers=2,
+                                                                          num_timbre_encoder_hidden_layers=2), cw, text, tmask, lyric, lmask, refer, order)
+    e_lat = _drift.emulated(o_sampler.generate_audio, o_dit.DitConfig(**tiny, num_hidden_layers=2), dw, null, e_enc, ctx, **kw)
+    _drift.check("encoder -> sampler chain", r, _rel(e_lat, o_lat))
     vcfg = ace355.VaeConfig()
     vw = weightgen.make_vae_weights(vcfg.weight_shapes(), seed=34, mode="init")
     vae = NativeVae(vcfg, gpu_device)

@@ -52,6 +52,8 @@ def test_tiny_forward_vs_reference_golden(gpu_device, golden_dir, case):
     emu = _drift.emulated(o_dit.dit_forward, o_dit.DitConfig(**TINY, sliding_window=window), w, x, t, t, enc, ctx)
     print(f"tiny forward case {case}: rel L2 vs reference fp32 = {r:.3e}; vs the oracle with bf16 storage {_rel(v, emu):.3e}")
     _drift.check(f"tiny forward {case}", r, _rel(emu, ref))   # measured 3.13e-3 against a drift of 3.12e-3
+    # ... and the HIP forward is several times closer to the oracle at ITS storage precision than either is to fp32 (measured 6.0e-4 - 7.6e-4)
+    assert _rel(v, emu) < 0.5 * _rel(emu, ref), (_rel(v, emu), _rel(emu, ref))
     assert abs(_rel(emu, ref) / _drift.table(f"g2/{case}", "v") - 1) < 0.02   # ... which is also the table's entry for this case
     assert float((v.cpu() - ref).abs().max()) < 0.05 * float(ref.abs().max())
 

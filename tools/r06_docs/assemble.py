@@ -19,7 +19,7 @@ rep={
  '@@ATTNVAE@@': f"attention {r['attn_tflops']:.0f} TFLOP/s, {r['attn_ms_per_pass']:.1f} ms per pass (0.{int(r['attn_tflops']/2500*100):02d}); VAE conv {r['vae_conv_tflops']:.0f} TFLOP/s, {r['vae_conv_ms_per_pass']:.1f} ms (0.{int(r['vae_conv_tflops']/2500*100):02d})",
  '@@SMALL@@': f"{b[0]:.1f} / {b[1]:.1f} / {b[2]:.1f} / {b[3]:.1f} ms per request; {b1:.1f} ms; {c0:.1f} ms",
  '@@CPU@@': f"{cb['value']:.4f} songs/s on {cb['cores']} threads (DiT extrapolated from 3 forwards, decode from 16 frames); configs[0] in full: {cb['config0_full_run']['seconds']:.2f} s",
- '@@TESTS@@': f"{npass} GPU tests + smoke ({smoke}); 77 CPU tests",
+ '@@TESTS@@': f"{npass} GPU tests + smoke ({smoke}); 79 CPU tests",
  '@@SPEEDNOTE@@': f"{d['ms_per_step']:.1f} ms on this round's evidence box; the round's boxes gave 456-475 ms for the same library, as in round 5",
  '@@ATTNFRAC@@': f"{100*r['attn_ms_per_pass']/d['ms_per_step']:.0f} %",
 }

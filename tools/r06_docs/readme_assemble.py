@@ -22,7 +22,7 @@ weights of the real architecture.  Every row names the file that backs it; `prof
 | 1 / 2 / 3 / 4 songs per request (with decode) | {b[0]:.1f} / {b[1]:.1f} / {b[2]:.1f} / {b[3]:.1f} ms (one song DiT-only {b1:.1f} ms; configs[0] {c0:.1f} ms) | `profiles/{TAG}_b*_line.json`, `{TAG}_cfg0_line.json` |
 | MXFP8 mode (`bench.py --fp8`; tolerance stated in DESIGN.md section 11: 4.3e-2, not a bf16-parity mode) | 21.5-22.6 songs/s (round 4-5 boxes) | `profiles/r05/` |
 | CPU oracle on the same box ("port", 16 threads) | {d['cpu_baseline']['value']:.4f} songs/s; configs[0] in full {d['cpu_baseline']['config0_full_run']['seconds']:.2f} s | bench line `cpu_baseline` |
-| Tests | {npass} GPU (+ smoke), 79 CPU; every parity value printed with the drift its gate is twice of | `profiles/{TAG}_gpu_pytest_measured.log`, `profiles/r06_gates_pytest.log` |
+| Tests | {npass} GPU (+ smoke), 79 CPU; every parity value printed with the drift its gate is twice of | `profiles/{TAG}_gpu_pytest_measured.log` |
 | Multi-GPU | one process per GPU, one broadcast per request, contiguous song slices, no per-step collective; two-rank success path tested on one GPU (gloo); RCCL with > 1 rank has not run on hardware | `tests/test_dist_gpu.py`, `tests/test_dist_cpu.py`, DESIGN.md sections 8 / 14.2 |
 
 Reproducibility: the same request gives the same bits (round 6 found the one launch for which that was not true - two faults in how 16x16x32 MFMAs were

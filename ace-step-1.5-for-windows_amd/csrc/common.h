@@ -150,6 +150,13 @@ struct GemmEpilogue {
     // dual-chain sampler (dit.hip) runs two independent launch sequences on two hardware queues and shapes every launch of both for 128
     // CUs, so that the chains run side by side instead of interleaving workgroups over all 256 (round 4: 512 -> 473 ms per 8-song pass)
     int cu_slots;
+    // Weight prefetch for the NEXT GEMM of the caller's sequence (round 6, small requests; set by the caller through gemm_prefetch_plan, all
+    // zero = none): a launch that leaves CUs without a tile carries `pf_x` extra workgroups per XCD that read, and throw away, the W rows the
+    // next launch's workgroups ON THAT XCD will stream - [xj * pf_chunk16, + pf_chunk16) in 16-byte units, xj = the XCD's column region in the
+    // next launch's XCD grid (8 / pf_xcd_n x pf_xcd_n) - so that they sit in that XCD's L2 when the next launch starts.
+    const void* pf_w;
+    unsigned pf_chunk16, pf_total16, pf_len16;   // (pf_len16 <= pf_chunk16: how much of a region is read - an L2 holds 4 MB)
+    int pf_xcd_n, pf_x;
     // a_zero_idx > 0: row a_zero_idx of A (counted from the A pointer, >= M) exists and is all zeros: the rows a tile pads beyond M read IT
     // instead of repeating row M - 1.  The padded rows' MFMAs are wasted either way (M = 6000 on 192-row tiles: 2.4 % of all of them); on
     // zeros the matrix pipe switches next to nothing for them, and under the power cap that energy comes back as clock.
@@ -160,6 +167,9 @@ struct GemmEpilogue {
 };
 int gemm_set_k_rotation(int mode);   // ace355_gemm_set_k_rotation; returns the previous mode
 int gemm_k_rotation_mode();          // the current mode (0: launch-shape-independent summation orders, also honoured by launch_attention)
+// Fills ep->pf_* for a following launch_gemm(.., M, N, K, mode ..) whose weight matrix is W (row stride K): the XCD column regions that launch
+// will use (same tile / XCD-grid choice as launch_gemm makes).  Leaves ep untouched when that launch would not be one the prefetch helps.
+void gemm_prefetch_plan(GemmEpilogue* ep, const void* W, int M, int N, int K, int mode, int cu_slots);
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep, hipStream_t s);
 // MXFP8 operands: Aq / Wq fp8 e4m3 [M, K] / [N, K] (row stride = K bytes), scales as GemmEpilogue::mx_sa / mx_sw describe; same

@@ -160,6 +160,8 @@ struct ace355_dit {
         bool concurrent = false;      // the answer for the current call's stream
         long calls = 0;               // sampler calls that ran as two chains (tests)
     } dual;
+    bool pf_block = false;   // set by ace355_dit_sample around a two-chain call: the other chain's launches want the CUs a prefetch would take
+    struct { const void* w = nullptr; int M = 0, N = 0, K = 0, mode = 0; } pf_next;   // set by forward_core before a gemm(): the NEXT projection (weight prefetch)
     bool alias = false;      // this object is a chain context: weights, slots and rope tables belong to the owning handle
     int cu_slots = 0;        // GemmEpilogue::cu_slots / AttnArgs::cu_slots of this context's launches (0: the whole chip)
 
@@ -290,6 +292,10 @@ int gemm(ace355_dit* h, const bf16_t* A, int lda, const bf16_t* W, int ldw, void
     const bool side = h->fk.side && s == h->fk.side;
     e2.sk_cnt = side ? h->fk.sk_cnt : h->sk_cnt;
     e2.cu_slots = h->cu_slots;
+    if (h->pf_next.w) {   // the GEMM that follows this one in forward_core's sequence: its weight rows start towards the L2s now (GemmEpilogue::pf_*)
+        gemm_prefetch_plan(&e2, h->pf_next.w, h->pf_next.M, h->pf_next.N, h->pf_next.K, h->pf_next.mode, h->cu_slots);
+        h->pf_next.w = nullptr;
+    }
     // pad rows of the last row tile read the workspace's zero row (forward_core keeps row fwd_M of xn / ao / act zero)
     if (h->zr_on && h->zr_M == h->fwd_M && h->fwd_M >= M) {
         const struct { const bf16_t* base; int ld; } ops[3] = {{h->xn, h->D}, {h->ao, h->QD}, {h->act, h->F}};
@@ -587,11 +593,17 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
     rc = gemm(h, h->xin, 2 * h->cfg.in_channels, h->w_in, 2 * h->cfg.in_channels, h->h, D, M, D, 2 * h->cfg.in_channels, ep, s);
     if (rc) return rc;
 
+    // Weight prefetch of the one-song launches (gemm_prefetch_plan, gemm.hip): every projection tells its launch which projection follows
+    const bool pf_on = h->precision != ACE355_PRECISION_MXFP8 && !h->pf_block;
     RoctxRange r_fwd("ace355.dit_forward");
     for (int li = 0; li < h->NL; ++li) {
         RoctxRange r_layer("ace355.dit_layer");
         const LayerW& W = h->layers[li];
         const bool sliding = (h->cfg.sliding_layer_mask >> li) & 1ull;
+        // the projection that FOLLOWS the next gemm() call: its weight rows are prefetched by that launch's spare workgroups (gemm(): pf_next)
+        auto next_gemm = [&](const bf16_t* w, int m, int n, int k, int mode) {
+            if (pf_on && m > 0) { h->pf_next.w = w; h->pf_next.M = m; h->pf_next.N = n; h->pf_next.K = k; h->pf_next.mode = mode; }
+        };
         // ---- self attention (base.py:499-511)
         // Layer 0 of a CFG forward: the conditional and the null sequence of a song enter the decoder with the same latents, context and
         // timestep (x = cat([xt, xt]), base.py:1929) and differ only from the first cross-attention on - the reference computes the same
@@ -622,6 +634,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         }
         int vt_done = 0;   // small-M launches write V^T from the QKV epilogue (GemmEpilogue::vt_out): no transpose_v launch
         ep.vt_out = h->vt; ep.vt_ld = Sp; ep.vt_heads = h->KVH; ep.vt_done = &vt_done;
+        next_gemm(W.wo, M, D, QD, 2);
         if (mx_qkv) rc = gemm_mx(h, nullptr, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else if (mx_usable(h, W.mx_qkv, M, QKV, D, 4, QD, QD + KVD)) rc = gemm_mx(h, h->xn, D, W.mx_qkv, h->qkv, QKV, M, QKV, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wqkv, D, h->qkv, QKV, Mq, QKV, D, ep, s);
@@ -668,6 +681,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             ep.nf_gB = g_mlp; ep.nf_sqB = rowsq(li, 2);
         }
         if (dedup0) ep.a_wrap = Mc;   // rows of the null half read the conditional half's attention output
+        if (Mc > 0) next_gemm(W.wq_c, Mc, QD, D, 4); else next_gemm(W.wgu, M, 2 * F, D, 3);
         if (ao_is_mx) rc = gemm_mx(h, nullptr, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else if (mx_usable(h, W.mx_o, M, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_o, h->h, D, M, D, QD, ep, s);
         else rc = gemm(h, h->ao, QD, W.wo, QD, h->h, D, M, D, QD, ep, s);
@@ -686,6 +700,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
         ep.hn_wq = ep.hn_wk = W.qn_c, ep.hn_cos = ep.hn_sin = nullptr;
         ep.hn_q_cols = ep.hn_qk_cols = QD, ep.hn_eps = eps;
         if (fold) { ep.nc_rowsq = rowsq(li, 1); ep.nc_bias = nullptr; ep.nc_inv_d = inv_d; ep.nc_eps = eps; }
+        next_gemm(W.wo_c, Mc, D, QD, 2);
         if (mx_qc) rc = gemm_mx(h, nullptr, D, W.mx_qc, h->qkv, QD, Mc, QD, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wq_c, D, h->qkv, QD, Mc, QD, D, ep, s);
         if (rc) return rc;
@@ -719,6 +734,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = Mc;
             ep.nf_gA = ep.nf_gB = g_mlp; ep.nf_sqA = ep.nf_sqB = rowsq(li, 2);
         }
+        next_gemm(W.wgu, M, 2 * F, D, 3);
         if (cao_is_mx) rc = gemm_mx(h, nullptr, QD, W.mx_oc, h->h, D, Mc, D, QD, ep, s);
         else if (mx_cross && mx_usable(h, W.mx_oc, Mc, D, QD, 2)) rc = gemm_mx(h, h->ao, QD, W.mx_oc, h->h, D, Mc, D, QD, ep, s);
         else rc = gemm(h, h->ao, QD, W.wo_c, QD, h->h, D, Mc, D, QD, ep, s);
@@ -743,6 +759,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             ep.nc_rowsq = rowsq(li, 2); ep.nc_bias = nf.bias_gu + ((size_t)li * nf.rows + nf.step) * 2 * F;
             ep.nc_inv_d = inv_d; ep.nc_eps = eps;
         }
+        next_gemm(W.wdown, M, D, F, 2);
         if (mx_gu) rc = gemm_mx(h, nullptr, D, W.mx_gu, act_q ? (void*)h->aq : (void*)h->act, F, M, 2 * F, D, ep, s);
         else if (mx_usable(h, W.mx_gu, M, 2 * F, D, 3)) rc = gemm_mx(h, h->xn, D, W.mx_gu, h->act, F, M, 2 * F, D, ep, s);
         else rc = gemm(h, h->xn, D, W.wgu, D, h->act, F, M, 2 * F, D, ep, s);
@@ -752,6 +769,7 @@ int forward_core(ace355_dit* h, int N, int T, const int* slots, int temb_rows, h
             ep.nf_xg = h->xn; ep.nf_ldx = D; ep.nf_split = M;
             ep.nf_gA = ep.nf_gB = gs_p + (size_t)((li + 1) * 2 + 0) * 2 * D; ep.nf_sqA = ep.nf_sqB = rowsq(li + 1, 0);
         }
+        next_gemm(h->layers[(li + 1) % h->NL].wqkv, M, QKV, D, 4);
         if (act_q) rc = gemm_mx(h, nullptr, F, W.mx_down, h->h, D, M, D, F, ep, s, h->aq, h->as_);
         else if (mx_down) rc = gemm_mx(h, h->act, F, W.mx_down, h->h, D, M, D, F, ep, s);
         else rc = gemm(h, h->act, F, W.wdown, F, h->h, D, M, D, F, ep, s);
@@ -1289,9 +1307,11 @@ int ace355_dit_sample(ace355_dit* h, const float* xt0_dev, const float* ctx_dev,
         ace355_dit* h;
         ~CallState() {
             h->cu_slots = 0;
-            if (h->dual.ctx) h->dual.ctx->cu_slots = 0;
+            h->pf_block = false;
+            if (h->dual.ctx) { h->dual.ctx->cu_slots = 0; h->dual.ctx->pf_block = false; }
         }
     } call_state{h};
+    if (nchains == 2) h->pf_block = h->dual.ctx->pf_block = true;
     int rc;
     for (int k = 0; k < nchains; ++k) {
         ace355_dit* c = ctxs[k];

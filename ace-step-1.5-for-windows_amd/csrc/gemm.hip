@@ -871,6 +871,30 @@ __device__ __forceinline__ void wait_vmcnt() {
 // request (configs[0]: 64.1 vs 48.3 ms).  The K loop of those launches is bound by what ONE CU can pull through the L2 -> LDS DMA path
 // (32 KB per K step at ~70 GB/s = 0.46 us, the in-pass figure of DESIGN.md section 10), not by MFMA issue: a second wave group adds no
 // ingest bandwidth, and the two-stage rings it leaves room for (2 x 2 x 32 KB) hide less latency than this kernel's four stages.
+// GemmEpilogue::pf_*: workgroup `rank` of the pf_x prefetch workgroups of XCD `xcd` reads its share of the W rows the next launch's tiles on this
+// XCD will stream (column region xj of that launch's XCD grid) and discards them: plain 16-byte loads, eight in flight per lane, which leave
+// the lines in this XCD's L2.
+__device__ __noinline__ void gemm_prefetch_region(const void* pf_w, unsigned pf_chunk16, unsigned pf_total16, unsigned pf_len16, int pf_xcd_n, int pf_x, int xcd, int rank, int nthr) {
+    typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+    const int xi = xcd / pf_xcd_n, xj = xcd - xi * pf_xcd_n;
+    const unsigned long long base = (unsigned long long)xj * pf_chunk16;
+    if (base >= pf_total16) return;
+    const unsigned long long n = min((unsigned long long)pf_len16, (unsigned long long)pf_total16 - base);
+    const u32x4p* p = reinterpret_cast<const u32x4p*>(pf_w) + base;
+    const unsigned long long nt = (unsigned long long)pf_x * nthr;
+    unsigned long long i = (unsigned long long)rank * nthr + threadIdx.x;
+    unsigned acc = 0;
+    for (; i + 7 * nt < n; i += 8 * nt) {
+        u32x4p v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[i + u * nt];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].w;
+    }
+    for (; i < n; i += nt) acc ^= p[i].x;
+    if (acc == 0x9e3779b9u && rank == 0x7fffffff) asm volatile("s_nop 0" ::"v"(acc));   // (keeps the loads; never taken)
+}
+
 template <int MODE, int MT, int WNW, int NTW = 2, int PERS = 0, int NS = 2, int FP8 = 0>
 __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __restrict__ A0, int lda, const bf16_t* __restrict__ W0,
                                                           int ldw, void* __restrict__ Cv, int ldc, int M, int N, int K,
@@ -905,6 +929,13 @@ __global__ __launch_bounds__(WNW * 128, 2) void gemm_sp_kernel(const bf16_t* __r
         const int xcd = blockIdx.x & 7;
         const int xcd_n = 8 / xcd_m;
         const int rm = (tiles_m + xcd_m - 1) / xcd_m, rn = (tiles_n + xcd_n - 1) / xcd_n;  // region size in tiles
+        if constexpr (PERS == 0 && !FP8) {
+            // the workgroups behind the region's rm * rn slots (GemmEpilogue::pf_x per XCD) prefetch the NEXT launch's weight rows of this XCD
+            if (ep.pf_x > 0 && idx >= rm * rn) {
+                if (blockIdx.y == 0) gemm_prefetch_region(ep.pf_w, ep.pf_chunk16, ep.pf_total16, ep.pf_len16, ep.pf_xcd_n, ep.pf_x, xcd, idx - rm * rn, (int)blockDim.x);
+                return;
+            }
+        }
         const int xi = xcd / xcd_n, xj = xcd - xi * xcd_n;
         const int m_lo = xi * rm, n_lo = xj * rn;
         const int hm = min(rm, tiles_m - m_lo), hn = min(rn, tiles_n - n_lo);  // this region's extent (may be ragged / empty)
@@ -1519,6 +1550,19 @@ static int gemm_cu_slots(int hint = 0) {
     return v;
 }
 
+static int choose_xcd_m(int tiles_m, int tiles_n, int M, int N, int xcd_m_env) {
+    int xcd_m = 8;
+    double best = 1e30;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+        const int xn = 8 / xm;
+        if (xm > tiles_m || xn > tiles_n) continue;
+        const double cost = (double)xn * M + (double)xm * N;
+        if (cost < best) { best = cost; xcd_m = xm; }
+    }
+    if (xcd_m_env == 1 || xcd_m_env == 2 || xcd_m_env == 4 || xcd_m_env == 8) xcd_m = xcd_m_env;
+    return xcd_m;
+}
+
 template <int MODE>
 static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc,
                         int M, int N, int K, const GemmEpilogue& ep, int tiles_n, int nwg) {
@@ -1537,20 +1581,11 @@ static void launch_mode(int variant, int mt, int big, hipStream_t s, const bf16_
     }
     // XCD grid: minimise xcd_n*|A| + xcd_m*|W| = (8/xm) * M + xm * N (same K), over xm in {1,2,4,8}
     const int tiles_m = nwg / tiles_n;
-    int xcd_m = 8;
-    {
-        double best = 1e30;
-        for (int xm = 1; xm <= 8; xm *= 2) {
-            const int xn = 8 / xm;
-            if (xm > tiles_m || xn > tiles_n) continue;
-            const double cost = (double)xn * M + (double)xm * N;
-            if (cost < best) { best = cost; xcd_m = xm; }
-        }
-        if (xcd_m_env == 1 || xcd_m_env == 2 || xcd_m_env == 4 || xcd_m_env == 8) xcd_m = xcd_m_env;
-    }
+    const int xcd_m = choose_xcd_m(tiles_m, tiles_n, M, N, xcd_m_env);
     const int xcd_n = 8 / xcd_m;
     const int region = ((tiles_m + xcd_m - 1) / xcd_m) * ((tiles_n + xcd_n - 1) / xcd_n);
-    const dim3 grid(8 * region, ep.kparts > 1 ? ep.kparts : 1);
+    // (+ GemmEpilogue::pf_x prefetch workgroups per XCD behind the region's slots: launch_gemm cleared pf_x where they do not belong)
+    const dim3 grid(8 * (region + (ep.pf_x > 0 ? ep.pf_x : 0)), ep.kparts > 1 ? ep.kparts : 1);
     // one workgroup per CU at most: nothing but a deeper DMA pipeline hides the weight stream's HBM latency
     const int cus = gemm_cu_slots(ep.cu_slots), pers_x = cus / 8;   // persistent workgroups per XCD
     const bool deep = deep_env >= 0 ? deep_env != 0 : (long)nwg * (ep.kparts > 1 ? ep.kparts : 1) <= cus;
@@ -1601,6 +1636,72 @@ int gemm_set_k_rotation(int mode) {
     return prev;
 }
 
+struct TileChoice { int mt, bn, big; };
+static TileChoice choose_tile(int M, int N, int mode, int cu_hint, int variant) {
+    // Tile choice.  The kernel is L2->LDS bandwidth bound (ablation in DESIGN.md), so the biggest tile that still fills
+    // the chip wins: 192x256 (8 waves, 110 flop per staged byte) when it yields >= ~0.8 x 256 workgroups, else the
+    // 4-wave 128/192 x 128 tiles with the height that minimises (rounds of 512 resident workgroups) x rows.
+    int mt = 2, bn = BN;
+    int big = 0;  // 0: 4-wave 128/192x128 tiles, 1: 8-wave 192x256, 2: 8-wave 192x128
+    if (variant != 1) {
+        const long cus = gemm_cu_slots(cu_hint);
+        const long slots = 2 * cus;
+        const long tn128 = (N + 127) / 128;
+        const long t128 = (long)((M + 127) / 128) * tn128, t192 = (long)((M + 191) / 192) * tn128;
+        const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
+        if (c192 < c128) mt = 3;
+        static int bigenv = -1;
+        if (bigenv < 0) bigenv = env_int("ACE355_GEMM_BIG", 1);  // 0 never, 1 heuristic, 2 always
+        const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
+        // (>= 180 tiles: three quarters of the CUs with one 8-wave workgroup each beat the same work as 384 four-wave workgroups on 512
+        //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
+        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 * cus / 256 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
+        else if (mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 * cus / 256 && t192 <= 320 * cus / 256))) { mt = 3; bn = 128; big = 2; }
+    }
+    // One sequence's worth of rows (the conditional rows' cross-attention projections of a one-song request: M = 375 -> 48 workgroups of
+    // 128 x 128, each pulling 32 KB per K step through ONE CU's DMA path while 200 CUs idle): 64-row tiles double the workgroups and cut a
+    // K step to 24 KB (ACE355_GEMM_MT1=0 for A/B).  Only where the 128-row form leaves more than half of the chip without a workgroup.
+    if (variant != 1 && big == 0 && mode != 3) {
+        static int mt1_env = -1;
+        if (mt1_env < 0) mt1_env = env_int("ACE355_GEMM_MT1", 1);
+        const long cus = gemm_cu_slots(cu_hint);
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+        if (mt1_env && t128 * 2 <= cus && M > 64) mt = 1;
+    }
+    return TileChoice{mt, bn, big};
+}
+
+// GemmEpilogue::pf_* for a launch that PRECEDES launch_gemm(.., W, M, N, K, mode ..) in the caller's sequence (declared in common.h).
+// Where it pays (round 6, tools/r06_gemm_pf_ab*.sh, tools/r06_hot_cold_w*.py; one 30 s song, DiT only, same box): 135.2-135.7 -> 129.8-131.0 ms with
+// 16-32 prefetch workgroups per XCD and 1-4 MB read per XCD region (all within noise of each other; 2-8 workgroups make the prefetch the
+// launch's critical path: 145-208 ms); per launch the head-norm projections gain what a back-to-back repeat of the launch gains (QKV 26.8 ->
+// 23.1 us, cross-q 18.8 -> 15.1), the residual projections ~ 1 us, gate|up nothing (6.3 MB per XCD do not fit beside the running launch's
+// working set: left out).  Requests of two or more songs lose (187 -> 191 ms at one chain of two songs): one sequence's rows only.
+void gemm_prefetch_plan(GemmEpilogue* ep, const void* W, int M, int N, int K, int mode, int cu_slots) {
+    constexpr int PF_X = 24;            // prefetch workgroups per XCD
+    constexpr int PF_CAP_KB = 2048;     // bytes of a region that are read, per XCD (an L2 holds 4 MB)
+    constexpr int PF_MAX_ROWS = 800;    // token rows of the next launch (one 30 s song with its CFG copy: 750)
+    static int on = -1, xcd_m_env = 0;
+    if (on < 0) {
+        on = env_int("ACE355_GEMM_PF", 1);   // 0: no prefetch workgroups anywhere (A/B, tests)
+        xcd_m_env = env_int("ACE355_GEMM_XCDM", 0);
+    }
+    const int variant = gemm_variant();
+    if (!on || variant == 1 || !W || M > PF_MAX_ROWS || K % 8 || !(mode == 2 || mode == 4)) return;
+    const TileChoice tc = choose_tile(M, N, mode, cu_slots, variant);
+    const int tiles_n = (N + tc.bn - 1) / tc.bn, tiles_m = (M + tc.mt * 64 - 1) / (tc.mt * 64);
+    const int xcd_m = choose_xcd_m(tiles_m, tiles_n, M, N, xcd_m_env), xcd_n = 8 / xcd_m;
+    const int rn = (tiles_n + xcd_n - 1) / xcd_n;
+    const unsigned long long chunk16 = (unsigned long long)rn * tc.bn * K / 8, total16 = (unsigned long long)N * K / 8;
+    if (total16 >= (1ull << 32)) return;
+    ep->pf_w = W;
+    ep->pf_chunk16 = (unsigned)std::min(chunk16, total16);
+    ep->pf_total16 = (unsigned)total16;
+    ep->pf_len16 = (unsigned)std::min<unsigned long long>(ep->pf_chunk16, (unsigned long long)PF_CAP_KB * 64ull);
+    ep->pf_xcd_n = xcd_n;
+    ep->pf_x = PF_X;
+}
+
 int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int ldc, int M, int N, int K,
                 const GemmEpilogue& ep_in, hipStream_t s) {
     GemmEpilogue ep = ep_in;
@@ -1629,36 +1730,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
     ACE_CHECK(ep.mode != 3 || (N % 64) == 0, "gemm: swiglu needs N % 64 == 0");
     ACE_CHECK(ep.mode != 2 || !ep.g1 || ep.rows_per_seq > 0, "gemm: rows_per_seq must be > 0");
     const int variant = gemm_variant();
-    // Tile choice.  The kernel is L2->LDS bandwidth bound (ablation in DESIGN.md), so the biggest tile that still fills
-    // the chip wins: 192x256 (8 waves, 110 flop per staged byte) when it yields >= ~0.8 x 256 workgroups, else the
-    // 4-wave 128/192 x 128 tiles with the height that minimises (rounds of 512 resident workgroups) x rows.
-    int mt = 2, bn = BN;
-    int big = 0;  // 0: 4-wave 128/192x128 tiles, 1: 8-wave 192x256, 2: 8-wave 192x128
-    if (variant != 1) {
-        const long cus = gemm_cu_slots(ep.cu_slots);
-        const long slots = 2 * cus;
-        const long tn128 = (N + 127) / 128;
-        const long t128 = (long)((M + 127) / 128) * tn128, t192 = (long)((M + 191) / 192) * tn128;
-        const long c128 = ((t128 + slots - 1) / slots) * 128, c192 = ((t192 + slots - 1) / slots) * 192;
-        if (c192 < c128) mt = 3;
-        static int bigenv = -1;
-        if (bigenv < 0) bigenv = env_int("ACE355_GEMM_BIG", 1);  // 0 never, 1 heuristic, 2 always
-        const long tbig = (long)((M + 191) / 192) * ((N + 255) / 256);
-        // (>= 180 tiles: three quarters of the CUs with one 8-wave workgroup each beat the same work as 384 four-wave workgroups on 512
-        //  slots - the SwiGLU projection of a batch-1 request, M = 750: 38.5 vs 42.4 us, round 3)
-        if (bigenv == 2 || (bigenv == 1 && tbig >= 180 * cus / 256 && (N % 256 == 0 || N >= 1024))) { mt = 3; bn = 256; big = 1; }
-        else if (ep.mode != 3 && (bigenv == 3 || (bigenv == 1 && t192 >= 200 * cus / 256 && t192 <= 320 * cus / 256))) { mt = 3; bn = 128; big = 2; }
-    }
-    // One sequence's worth of rows (the conditional rows' cross-attention projections of a one-song request: M = 375 -> 48 workgroups of
-    // 128 x 128, each pulling 32 KB per K step through ONE CU's DMA path while 200 CUs idle): 64-row tiles double the workgroups and cut a
-    // K step to 24 KB (ACE355_GEMM_MT1=0 for A/B).  Only where the 128-row form leaves more than half of the chip without a workgroup.
-    if (variant != 1 && big == 0 && ep.mode != 3) {
-        static int mt1_env = -1;
-        if (mt1_env < 0) mt1_env = env_int("ACE355_GEMM_MT1", 1);
-        const long cus = gemm_cu_slots(ep.cu_slots);
-        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-        if (mt1_env && t128 * 2 <= cus && M > 64) mt = 1;
-    }
+    const TileChoice tc = choose_tile(M, N, ep.mode, ep.cu_slots, variant);
+    const int mt = tc.mt, bn = tc.bn, big = tc.big;
     // (Slab split-K - K cut over blockIdx.y for EVERY mode, partial accumulators parked in an XCD's L2 and reduced by the last part - was built in
     //  round 3, measured slower than the deep pipeline it competes with (157.4 vs 149.9 ms per one-song request) and removed in round 6:
     //  tools/r06_slab_splitk.patch)
@@ -1708,6 +1781,8 @@ int launch_gemm(const bf16_t* A, int lda, const bf16_t* W, int ldw, void* C, int
                                 al16(ep.nf_gA) && al16(ep.nf_gB)), "gemm: folded-norm producer arguments");
         ACE_CHECK(!ep.nc_rowsq || ((ep.mode == 0 || ep.mode == 3 || ep.mode == 4) && al16(ep.nc_bias)), "gemm: folded-norm consumer arguments");
     }
+    // prefetch workgroups for the next launch's weights (GemmEpilogue::pf_*) ride only on launches that leave CUs without a tile
+    if (ep.pf_x > 0 && (variant == 1 || !ep.pf_w || (long)nwg * ep.kparts > gemm_cu_slots(ep.cu_slots))) ep.pf_x = 0;
     switch (ep.mode) {
         case 0: launch_mode<0>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;
         case 1: launch_mode<1>(variant, mt, big, s, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_n, nwg); break;

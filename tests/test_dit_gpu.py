@@ -221,7 +221,7 @@ def test_zero_row_and_tile64_switches_keep_the_bits(gpu_device):
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for name, env in (("base", {}), ("zrow0", {"ACE355_GEMM_ZROW": "0"}), ("mt1_0", {"ACE355_GEMM_MT1": "0"})):
+        for name, env in (("base", {}), ("zrow0", {"ACE355_GEMM_ZROW": "0"}), ("mt1_0", {"ACE355_GEMM_MT1": "0"}), ("pf0", {"ACE355_GEMM_PF": "0"})):
             path = os.path.join(d, name + ".pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, (name, r.stderr[-3000:])
@@ -229,6 +229,9 @@ def test_zero_row_and_tile64_switches_keep_the_bits(gpu_device):
     r_m = _rel(outs["mt1_0"], outs["base"])
     print(f"zero row on vs off: equal = {torch.equal(outs['zrow0'], outs['base'])}; 64-row tiles on vs off: {r_m:.3e}")
     assert torch.equal(outs["zrow0"], outs["base"])
+    # ACE355_GEMM_PF=0: no launch carries prefetch workgroups for the next projection's weights (round 6; a one-song request has them by default):
+    # they read and discard - the same bits
+    assert torch.equal(outs["pf0"], outs["base"]), "the weight prefetch changed a result"
     assert r_m < 2e-3, r_m
 
 

@@ -32,8 +32,8 @@ song's low bits follow the batch it runs in (~3e-3 relative L2, both at the refe
 bit for bit the same, for + 6 % of time per request at one song per GPU, under 1 % at two to four, + 2 % at eight (DESIGN.md section 14.2 / 14.4).
 
 What is slow and why (DESIGN.md sections 5, 12-14): the big GEMMs sit at the chip's power cap (changes that removed waiting did not move the pass, changes that
-removed energy did); attention (9 % of the pass) runs at 0.20 of the MFMA peak with its softmax and MFMA phases in step; one-song requests are bound by the
-per-layer launch structure (0.18 of the peak).  The round-by-round story is in DESIGN.md sections 7 and 12-14 and Appendix A.
+removed energy did); attention (9 % of the pass) runs at 0.20 of the MFMA peak with its softmax and MFMA phases in step; one-song requests are bound by cold weights
+(3.15 GB per forward through 4 MB L2s; the next projection's rows are prefetched into the right L2 by spare workgroups since round 6: - 4 %) and the per-layer launch structure (0.19 of the peak).  The round-by-round story is in DESIGN.md sections 7 and 12-14 and Appendix A.
 '''
 open(f'{ROOT}/README.md','w').write(head+status)
 print(len(head+status))
